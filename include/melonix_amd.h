@@ -1,0 +1,190 @@
+/*
+ * melonix_amd.h — C-ABI boundary of the MI355X-native melonix hot path.
+ *
+ * This is the drop-in boundary: plain C types, opaque handles, caller-allocated
+ * outputs, int status codes (0 = ok, negative = error; text via mx_last_error()).
+ * No C++ types, no exceptions and no torch types cross it.  The C++ facade in
+ * melonix_amd/cpp/ (Spec, SpecCache, saveWav — the reference's own class
+ * surface) and every parity test / bench call through these entry points.
+ *
+ * Each entry point names the reference interface it replaces; file:line are
+ * relative to the reference tree (mika314/melonix @ 2025-05-23).
+ *
+ * Device layout of an mx_audio (HBM): [MX_AUDIO_PAD zeros][n samples f32][MX_AUDIO_PAD zeros]
+ * so that a frame [end-N, end) that straddles either end of the file reads
+ * zeros exactly like spec.cpp:50-54 without per-sample bounds checks.
+ */
+#ifndef MELONIX_AMD_H
+#define MELONIX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MX_OK 0
+#define MX_ERR_INVALID (-1)  /* bad argument */
+#define MX_ERR_DEVICE (-2)   /* HIP runtime error / no MI355X visible */
+#define MX_ERR_NOMEM (-3)
+#define MX_ERR_IO (-4)
+
+#define MX_AUDIO_PAD 32768 /* samples of zero padding either side (>= largest N) */
+
+typedef struct mx_ctx mx_ctx;     /* one per GPU / per process rank */
+typedef struct mx_audio mx_audio; /* device-resident mono f32 audio */
+
+/* Per-frame pitch record (build-defined op, SURVEY §8 a-6: the reference has no
+ * detector; note law from app.cpp:499-516). */
+typedef struct mx_pitch {
+  int32_t bin; /* argmax_k mag[k], k in [kmin,kmax], ties -> lowest k */
+  float mag;   /* mag[bin] */
+} mx_pitch;
+
+/* marker.hpp:4-9 */
+typedef struct mx_marker {
+  int32_t sample;
+  double note;
+  double dTime;
+  double pitchBend;
+} mx_marker;
+
+/* One App::process() call of the export loop (app.cpp:294-345), precomputed. */
+typedef struct mx_step {
+  double cursor;       /* warped time at entry (app.cpp:1201-1206) */
+  int32_t grain_start; /* key of the chosen grain = first source sample (app.cpp:298-301) */
+  int32_t grain_len;   /* grain.size() */
+  float rate;          /* powf(2, pitchBend/12) (app.cpp:297) */
+  float next_first;    /* nextGrainFirstSample (app.cpp:312-329) */
+  int32_t sz;          /* samples this step emits (app.cpp:332-343) */
+  int32_t _pad;
+  int64_t out_offset;  /* exclusive prefix sum of sz = position in the PCM stream */
+} mx_step;
+
+/* ---- context ------------------------------------------------------------ */
+
+/* device: HIP ordinal.  Fails with MX_ERR_DEVICE when no gfx950 device is usable. */
+int mx_ctx_create(int device, mx_ctx **out);
+void mx_ctx_destroy(mx_ctx *ctx);
+/* A new context launches on its own non-blocking stream.  mx_ctx_set_stream makes it launch on a
+ * caller-owned hipStream_t instead (e.g. torch's current stream; NULL = the HIP null stream);
+ * mx_ctx_use_own_stream switches back. */
+int mx_ctx_set_stream(mx_ctx *ctx, void *hip_stream);
+int mx_ctx_use_own_stream(mx_ctx *ctx);
+int mx_ctx_synchronize(mx_ctx *ctx);
+/* Tuning knob: consecutive frames one workgroup walks (0 = per-N default). */
+int mx_ctx_set_frames_per_block(mx_ctx *ctx, int frames);
+/* Thread-local description of the last error returned on this thread. */
+const char *mx_last_error(void);
+/* "melonix_amd <version> gfx950" */
+const char *mx_version(void);
+
+/* ---- audio ---------------------------------------------------------------
+ * Replaces Spec::Spec(std::span<float> wav) borrowing App::wavData
+ * (spec.cpp:10-16, app.cpp:251): the samples are copied to HBM once. */
+int mx_audio_upload(mx_ctx *ctx, const float *host_wav, int64_t n, mx_audio **out);
+/* Zero-copy: wrap a device buffer already laid out [PAD zeros][n][PAD zeros]
+ * (d_padded points at the first pad sample).  The caller keeps ownership. */
+int mx_audio_wrap_device(mx_ctx *ctx, const float *d_padded, int64_t n, mx_audio **out);
+int64_t mx_audio_length(const mx_audio *a);
+int mx_audio_free(mx_ctx *ctx, mx_audio *a);
+
+/* ---- STFT magnitude spectrogram + pitch pick -------------------------------
+ * Replaces Spec::internalGetSpec (spec.cpp:44-66) with SpectrSize (spec.cpp:8)
+ * generalised to N in {4096, 16384, 32768}: frame = samples [end-N, end),
+ * one-sided exponential window expf(-2.5e-4f*(start-i)) left of `start`,
+ * zeros outside the file, |DFT|/N for bins 0..N/2-1.
+ *
+ * kmin/kmax: pitch-pick band (inclusive, clamped to [0, N/2-1]); pass -1,-1
+ * for the default band (notes 24..84 = 55..1760 Hz) at 48 kHz; for any other
+ * sample rate pass the bins mx_pitch_band() returns.
+ */
+
+/* Default pitch band for (N, sampleRate): kmin=ceil(55*N/sr), kmax=floor(1760*N/sr). */
+void mx_pitch_band(int N, int sampleRate, int *kmin, int *kmax);
+
+/* Arbitrary (start,end) pairs — the drop-in mode: one call drains a whole
+ * batch of Spec::getSpec jobs (spec.cpp:18-42, 68-97).  ranges = count x {start,end}
+ * (host).  mags_out = count x N/2 f32 (host, may be NULL); pitch_out = count
+ * records (host, may be NULL).  Blocks until the results are in host memory. */
+int mx_stft_ranges(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges, int64_t count,
+                   int kmin, int kmax, float *mags_out, mx_pitch *pitch_out);
+
+/* Uniform hop — the bulk mode: frame h in [first_frame, first_frame+count) is
+ * (start,end) = (h*hop, (h+1)*hop), i.e. the UI's column indexing
+ * (spec-cache.cpp:12,63-65) with an identity time map and `hop` samples per pixel.
+ * Host outputs as above; blocks. */
+int mx_stft_hop(mx_ctx *ctx, const mx_audio *a, int N, int hop, int64_t first_frame, int64_t count,
+                int kmin, int kmax, float *mags_out, mx_pitch *pitch_out);
+
+/* Same, outputs stay in HBM (d_mags: count x N/2 f32, d_pitch: count records;
+ * either may be NULL).  Asynchronous on the ctx stream. */
+int mx_stft_hop_dev(mx_ctx *ctx, const mx_audio *a, int N, int hop, int64_t first_frame,
+                    int64_t count, int kmin, int kmax, float *d_mags, mx_pitch *d_pitch);
+int mx_stft_ranges_dev(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *d_ranges,
+                       int64_t count, int kmin, int kmax, float *d_mags, mx_pitch *d_pitch);
+
+/* Fused colormap (SpecCache::populateTex, spec-cache.cpp:77-96): magnitudes
+ * * k -> clamp -> 3-segment RGB8, rgb_out = count x N/2 x 3 bytes (host). */
+int mx_stft_ranges_rgb(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges, int64_t count,
+                       float k, uint8_t *rgb_out);
+
+/* Number of frames of the bulk indexing: ceil(n / hop). */
+int64_t mx_frame_count(int64_t n, int hop);
+
+/* ---- time maps (host, cold-cache pure functions of the marker list) -------
+ * Replace App::sample2Time / time2Sample / time2PitchBend / duration
+ * (app.cpp:1020-1122).  markers must be sorted by sample. */
+double mx_sample2time(const mx_marker *markers, int nmarkers, int sampleRate, int val);
+int mx_time2sample(const mx_marker *markers, int nmarkers, int sampleRate, double val);
+double mx_duration(const mx_marker *markers, int nmarkers, int sampleRate, int64_t nsamples);
+float mx_time2pitchbend(const mx_marker *markers, int nmarkers, int sampleRate, int64_t nsamples,
+                        double val);
+/* SpecCache::getTex key + populateTex range (spec-cache.cpp:12, 63-65). */
+void mx_column_range(const mx_marker *markers, int nmarkers, int sampleRate, double time,
+                     int screenWidth, double rangeTime, int *key, int *start, int *end);
+
+/* ---- grains + resynthesis schedule ------------------------------------------
+ * mx_grains replaces the grain scan of App::preproc (app.cpp:153-235).
+ * starts/lens are library-allocated (free with mx_free). */
+int mx_grains(const float *host_wav, int64_t n, int32_t **starts, int32_t **lens, int64_t *count);
+/* Device version: zero-crossing predicates evaluated on the GPU from the
+ * resident audio; same outputs. */
+int mx_grains_dev(mx_ctx *ctx, const mx_audio *a, int32_t **starts, int32_t **lens, int64_t *count);
+
+/* Replays the cursor recurrence of App::exportWav / App::process
+ * (app.cpp:1200-1207, 294-331) on the host: one mx_step per process() call that
+ * finds a grain.  *nsamples = sum(sz) + 1500 (the terminating call appends
+ * preferredGrainSize zeros, app.cpp:303-309).  steps is library-allocated. */
+int mx_schedule_build(const float *host_wav, int64_t n, int sampleRate, const int32_t *grain_starts,
+                      const int32_t *grain_lens, int64_t ngrains, const mx_marker *markers,
+                      int nmarkers, mx_step **steps, int64_t *nsteps, int64_t *nsamples);
+void mx_free(void *p);
+
+/* Gather-lerp resampler + float->int16 (app.cpp:332-343, 1209-1212) over a
+ * precomputed schedule.  pcm_f32_out / pcm_i16_out: nsamples each (host, either
+ * may be NULL).  Bit-exact vs the reference arithmetic (no FMA contraction). */
+int mx_resynth(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nsteps,
+               int64_t nsamples, float *pcm_f32_out, int16_t *pcm_i16_out);
+/* Device-resident variant: d_steps / outputs in HBM, asynchronous. */
+int mx_resynth_dev(mx_ctx *ctx, const mx_audio *a, const mx_step *d_steps, int64_t nsteps,
+                   int64_t nsamples, float *d_pcm_f32, int16_t *d_pcm_i16);
+
+/* Whole App::exportWav (app.cpp:1194-1215): grains -> schedule -> GPU resynth
+ * -> int16 -> saveWav.  strict_reference_header!=0 reproduces save-wav.cpp:43. */
+int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate,
+                  const mx_marker *markers, int nmarkers, const char *path,
+                  int strict_reference_header);
+
+/* ---- WAV writer -------------------------------------------------------------
+ * Replaces saveWav (save-wav.cpp:17-48).  strict_reference_header != 0
+ * reproduces the size-field quirk of save-wav.cpp:43 byte for byte (data size
+ * = 2m+16, PCM samples 0 and 1 zeroed); 0 writes a correct RIFF header. */
+int mx_save_wav(const char *path, const int16_t *pcm, int64_t m, int sampleRate,
+                int strict_reference_header);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MELONIX_AMD_H */

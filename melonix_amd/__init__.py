@@ -1,0 +1,211 @@
+"""melonix_amd — MI355X-native (gfx950) implementation of the melonix frame-parallel
+DSP hot path: exponentially-windowed STFT magnitude spectrogram + pitch pick
+(reference spec.cpp / spec-cache.cpp) and the marker-driven granular pitch-shift
+resynthesis (reference app.cpp:153-345, 1194-1215) that feeds saveWav.
+
+The product is libmelonix_amd.so (hand-written HIP kernels behind the C-ABI of
+include/melonix_amd.h) plus the C++ drop-in facade under melonix_amd/cpp/.
+This Python package is only the test/bench harness around that library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import MX_AUDIO_PAD, PITCH_DTYPE, STEP_DTYPE, MxError  # noqa: F401
+
+__all__ = ["Context", "Audio", "MxError", "pitch_band", "frame_count", "grains_host", "schedule_build",
+           "save_wav", "column_range", "time2sample", "sample2time", "time2pitchbend", "duration"]
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def pitch_band(N: int, sr: int = 48000):
+    a, b = C.c_int(), C.c_int()
+    _capi.lib().mx_pitch_band(N, sr, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def frame_count(n: int, hop: int) -> int:
+    return _capi.lib().mx_frame_count(n, hop)
+
+
+class Audio:
+    def __init__(self, ctx: "Context", handle, n: int, keepalive=None):
+        self.ctx, self.handle, self.n, self._keep = ctx, handle, n, keepalive
+
+    def free(self):
+        if self.handle:
+            _capi.lib().mx_audio_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per GPU / rank (mx_ctx)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        _capi.check(_capi.lib().mx_ctx_create(device, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            _capi.lib().mx_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: int | None):
+        """Launch on this hipStream_t (0/None = the HIP null stream, torch's default stream)."""
+        _capi.check(_capi.lib().mx_ctx_set_stream(self.handle, C.c_void_p(hip_stream or 0)))
+
+    def use_own_stream(self):
+        _capi.check(_capi.lib().mx_ctx_use_own_stream(self.handle))
+
+    def set_frames_per_block(self, g: int):
+        _capi.check(_capi.lib().mx_ctx_set_frames_per_block(self.handle, g))
+
+    def synchronize(self):
+        _capi.check(_capi.lib().mx_ctx_synchronize(self.handle))
+
+    # ---- audio ----
+    def upload(self, wav) -> Audio:
+        wav = np.ascontiguousarray(wav, dtype=np.float32)
+        h = C.c_void_p()
+        _capi.check(_capi.lib().mx_audio_upload(self.handle, _ptr(wav), len(wav), C.byref(h)))
+        return Audio(self, h, len(wav))
+
+    def wrap_device(self, d_padded_ptr: int, n: int, keepalive=None) -> Audio:
+        h = C.c_void_p()
+        _capi.check(_capi.lib().mx_audio_wrap_device(self.handle, C.c_void_p(d_padded_ptr), n, C.byref(h)))
+        return Audio(self, h, n, keepalive)
+
+    # ---- STFT, host outputs ----
+    def stft_hop(self, audio: Audio, N: int, hop: int, first: int = 0, count: int | None = None, band=(-1, -1),
+                 want_mags: bool = True, want_pitch: bool = True):
+        if count is None:
+            count = frame_count(audio.n, hop) - first
+        mags = np.empty((count, N // 2), dtype=np.float32) if want_mags else None
+        pitch = np.empty(count, dtype=PITCH_DTYPE) if want_pitch else None
+        _capi.check(_capi.lib().mx_stft_hop(self.handle, audio.handle, N, hop, first, count, band[0], band[1],
+                                            _ptr(mags), _ptr(pitch)))
+        return mags, pitch
+
+    def stft_ranges(self, audio: Audio, N: int, ranges, band=(-1, -1), want_mags: bool = True,
+                    want_pitch: bool = True):
+        ranges = np.ascontiguousarray(ranges, dtype=np.int32).reshape(-1, 2)
+        count = len(ranges)
+        mags = np.empty((count, N // 2), dtype=np.float32) if want_mags else None
+        pitch = np.empty(count, dtype=PITCH_DTYPE) if want_pitch else None
+        _capi.check(_capi.lib().mx_stft_ranges(self.handle, audio.handle, N, _ptr(ranges), count, band[0], band[1],
+                                               _ptr(mags), _ptr(pitch)))
+        return mags, pitch
+
+    # ---- STFT, device-resident outputs (raw device pointers, async on the ctx stream) ----
+    def stft_hop_dev(self, audio: Audio, N: int, hop: int, first: int, count: int, d_mags: int | None,
+                     d_pitch: int | None, band=(-1, -1)):
+        _capi.check(_capi.lib().mx_stft_hop_dev(self.handle, audio.handle, N, hop, first, count, band[0], band[1],
+                                                C.c_void_p(d_mags or 0), C.c_void_p(d_pitch or 0)))
+
+    def stft_ranges_dev(self, audio: Audio, N: int, d_ranges: int, count: int, d_mags: int | None,
+                        d_pitch: int | None, band=(-1, -1)):
+        _capi.check(_capi.lib().mx_stft_ranges_dev(self.handle, audio.handle, N, C.c_void_p(d_ranges), count,
+                                                   band[0], band[1], C.c_void_p(d_mags or 0),
+                                                   C.c_void_p(d_pitch or 0)))
+
+    # ---- grains / resynthesis ----
+    def grains_dev(self, audio: Audio):
+        s, l, cnt = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.c_int64()
+        _capi.check(_capi.lib().mx_grains_dev(self.handle, audio.handle, C.byref(s), C.byref(l), C.byref(cnt)))
+        return _take_i32(s, cnt.value), _take_i32(l, cnt.value)
+
+    def resynth(self, audio: Audio, steps, nsamples: int, want_f32: bool = True, want_i16: bool = True):
+        steps = np.ascontiguousarray(steps, dtype=STEP_DTYPE)
+        f32 = np.empty(nsamples, dtype=np.float32) if want_f32 else None
+        i16 = np.empty(nsamples, dtype=np.int16) if want_i16 else None
+        _capi.check(_capi.lib().mx_resynth(self.handle, audio.handle, _ptr(steps), len(steps), nsamples, _ptr(f32),
+                                           _ptr(i16)))
+        return f32, i16
+
+    def resynth_dev(self, audio: Audio, d_steps: int, nsteps: int, nsamples: int, d_f32: int | None,
+                    d_i16: int | None):
+        _capi.check(_capi.lib().mx_resynth_dev(self.handle, audio.handle, C.c_void_p(d_steps), nsteps, nsamples,
+                                               C.c_void_p(d_f32 or 0), C.c_void_p(d_i16 or 0)))
+
+    def export_wav(self, wav, sr: int, markers, path: str, strict: bool = True):
+        wav = np.ascontiguousarray(wav, dtype=np.float32)
+        m = _capi.markers_array(markers)
+        _capi.check(_capi.lib().mx_export_wav(self.handle, _ptr(wav), len(wav), sr, m, len(markers),
+                                              str(path).encode(), 1 if strict else 0))
+
+
+def _take_i32(p, cnt):
+    out = np.ctypeslib.as_array(p, shape=(max(cnt, 1),))[:cnt].astype(np.int32, copy=True)
+    _capi.lib().mx_free(p)
+    return out
+
+
+# ---- host-side entry points (no GPU needed) ----
+def grains_host(wav):
+    wav = np.ascontiguousarray(wav, dtype=np.float32)
+    s, l, cnt = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.c_int64()
+    _capi.check(_capi.lib().mx_grains(_ptr(wav), len(wav), C.byref(s), C.byref(l), C.byref(cnt)))
+    return _take_i32(s, cnt.value), _take_i32(l, cnt.value)
+
+
+def schedule_build(wav, sr: int, starts, lens, markers):
+    """-> (steps structured array, nsamples)"""
+    wav = np.ascontiguousarray(wav, dtype=np.float32)
+    starts = np.ascontiguousarray(starts, dtype=np.int32)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    m = _capi.markers_array(markers)
+    p, ns, tot = C.POINTER(_capi.Step)(), C.c_int64(), C.c_int64()
+    _capi.check(_capi.lib().mx_schedule_build(_ptr(wav), len(wav), sr, _ptr(starts), _ptr(lens), len(starts), m,
+                                              len(markers), C.byref(p), C.byref(ns), C.byref(tot)))
+    steps = np.frombuffer(C.string_at(p, ns.value * C.sizeof(_capi.Step)), dtype=STEP_DTYPE).copy() if ns.value \
+        else np.zeros(0, STEP_DTYPE)
+    _capi.lib().mx_free(p)
+    return steps, tot.value
+
+
+def save_wav(path, pcm16, sr: int, strict: bool = True):
+    pcm16 = np.ascontiguousarray(pcm16, dtype=np.int16)
+    _capi.check(_capi.lib().mx_save_wav(str(path).encode(), _ptr(pcm16), len(pcm16), sr, 1 if strict else 0))
+
+
+def sample2time(markers, sr, val):
+    return _capi.lib().mx_sample2time(_capi.markers_array(markers), len(markers), sr, int(val))
+
+
+def time2sample(markers, sr, val):
+    return _capi.lib().mx_time2sample(_capi.markers_array(markers), len(markers), sr, float(val))
+
+
+def duration(markers, sr, n):
+    return _capi.lib().mx_duration(_capi.markers_array(markers), len(markers), sr, int(n))
+
+
+def time2pitchbend(markers, sr, n, val):
+    return _capi.lib().mx_time2pitchbend(_capi.markers_array(markers), len(markers), sr, int(n), float(val))
+
+
+def column_range(markers, sr, time, width, range_time):
+    k, s, e = C.c_int(), C.c_int(), C.c_int()
+    _capi.lib().mx_column_range(_capi.markers_array(markers), len(markers), sr, float(time), int(width),
+                                float(range_time), C.byref(k), C.byref(s), C.byref(e))
+    return k.value, s.value, e.value

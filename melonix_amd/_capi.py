@@ -1,0 +1,114 @@
+"""ctypes binding of include/melonix_amd.h (the C-ABI of libmelonix_amd.so).
+
+Thin by design: every function maps 1:1 onto a C entry point.  There is no
+Python/numpy implementation of any transform here — if the shared library is
+missing the import fails loudly, and every transform needs a live gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmelonix_amd.so")
+
+MX_OK = 0
+MX_ERR_INVALID, MX_ERR_DEVICE, MX_ERR_NOMEM, MX_ERR_IO = -1, -2, -3, -4
+MX_AUDIO_PAD = 32768
+
+
+class MxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"melonix_amd error {code}: {msg}")
+        self.code = code
+
+
+class Pitch(C.Structure):
+    _fields_ = [("bin", C.c_int32), ("mag", C.c_float)]
+
+
+class Marker(C.Structure):
+    _fields_ = [("sample", C.c_int32), ("note", C.c_double), ("dTime", C.c_double), ("pitchBend", C.c_double)]
+
+
+class Step(C.Structure):
+    _fields_ = [("cursor", C.c_double), ("grain_start", C.c_int32), ("grain_len", C.c_int32), ("rate", C.c_float),
+                ("next_first", C.c_float), ("sz", C.c_int32), ("_pad", C.c_int32), ("out_offset", C.c_int64)]
+
+
+PITCH_DTYPE = np.dtype([("bin", "<i4"), ("mag", "<f4")])
+STEP_DTYPE = np.dtype([("cursor", "<f8"), ("grain_start", "<i4"), ("grain_len", "<i4"), ("rate", "<f4"),
+                       ("next_first", "<f4"), ("sz", "<i4"), ("_pad", "<i4"), ("out_offset", "<i8")])
+assert PITCH_DTYPE.itemsize == C.sizeof(Pitch) and STEP_DTYPE.itemsize == C.sizeof(Step)
+
+# name -> (restype, argtypes); kept in the order of include/melonix_amd.h
+_vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+_pi32 = C.POINTER(C.c_int32)
+SIGNATURES = {
+    "mx_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "mx_ctx_destroy": (None, [_vp]),
+    "mx_ctx_set_stream": (_i, [_vp, _vp]),
+    "mx_ctx_use_own_stream": (_i, [_vp]),
+    "mx_ctx_synchronize": (_i, [_vp]),
+    "mx_ctx_set_frames_per_block": (_i, [_vp, _i]),
+    "mx_last_error": (C.c_char_p, []),
+    "mx_version": (C.c_char_p, []),
+    "mx_audio_upload": (_i, [_vp, _vp, _i64, C.POINTER(_vp)]),
+    "mx_audio_wrap_device": (_i, [_vp, _vp, _i64, C.POINTER(_vp)]),
+    "mx_audio_length": (_i64, [_vp]),
+    "mx_audio_free": (_i, [_vp, _vp]),
+    "mx_pitch_band": (None, [_i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "mx_stft_ranges": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp]),
+    "mx_stft_hop": (_i, [_vp, _vp, _i, _i, _i64, _i64, _i, _i, _vp, _vp]),
+    "mx_stft_hop_dev": (_i, [_vp, _vp, _i, _i, _i64, _i64, _i, _i, _vp, _vp]),
+    "mx_stft_ranges_dev": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp]),
+    "mx_stft_ranges_rgb": (_i, [_vp, _vp, _i, _vp, _i64, _f, _vp]),
+    "mx_frame_count": (_i64, [_i64, _i]),
+    "mx_sample2time": (_d, [_vp, _i, _i, _i]),
+    "mx_time2sample": (_i, [_vp, _i, _i, _d]),
+    "mx_duration": (_d, [_vp, _i, _i, _i64]),
+    "mx_time2pitchbend": (_f, [_vp, _i, _i, _i64, _d]),
+    "mx_column_range": (None, [_vp, _i, _i, _d, _i, _d, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "mx_grains": (_i, [_vp, _i64, C.POINTER(_pi32), C.POINTER(_pi32), C.POINTER(_i64)]),
+    "mx_grains_dev": (_i, [_vp, _vp, C.POINTER(_pi32), C.POINTER(_pi32), C.POINTER(_i64)]),
+    "mx_schedule_build": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i, C.POINTER(C.POINTER(Step)),
+                               C.POINTER(_i64), C.POINTER(_i64)]),
+    "mx_free": (None, [_vp]),
+    "mx_resynth": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "mx_resynth_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "mx_export_wav": (_i, [_vp, _vp, _i64, _i, _vp, _i, C.c_char_p, _i]),
+    "mx_save_wav": (_i, [C.c_char_p, _vp, _i64, _i, _i]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Loads libmelonix_amd.so.  Raises if it has not been built — there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m melonix_amd.build` (hipcc, gfx950). "
+                "melonix_amd has no CPU/Python compute path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int) -> None:
+    if rc != MX_OK:
+        raise MxError(rc, (lib().mx_last_error() or b"").decode(errors="replace"))
+
+
+def markers_array(markers):
+    arr = (Marker * max(1, len(markers)))()
+    for i, m in enumerate(markers):
+        arr[i] = Marker(int(m[0]), float(m[1]), float(m[2]), float(m[3]))
+    return arr

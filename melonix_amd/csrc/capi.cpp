@@ -1,0 +1,612 @@
+// capi.cpp — implementation of the C-ABI boundary declared in
+// include/melonix_amd.h.  Built by hipcc into libmelonix_amd.so together with
+// the gfx950 kernels.  There is no CPU compute path here: every transform
+// entry point needs a live gfx950 device and fails with MX_ERR_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/melonix_amd.h"
+#include "host_logic.h"
+#include "kernels.h"
+#include "stft_tables.h"
+
+using namespace mx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(MX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct NTables {
+  float2 *tw2 = nullptr, *tw3 = nullptr, *ubase = nullptr;
+};
+
+}  // namespace
+
+struct mx_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  float *wext = nullptr;  // d-indexed window weights
+  std::map<int, NTables> tables;
+  std::map<std::pair<int, int>, float *> wtabs;  // (N, hop) -> forward weights
+  std::vector<float> wext_host;
+  int frames_per_block = 0;  // 0 = per-N default
+  std::mutex mu;
+};
+
+struct mx_audio {
+  float *d_padded = nullptr;
+  int64_t n = 0;
+  bool owned = false;
+};
+
+namespace {
+
+int default_frames_per_block(int N) {
+  if (const char *e = getenv("MELONIX_FRAMES_PER_BLOCK")) {
+    const int v = atoi(e);
+    if (v > 0) return v;
+  }
+  return N == 4096 ? 16 : (N == 16384 ? 8 : 4);
+}
+
+template <int N>
+int build_tables(NTables &t) {
+  const auto tw2 = make_tw2<N>();
+  const auto tw3 = make_tw3<N>();
+  const auto ub = make_ubase<N>();
+  HIP_TRY(hipMalloc(&t.tw2, tw2.size() * sizeof(float2)));
+  HIP_TRY(hipMalloc(&t.tw3, tw3.size() * sizeof(float2)));
+  HIP_TRY(hipMalloc(&t.ubase, ub.size() * sizeof(float2)));
+  HIP_TRY(hipMemcpy(t.tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(t.tw3, tw3.data(), tw3.size() * sizeof(float2), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(t.ubase, ub.data(), ub.size() * sizeof(float2), hipMemcpyHostToDevice));
+  return MX_OK;
+}
+
+int get_tables(mx_ctx *ctx, int N, NTables &out) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto it = ctx->tables.find(N);
+  if (it != ctx->tables.end()) {
+    out = it->second;
+    return MX_OK;
+  }
+  NTables t;
+  int rc;
+  switch (N) {
+    case 4096: rc = build_tables<4096>(t); break;
+    case 16384: rc = build_tables<16384>(t); break;
+    case 32768: rc = build_tables<32768>(t); break;
+    default: return fail(MX_ERR_INVALID, "unsupported FFT size %d (supported: 4096, 16384, 32768)", N);
+  }
+  if (rc) return rc;
+  ctx->tables[N] = t;
+  out = t;
+  return MX_OK;
+}
+
+int get_wtab(mx_ctx *ctx, int N, int hop, const float **out) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const auto key = std::make_pair(N, hop);
+  auto it = ctx->wtabs.find(key);
+  if (it != ctx->wtabs.end()) {
+    *out = it->second;
+    return MX_OK;
+  }
+  const std::vector<float> w = make_wtab(N, hop, ctx->wext_host);
+  float *d = nullptr;
+  HIP_TRY(hipMalloc(&d, w.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(d, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+  ctx->wtabs[key] = d;
+  *out = d;
+  return MX_OK;
+}
+
+int check_common(mx_ctx *ctx, const mx_audio *a, int N, int64_t count, int &kmin, int &kmax) {
+  if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
+  if (N != 4096 && N != 16384 && N != 32768)
+    return fail(MX_ERR_INVALID, "unsupported FFT size %d (supported: 4096, 16384, 32768)", N);
+  if (count < 0) return fail(MX_ERR_INVALID, "negative frame count");
+  if (kmin < 0 && kmax < 0) mx_pitch_band(N, 48000, &kmin, &kmax);
+  kmin = std::max(kmin, 0);
+  kmax = std::min(kmax, N / 2 - 1);
+  if (kmin > kmax) return fail(MX_ERR_INVALID, "empty pitch band [%d,%d]", kmin, kmax);
+  return MX_OK;
+}
+
+int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_t first_frame,
+                const int32_t *d_ranges, int64_t count, int kmin, int kmax, float *d_mags,
+                mx_pitch *d_pitch, uint8_t *d_rgb, float cmap_k) {
+  NTables t;
+  int rc = get_tables(ctx, N, t);
+  if (rc) return rc;
+  StftArgs s{};
+  s.audio = a->d_padded;
+  s.n = a->n;
+  s.wext = ctx->wext;
+  s.tw2 = t.tw2;
+  s.tw3 = t.tw3;
+  s.ubase = t.ubase;
+  s.ranges = d_ranges;
+  s.hop = hop;
+  s.first_frame = first_frame;
+  s.count = count;
+  s.kmin = kmin;
+  s.kmax = kmax;
+  s.mags = d_mags;
+  s.pitch = d_pitch;
+  s.rgb = d_rgb;
+  s.cmap_k = cmap_k;
+  s.frames_per_block = ctx->frames_per_block > 0 ? ctx->frames_per_block : default_frames_per_block(N);
+  if (mode != kRanges) {
+    rc = get_wtab(ctx, N, hop, &s.wtab);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(launch_stft(N, mode, s, ctx->stream));
+  return MX_OK;
+}
+
+// frames per host-staging chunk: keep the device staging buffer <= ~1 GiB
+int64_t chunk_frames(int N) { return std::max<int64_t>(1, (int64_t)(1ull << 30) / ((int64_t)(N / 2) * 4)); }
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+const char *mx_last_error(void) { return g_err.c_str(); }
+const char *mx_version(void) { return "melonix_amd 0.1.0 gfx950"; }
+
+int mx_ctx_create(int device, mx_ctx **out) {
+  if (!out) return fail(MX_ERR_INVALID, "out is null");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(MX_ERR_DEVICE, "no HIP device visible (%s); melonix_amd has no CPU path",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(MX_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MX_ERR_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device,
+                prop.gcnArchName);
+  HIP_TRY(hipSetDevice(device));
+  mx_ctx *c = new (std::nothrow) mx_ctx();
+  if (!c) return fail(MX_ERR_NOMEM, "out of host memory");
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(MX_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  try {
+    c->wext_host = make_wext();
+  } catch (const std::bad_alloc &) {
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return fail(MX_ERR_NOMEM, "out of host memory");
+  }
+  e = hipMalloc(&c->wext, c->wext_host.size() * sizeof(float));
+  if (e == hipSuccess)
+    e = hipMemcpy(c->wext, c->wext_host.data(), c->wext_host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (c->wext) hipFree(c->wext);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return fail(MX_ERR_DEVICE, "uploading the window table: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return MX_OK;
+}
+
+void mx_ctx_destroy(mx_ctx *ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->tables) {
+    hipFree(kv.second.tw2);
+    hipFree(kv.second.tw3);
+    hipFree(kv.second.ubase);
+  }
+  for (auto &kv : ctx->wtabs) hipFree(kv.second);
+  hipFree(ctx->wext);
+  hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int mx_ctx_set_stream(mx_ctx *ctx, void *hip_stream) {
+  if (!ctx) return fail(MX_ERR_INVALID, "null context");
+  ctx->stream = (hipStream_t)hip_stream;  // NULL is the HIP null stream (torch's default stream)
+  return MX_OK;
+}
+
+int mx_ctx_use_own_stream(mx_ctx *ctx) {
+  if (!ctx) return fail(MX_ERR_INVALID, "null context");
+  ctx->stream = ctx->own_stream;
+  return MX_OK;
+}
+
+int mx_ctx_synchronize(mx_ctx *ctx) {
+  if (!ctx) return fail(MX_ERR_INVALID, "null context");
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MX_OK;
+}
+
+int mx_ctx_set_frames_per_block(mx_ctx *ctx, int g) {  // tuning knob (bench sweeps)
+  if (!ctx || g < 0) return fail(MX_ERR_INVALID, "bad argument");
+  ctx->frames_per_block = g;
+  return MX_OK;
+}
+
+// ---- audio ------------------------------------------------------------------
+int mx_audio_upload(mx_ctx *ctx, const float *host_wav, int64_t n, mx_audio **out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !host_wav)) return fail(MX_ERR_INVALID, "bad argument");
+  if (n > 0x7fffffffLL - 2 * MX_AUDIO_PAD)
+    return fail(MX_ERR_INVALID, "audio longer than the reference's int sample indices allow");
+  HIP_TRY(hipSetDevice(ctx->device));
+  mx_audio *a = new (std::nothrow) mx_audio();
+  if (!a) return fail(MX_ERR_NOMEM, "out of host memory");
+  const size_t total = (size_t)n + 2 * (size_t)MX_AUDIO_PAD;
+  hipError_t e = hipMalloc(&a->d_padded, total * sizeof(float));
+  if (e == hipSuccess) e = hipMemsetAsync(a->d_padded, 0, total * sizeof(float), ctx->stream);
+  if (e == hipSuccess && n > 0)
+    e = hipMemcpyAsync(a->d_padded + MX_AUDIO_PAD, host_wav, (size_t)n * sizeof(float), hipMemcpyHostToDevice,
+                       ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    if (a->d_padded) hipFree(a->d_padded);
+    delete a;
+    return fail(MX_ERR_DEVICE, "audio upload: %s", hipGetErrorString(e));
+  }
+  a->n = n;
+  a->owned = true;
+  *out = a;
+  return MX_OK;
+}
+
+int mx_audio_wrap_device(mx_ctx *ctx, const float *d_padded, int64_t n, mx_audio **out) {
+  if (!ctx || !out || !d_padded || n < 0) return fail(MX_ERR_INVALID, "bad argument");
+  mx_audio *a = new (std::nothrow) mx_audio();
+  if (!a) return fail(MX_ERR_NOMEM, "out of host memory");
+  a->d_padded = const_cast<float *>(d_padded);
+  a->n = n;
+  a->owned = false;
+  *out = a;
+  return MX_OK;
+}
+
+int64_t mx_audio_length(const mx_audio *a) { return a ? a->n : -1; }
+
+int mx_audio_free(mx_ctx *ctx, mx_audio *a) {
+  if (!a) return MX_OK;
+  if (a->owned) {
+    if (ctx) {
+      hipSetDevice(ctx->device);
+      hipStreamSynchronize(ctx->stream);
+    }
+    hipFree(a->d_padded);
+  }
+  delete a;
+  return MX_OK;
+}
+
+// ---- STFT ---------------------------------------------------------------------
+void mx_pitch_band(int N, int sampleRate, int *kmin, int *kmax) {
+  // notes 24..84 of the default view (app.hpp:45-46): f = 55*2^((note-24)/12), bin = f*N/sr (app.cpp:499-516)
+  const double lo = 55.0 * N / sampleRate, hi = 1760.0 * N / sampleRate;
+  int a = (int)lo;
+  if ((double)a < lo) ++a;
+  if (kmin) *kmin = a;
+  if (kmax) *kmax = (int)hi;
+}
+
+int64_t mx_frame_count(int64_t n, int hop) { return hop > 0 && n >= 0 ? (n + hop - 1) / hop : -1; }
+
+int mx_stft_hop_dev(mx_ctx *ctx, const mx_audio *a, int N, int hop, int64_t first_frame, int64_t count,
+                    int kmin, int kmax, float *d_mags, mx_pitch *d_pitch) {
+  int rc = check_common(ctx, a, N, count, kmin, kmax);
+  if (rc) return rc;
+  if (hop <= 0 || hop > MX_AUDIO_PAD) return fail(MX_ERR_INVALID, "hop %d out of range [1,%d]", hop, MX_AUDIO_PAD);
+  if (first_frame < 0 || (count > 0 && (first_frame + count - 1) * (int64_t)hop >= a->n))
+    return fail(MX_ERR_INVALID, "frames [%lld,%lld) exceed ceil(n/hop)", (long long)first_frame,
+                (long long)(first_frame + count));
+  return stft_launch(ctx, a, N, (hop % 2 == 0) ? kBulkAligned : kBulkAny, hop, first_frame, nullptr, count, kmin,
+                     kmax, d_mags, d_pitch, nullptr, 0.f);
+}
+
+int mx_stft_ranges_dev(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *d_ranges, int64_t count, int kmin,
+                       int kmax, float *d_mags, mx_pitch *d_pitch) {
+  int rc = check_common(ctx, a, N, count, kmin, kmax);
+  if (rc) return rc;
+  if (count > 0 && !d_ranges) return fail(MX_ERR_INVALID, "ranges is null");
+  return stft_launch(ctx, a, N, kRanges, 0, 0, d_ranges, count, kmin, kmax, d_mags, d_pitch, nullptr, 0.f);
+}
+
+static int stft_host_common(mx_ctx *ctx, const mx_audio *a, int N, bool ranges_mode, int hop, int64_t first_frame,
+                            const int32_t *ranges, int64_t count, int kmin, int kmax, float *mags_out,
+                            mx_pitch *pitch_out) {
+  int rc = check_common(ctx, a, N, count, kmin, kmax);
+  if (rc) return rc;
+  if (count == 0) return MX_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int64_t chunk = std::min<int64_t>(count, chunk_frames(N));
+  float *d_mags = nullptr;
+  mx_pitch *d_pitch = nullptr;
+  int32_t *d_ranges = nullptr;
+  const size_t row = (size_t)(N / 2);
+  hipError_t e = hipSuccess;
+  if (mags_out) e = hipMalloc(&d_mags, (size_t)chunk * row * sizeof(float));
+  if (e == hipSuccess && pitch_out) e = hipMalloc(&d_pitch, (size_t)chunk * sizeof(mx_pitch));
+  if (e == hipSuccess && ranges_mode) e = hipMalloc(&d_ranges, (size_t)chunk * 2 * sizeof(int32_t));
+  if (e != hipSuccess) {
+    hipFree(d_mags); hipFree(d_pitch); hipFree(d_ranges);
+    return fail(MX_ERR_NOMEM, "device staging buffers: %s", hipGetErrorString(e));
+  }
+  rc = MX_OK;
+  for (int64_t done = 0; done < count && rc == MX_OK; done += chunk) {
+    const int64_t c = std::min(chunk, count - done);
+    if (ranges_mode) {
+      e = hipMemcpyAsync(d_ranges, ranges + 2 * done, (size_t)c * 2 * sizeof(int32_t), hipMemcpyHostToDevice,
+                         ctx->stream);
+      if (e != hipSuccess) { rc = fail(MX_ERR_DEVICE, "ranges upload: %s", hipGetErrorString(e)); break; }
+      rc = mx_stft_ranges_dev(ctx, a, N, d_ranges, c, kmin, kmax, d_mags, d_pitch);
+    } else {
+      rc = mx_stft_hop_dev(ctx, a, N, hop, first_frame + done, c, kmin, kmax, d_mags, d_pitch);
+    }
+    if (rc) break;
+    if (mags_out)
+      e = hipMemcpyAsync(mags_out + (size_t)done * row, d_mags, (size_t)c * row * sizeof(float),
+                         hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && pitch_out)
+      e = hipMemcpyAsync(pitch_out + done, d_pitch, (size_t)c * sizeof(mx_pitch), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "result download: %s", hipGetErrorString(e));
+  }
+  hipFree(d_mags); hipFree(d_pitch); hipFree(d_ranges);
+  return rc;
+}
+
+int mx_stft_hop(mx_ctx *ctx, const mx_audio *a, int N, int hop, int64_t first_frame, int64_t count, int kmin,
+                int kmax, float *mags_out, mx_pitch *pitch_out) {
+  if (hop <= 0) return fail(MX_ERR_INVALID, "hop must be positive");
+  return stft_host_common(ctx, a, N, false, hop, first_frame, nullptr, count, kmin, kmax, mags_out, pitch_out);
+}
+
+int mx_stft_ranges(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges, int64_t count, int kmin, int kmax,
+                   float *mags_out, mx_pitch *pitch_out) {
+  if (count > 0 && !ranges) return fail(MX_ERR_INVALID, "ranges is null");
+  return stft_host_common(ctx, a, N, true, 0, 0, ranges, count, kmin, kmax, mags_out, pitch_out);
+}
+
+int mx_stft_ranges_rgb(mx_ctx *, const mx_audio *, int, const int32_t *, int64_t, float, uint8_t *) {
+  return fail(MX_ERR_INVALID, "mx_stft_ranges_rgb: fused colormap not built yet (SURVEY §8f row 1)");
+}
+
+// ---- time maps -----------------------------------------------------------------
+double mx_sample2time(const mx_marker *m, int nm, int sr, int val) { return TimeMap(m, nm, sr, 0).sample2time(val); }
+int mx_time2sample(const mx_marker *m, int nm, int sr, double val) { return TimeMap(m, nm, sr, 0).time2sample(val); }
+double mx_duration(const mx_marker *m, int nm, int sr, int64_t n) { return TimeMap(m, nm, sr, n).duration(); }
+float mx_time2pitchbend(const mx_marker *m, int nm, int sr, int64_t n, double val) {
+  return TimeMap(m, nm, sr, n).time2pitchbend(val);
+}
+void mx_column_range(const mx_marker *m, int nm, int sr, double time, int width, double rangeTime, int *key,
+                     int *start, int *end) {
+  const TimeMap tm(m, nm, sr, 0);
+  const int k = static_cast<int>(time * width / rangeTime);  // spec-cache.cpp:12
+  const double st = k * rangeTime / width;                   // spec-cache.cpp:63
+  const double pixelSize = rangeTime / width;                // spec-cache.cpp:64
+  if (key) *key = k;
+  if (start) *start = tm.time2sample(st);                    // spec-cache.cpp:65
+  if (end) *end = tm.time2sample(st + pixelSize);
+}
+
+// ---- grains + schedule -----------------------------------------------------------
+static int export_vectors(const std::vector<int32_t> &s, const std::vector<int32_t> &l, int32_t **starts,
+                          int32_t **lens, int64_t *count) {
+  const size_t n = s.size();
+  int32_t *ps = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(n, 1));
+  int32_t *pl = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(n, 1));
+  if (!ps || !pl) { free(ps); free(pl); return fail(MX_ERR_NOMEM, "out of host memory"); }
+  if (n) { memcpy(ps, s.data(), n * sizeof(int32_t)); memcpy(pl, l.data(), n * sizeof(int32_t)); }
+  *starts = ps; *lens = pl; *count = (int64_t)n;
+  return MX_OK;
+}
+
+int mx_grains(const float *host_wav, int64_t n, int32_t **starts, int32_t **lens, int64_t *count) {
+  if (!starts || !lens || !count || n < 0 || (n > 0 && !host_wav)) return fail(MX_ERR_INVALID, "bad argument");
+  try {
+    ZcBitmaps zc;
+    zc_bitmaps_host(host_wav, n, zc);
+    std::vector<int32_t> s, l;
+    grains_from_bitmaps(zc, s, l);
+    return export_vectors(s, l, starts, lens, count);
+  } catch (const std::bad_alloc &) {
+    return fail(MX_ERR_NOMEM, "out of host memory");
+  }
+}
+
+int mx_grains_dev(mx_ctx *ctx, const mx_audio *a, int32_t **starts, int32_t **lens, int64_t *count) {
+  if (!ctx || !a || !starts || !lens || !count) return fail(MX_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  try {
+    ZcBitmaps zc;
+    zc.n = a->n;
+    const size_t words = (size_t)((a->n + 63) >> 6);
+    zc.zc7.assign(words, 0);
+    zc.zc3.assign(words, 0);
+    if (words) {
+      uint64_t *d7 = nullptr, *d3 = nullptr;
+      HIP_TRY(hipMalloc(&d7, words * 8));
+      hipError_t e = hipMalloc(&d3, words * 8);
+      if (e == hipSuccess) e = launch_zc_bitmaps(a->d_padded, a->n, d7, d3, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(zc.zc7.data(), d7, words * 8, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(zc.zc3.data(), d3, words * 8, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      hipFree(d7);
+      hipFree(d3);
+      if (e != hipSuccess) return fail(MX_ERR_DEVICE, "zero-crossing bitmaps: %s", hipGetErrorString(e));
+    }
+    std::vector<int32_t> s, l;
+    grains_from_bitmaps(zc, s, l);
+    return export_vectors(s, l, starts, lens, count);
+  } catch (const std::bad_alloc &) {
+    return fail(MX_ERR_NOMEM, "out of host memory");
+  }
+}
+
+int mx_schedule_build(const float *host_wav, int64_t n, int sampleRate, const int32_t *grain_starts,
+                      const int32_t *grain_lens, int64_t ngrains, const mx_marker *markers, int nmarkers,
+                      mx_step **steps, int64_t *nsteps, int64_t *nsamples) {
+  if (!steps || !nsteps || !nsamples || n < 0 || ngrains < 0 || nmarkers < 0 || (n > 0 && !host_wav) ||
+      (ngrains > 0 && (!grain_starts || !grain_lens)) || (nmarkers > 0 && !markers))
+    return fail(MX_ERR_INVALID, "bad argument");
+  for (int64_t g = 0; g < ngrains; ++g)
+    if (grain_starts[g] < 0 || grain_lens[g] <= 0 || (int64_t)grain_starts[g] + grain_lens[g] > n)
+      return fail(MX_ERR_INVALID, "grain %lld lies outside the audio", (long long)g);
+  try {
+    std::vector<mx_step> v;
+    std::string err;
+    int64_t total = 0;
+    const int rc = build_schedule(host_wav, n, sampleRate, grain_starts, grain_lens, ngrains, markers, nmarkers, v,
+                                  total, err);
+    if (rc) return fail(rc, "%s", err.c_str());
+    mx_step *p = (mx_step *)malloc(sizeof(mx_step) * std::max<size_t>(v.size(), 1));
+    if (!p) return fail(MX_ERR_NOMEM, "out of host memory");
+    if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(mx_step));
+    *steps = p;
+    *nsteps = (int64_t)v.size();
+    *nsamples = total;
+    return MX_OK;
+  } catch (const std::bad_alloc &) {
+    return fail(MX_ERR_NOMEM, "out of host memory");
+  }
+}
+
+void mx_free(void *p) { free(p); }
+
+// ---- resynthesis -------------------------------------------------------------------
+int mx_resynth_dev(mx_ctx *ctx, const mx_audio *a, const mx_step *d_steps, int64_t nsteps, int64_t nsamples,
+                   float *d_pcm_f32, int16_t *d_pcm_i16) {
+  if (!ctx || !a || nsteps < 0 || nsamples < 0 || (nsteps > 0 && !d_steps))
+    return fail(MX_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  // trailing zeros of the terminating process() call: clear the last 1500 samples
+  // (they lie past every step's run; see mx_schedule_build)
+  const int64_t tail = std::min<int64_t>(nsamples, 1500);
+  if (tail > 0) {
+    if (d_pcm_f32) HIP_TRY(hipMemsetAsync(d_pcm_f32 + (nsamples - tail), 0, (size_t)tail * sizeof(float), ctx->stream));
+    if (d_pcm_i16) HIP_TRY(hipMemsetAsync(d_pcm_i16 + (nsamples - tail), 0, (size_t)tail * sizeof(int16_t), ctx->stream));
+  }
+  ResynthArgs r{};
+  r.audio = a->d_padded;
+  r.steps = d_steps;
+  r.nsteps = nsteps;
+  r.nsamples = nsamples;
+  r.pcm_f32 = d_pcm_f32;
+  r.pcm_i16 = d_pcm_i16;
+  HIP_TRY(launch_resynth(r, ctx->stream));
+  return MX_OK;
+}
+
+int mx_resynth(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nsteps, int64_t nsamples,
+               float *pcm_f32_out, int16_t *pcm_i16_out) {
+  if (!ctx || !a || nsteps < 0 || nsamples < 0 || (nsteps > 0 && !steps)) return fail(MX_ERR_INVALID, "bad argument");
+  int64_t covered = 0;
+  for (int64_t i = 0; i < nsteps; ++i) {
+    const mx_step &s = steps[i];
+    if (s.out_offset != covered || s.sz < 0 || s.grain_start < 0 || s.grain_len <= 0 ||
+        (int64_t)s.grain_start + s.grain_len > a->n)
+      return fail(MX_ERR_INVALID, "step %lld is inconsistent with the schedule invariants", (long long)i);
+    covered += s.sz;
+  }
+  if (covered > nsamples) return fail(MX_ERR_INVALID, "steps emit %lld samples, nsamples is %lld", (long long)covered,
+                                      (long long)nsamples);
+  HIP_TRY(hipSetDevice(ctx->device));
+  mx_step *d_steps = nullptr;
+  float *d_f = nullptr;
+  int16_t *d_i = nullptr;
+  hipError_t e = hipSuccess;
+  if (nsteps) e = hipMalloc(&d_steps, (size_t)nsteps * sizeof(mx_step));
+  if (e == hipSuccess && pcm_f32_out && nsamples) e = hipMalloc(&d_f, (size_t)nsamples * sizeof(float));
+  if (e == hipSuccess && pcm_i16_out && nsamples) e = hipMalloc(&d_i, (size_t)nsamples * sizeof(int16_t));
+  int rc = MX_OK;
+  if (e != hipSuccess) rc = fail(MX_ERR_NOMEM, "device buffers: %s", hipGetErrorString(e));
+  if (rc == MX_OK && nsteps)
+    if ((e = hipMemcpyAsync(d_steps, steps, (size_t)nsteps * sizeof(mx_step), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+      rc = fail(MX_ERR_DEVICE, "schedule upload: %s", hipGetErrorString(e));
+  if (rc == MX_OK) {
+    // anything between the covered run and the tail is zero by definition
+    if (d_f) hipMemsetAsync(d_f + covered, 0, (size_t)(nsamples - covered) * sizeof(float), ctx->stream);
+    if (d_i) hipMemsetAsync(d_i + covered, 0, (size_t)(nsamples - covered) * sizeof(int16_t), ctx->stream);
+    rc = mx_resynth_dev(ctx, a, d_steps, nsteps, nsamples, d_f, d_i);
+  }
+  if (rc == MX_OK) {
+    if (d_f) e = hipMemcpyAsync(pcm_f32_out, d_f, (size_t)nsamples * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && d_i)
+      e = hipMemcpyAsync(pcm_i16_out, d_i, (size_t)nsamples * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
+  }
+  hipFree(d_steps); hipFree(d_f); hipFree(d_i);
+  return rc;
+}
+
+int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate, const mx_marker *markers,
+                  int nmarkers, const char *path, int strict_reference_header) {
+  if (!ctx || !path || n < 0 || (n > 0 && !host_wav)) return fail(MX_ERR_INVALID, "bad argument");
+  mx_audio *a = nullptr;
+  int rc = mx_audio_upload(ctx, host_wav, n, &a);
+  if (rc) return rc;
+  int32_t *gs = nullptr, *gl = nullptr;
+  int64_t ng = 0, nsteps = 0, nsamples = 0;
+  mx_step *steps = nullptr;
+  int16_t *pcm = nullptr;
+  rc = mx_grains_dev(ctx, a, &gs, &gl, &ng);
+  if (rc == MX_OK) rc = mx_schedule_build(host_wav, n, sampleRate, gs, gl, ng, markers, nmarkers, &steps, &nsteps, &nsamples);
+  if (rc == MX_OK) {
+    pcm = (int16_t *)malloc(sizeof(int16_t) * (size_t)std::max<int64_t>(nsamples, 1));
+    if (!pcm) rc = fail(MX_ERR_NOMEM, "out of host memory");
+  }
+  if (rc == MX_OK) rc = mx_resynth(ctx, a, steps, nsteps, nsamples, nullptr, pcm);
+  if (rc == MX_OK) rc = mx_save_wav(path, pcm, nsamples, sampleRate, strict_reference_header);
+  free(pcm); mx_free(steps); mx_free(gs); mx_free(gl);
+  mx_audio_free(ctx, a);
+  return rc;
+}
+
+int mx_save_wav(const char *path, const int16_t *pcm, int64_t m, int sampleRate, int strict_reference_header) {
+  const int rc = write_wav(path, pcm, m, sampleRate, strict_reference_header != 0);
+  if (rc == MX_ERR_INVALID) return fail(rc, "bad argument");
+  if (rc == MX_ERR_IO) return fail(rc, "cannot write %s", path);
+  return rc;
+}
+
+}  // extern "C"

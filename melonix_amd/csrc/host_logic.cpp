@@ -1,0 +1,275 @@
+// host_logic.cpp — see host_logic.h.  Host-only C++17 (no HIP).
+#include "host_logic.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace mx {
+
+// ---------------------------------------------------------------------------
+// TimeMap
+// ---------------------------------------------------------------------------
+TimeMap::TimeMap(const mx_marker *markers, int nmarkers, int sampleRate, int64_t nsamples)
+    : sr_(sampleRate), n_(nsamples) {
+  int prevSample = 0;
+  double prevTime = 0.0;
+  double prevPitchBend = 0.0;
+  segs_.reserve((size_t)std::max(nmarkers, 0));
+  for (int m = 0; m < nmarkers; ++m) {
+    const mx_marker &mk = markers[m];
+    // same accumulation as the loop header of app.cpp:1035 / :1067 / :1102
+    const double rightTime = prevTime + 1.0 * (mk.sample - prevSample) / sampleRate + mk.dTime;
+    segs_.push_back(Seg{prevSample, mk.sample, prevTime, rightTime, prevPitchBend, mk.pitchBend});
+    prevSample = mk.sample;
+    prevTime = rightTime;
+    prevPitchBend = mk.pitchBend;
+  }
+  lastSample_ = prevSample;
+  lastTime_ = prevTime;
+  lastPitchBend_ = prevPitchBend;
+}
+
+double TimeMap::sample2time(int val) const {
+  if (val <= 0) return 1. * val / sr_;
+  for (const Seg &s : segs_)
+    if (val > s.prevSample && val <= s.sample)
+      return s.prevTime + (val - s.prevSample) * (s.rightTime - s.prevTime) / (s.sample - s.prevSample);
+  return lastTime_ + 1. * (val - lastSample_) / sr_;
+}
+
+int TimeMap::time2sample(double val) const {
+  if (val <= 0) return static_cast<int>(val * sr_);
+  for (const Seg &s : segs_)
+    if (val > s.prevTime && val <= s.rightTime)
+      return static_cast<int>(s.prevSample +
+                              (val - s.prevTime) * (s.sample - s.prevSample) / (s.rightTime - s.prevTime));
+  return static_cast<int>(lastSample_ + (val - lastTime_) * sr_);
+}
+
+double TimeMap::duration() const { return sample2time(static_cast<int>(n_ - 1)); }
+
+float TimeMap::time2pitchbend(double val) const {
+  if (val <= 0) return 0;
+  for (const Seg &s : segs_)
+    if (val > s.prevTime && val <= s.rightTime)
+      return static_cast<float>(s.prevPitchBend + (val - s.prevTime) * (s.pitchBend - s.prevPitchBend) /
+                                                      (s.rightTime - s.prevTime));
+  const double dur = duration();
+  if (val > dur) return 0;
+  return static_cast<float>(lastPitchBend_ + (val - lastTime_) * (0 - lastPitchBend_) / (dur - lastTime_));
+}
+
+// ---------------------------------------------------------------------------
+// Zero-crossing bitmaps + grain chain
+// ---------------------------------------------------------------------------
+namespace {
+// The reference's tests are "wav >= 0 -> reject" on the left and "wav < 0 ->
+// reject" on the right, so a NaN passes on both sides; keep that.
+inline bool left_ok(float x) { return !(x >= 0); }
+inline bool right_ok(float x) { return !(x < 0); }
+
+inline bool test_bit(const std::vector<uint64_t> &b, int64_t i) { return (b[(size_t)(i >> 6)] >> (i & 63)) & 1; }
+
+// first set bit in [lo, hi] or -1
+int64_t next_set(const std::vector<uint64_t> &b, int64_t nbits, int64_t lo, int64_t hi) {
+  if (lo < 0) lo = 0;
+  if (hi >= nbits) hi = nbits - 1;
+  if (lo > hi) return -1;
+  int64_t w = lo >> 6;
+  uint64_t cur = b[(size_t)w] & (~0ull << (lo & 63));
+  const int64_t wend = hi >> 6;
+  for (;;) {
+    if (cur) {
+      const int64_t p = (w << 6) + __builtin_ctzll(cur);
+      return p <= hi ? p : -1;
+    }
+    if (++w > wend) return -1;
+    cur = b[(size_t)w];
+  }
+}
+// last set bit in [lo, hi] or -1
+int64_t prev_set(const std::vector<uint64_t> &b, int64_t nbits, int64_t lo, int64_t hi) {
+  if (lo < 0) lo = 0;
+  if (hi >= nbits) hi = nbits - 1;
+  if (lo > hi) return -1;
+  int64_t w = hi >> 6;
+  const int sh = 63 - (int)(hi & 63);
+  uint64_t cur = b[(size_t)w] & (~0ull >> sh);
+  const int64_t wbeg = lo >> 6;
+  for (;;) {
+    if (cur) {
+      const int64_t p = (w << 6) + 63 - __builtin_clzll(cur);
+      return p >= lo ? p : -1;
+    }
+    if (--w < wbeg) return -1;
+    cur = b[(size_t)w];
+  }
+}
+}  // namespace
+
+void zc_bitmaps_host(const float *wav, int64_t n, ZcBitmaps &out) {
+  out.n = n;
+  const size_t words = (size_t)((n + 63) >> 6);
+  out.zc7.assign(words, 0);
+  out.zc3.assign(words, 0);
+  if (n < 8) return;
+  // rr[i] = length (capped at 7) of the run of right_ok samples starting at i
+  std::vector<uint8_t> rr((size_t)n + 1, 0);
+  for (int64_t i = n - 1; i >= 0; --i) {
+    const int nxt = rr[(size_t)i + 1];
+    rr[(size_t)i] = right_ok(wav[i]) ? (uint8_t)std::min(nxt + 1, 7) : 0;
+  }
+  int lrun = 0;  // run of left_ok samples ending at i (capped)
+  for (int64_t i = 0; i + 1 < n; ++i) {
+    lrun = left_ok(wav[i]) ? std::min(lrun + 1, 7) : 0;
+    const int r = rr[(size_t)i + 1];
+    // bounds of the lambdas: idx >= k and idx < (int)(n - k - 1)
+    if (lrun >= 7 && r >= 7 && i >= 7 && i < n - 7 - 1) out.zc7[(size_t)(i >> 6)] |= 1ull << (i & 63);
+    if (lrun >= 3 && r >= 3 && i >= 3 && i < n - 3 - 1) out.zc3[(size_t)(i >> 6)] |= 1ull << (i & 63);
+  }
+}
+
+void grains_from_bitmaps(const ZcBitmaps &zc, std::vector<int32_t> &starts, std::vector<int32_t> &lens) {
+  starts.clear();
+  lens.clear();
+  const int64_t n = zc.n;
+  constexpr int kPref = 1500;  // preferredGrainSize, app.cpp:19
+  if (n < kPref + 1) return;   // the reference's size_t arithmetic wraps below this (app.cpp:161)
+  int64_t start = 0;
+  while (start < n - kPref - 1) {
+    const int64_t c = start + kPref;
+    // candidates c, c, c+1, c-1, ... c+749, c-749 (app.cpp:164-166): nearest first, later index on ties
+    const int64_t up = next_set(zc.zc7, n, c, c + 749);
+    const int64_t dn = prev_set(zc.zc7, n, c - 749, c);
+    int64_t pick = -1;
+    if (up >= 0 && dn >= 0) pick = (up - c <= c - dn) ? up : dn;
+    else if (up >= 0) pick = up;
+    else if (dn >= 0) pick = dn;
+    if (pick < 0) {
+      // app.cpp:198-228: first lookAround-3 crossing at i >= start+2250, i < n-1
+      pick = next_set(zc.zc3, n, start + kPref + kPref / 2, n - 2);
+      if (pick < 0) break;
+    }
+    starts.push_back((int32_t)start);
+    lens.push_back((int32_t)(pick - start));
+    start = pick;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Export-loop recurrence
+// ---------------------------------------------------------------------------
+int64_t step_size(float rate, int32_t L) {
+  if (!(rate > 0.f) || !std::isfinite(rate) || L <= 0) return -1;
+  const float Lf = (float)L;  // exact: L < 2^24 for any grain the scan can produce
+  const double est = std::ceil((double)L / (double)rate);
+  if (!(est < 2147483000.0)) return -1;
+  int64_t i = (int64_t)est;
+  // x(i) = float(i) * rate in binary32, exactly the product of app.cpp:317 / :336 (bias == 0.f)
+  auto x = [rate](int64_t k) -> float {
+    volatile float p = (float)(int)k * rate;
+    return p;
+  };
+  while (i > 0 && x(i - 1) >= Lf) --i;
+  while (x(i) < Lf) {
+    if (++i >= 2147483000LL) return -1;
+  }
+  return i;  // indices 0..i-1 satisfy floor(x) < L
+}
+
+int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *gstarts,
+                   const int32_t *glens, int64_t ngrains, const mx_marker *markers, int nmarkers,
+                   std::vector<mx_step> &steps, int64_t &nsamples, std::string &err) {
+  steps.clear();
+  nsamples = 0;
+  if (sampleRate <= 0) { err = "sampleRate must be positive"; return MX_ERR_INVALID; }
+  for (int m = 1; m < nmarkers; ++m)
+    if (markers[m].sample < markers[m - 1].sample) { err = "markers must be sorted by sample"; return MX_ERR_INVALID; }
+  const TimeMap tm(markers, nmarkers, sampleRate, n);
+  const int32_t *gend = gstarts + ngrains;
+  steps.reserve((size_t)ngrains + 16);
+
+  double cursor = 0.;  // app.cpp:1201
+  for (;;) {
+    const float pitchBend = tm.time2pitchbend(cursor);
+    const float rate = powf(2, pitchBend / 12);  // app.cpp:297
+    const int32_t *it1 = std::lower_bound(gstarts, gend, tm.time2sample(cursor));  // app.cpp:298-301
+    if (it1 == gend) {
+      nsamples += 1500;  // app.cpp:303-309: preferredGrainSize zeros, then dt = 0 ends the export
+      break;
+    }
+    const int64_t g = it1 - gstarts;
+    const int64_t sz = step_size(rate, glens[g]);
+    if (sz <= 0) {
+      err = "pitch bend drives the resampling rate out of range (rate=" + std::to_string(rate) + ")";
+      return MX_ERR_INVALID;
+    }
+    const double dt = 1. * (int)sz / sampleRate;  // app.cpp:323 / :344
+    const int32_t *it2 = std::lower_bound(gstarts, gend, tm.time2sample(cursor + dt));
+    mx_step st;
+    st.cursor = cursor;
+    st.grain_start = gstarts[g];
+    st.grain_len = glens[g];
+    st.rate = rate;
+    st.next_first = (it2 == gend) ? 0.f : wav[*it2];  // app.cpp:325-328
+    st.sz = (int32_t)sz;
+    st._pad = 0;
+    st.out_offset = nsamples;
+    steps.push_back(st);
+    nsamples += sz;
+    if (dt <= 0.) break;  // app.cpp:1204
+    cursor += dt;         // app.cpp:1206
+  }
+  return MX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// RIFF writer
+// ---------------------------------------------------------------------------
+namespace {
+void put_le(unsigned char *b, uint64_t v, int bytes) {
+  for (int i = 0; i < bytes; ++i, v >>= 8) b[i] = (unsigned char)(v & 0xff);
+}
+}  // namespace
+
+int write_wav(const char *path, const int16_t *pcm, int64_t m, int sampleRate, bool strict) {
+  if (!path || m < 0 || (m > 0 && !pcm)) return MX_ERR_INVALID;
+  unsigned char hdr[48];
+  std::memcpy(hdr, "RIFF", 4);
+  const uint64_t fileLength = 44 + 2 * (uint64_t)m;
+  put_le(hdr + 4, fileLength - 8, 4);
+  std::memcpy(hdr + 8, "WAVEfmt ", 8);
+  put_le(hdr + 16, 16, 4);
+  put_le(hdr + 20, 1, 2);
+  put_le(hdr + 22, 1, 2);
+  put_le(hdr + 24, (uint64_t)(int64_t)sampleRate, 4);
+  put_le(hdr + 28, (uint64_t)(int64_t)((sampleRate * 16 * 1) / 8), 4);
+  put_le(hdr + 32, 2, 2);
+  put_le(hdr + 34, 16, 2);
+  std::memcpy(hdr + 36, "data", 4);
+  size_t hdr_len = 44;
+  int64_t skip = 0;  // PCM samples replaced by header bytes
+  if (strict) {
+    // save-wav.cpp:43: writeWord(f, size_t(fileLength - dataChunkPos + 8)) with the
+    // default size = sizeof(size_t) = 8 -> eight bytes at offset 40.
+    put_le(hdr + 40, fileLength - 36 + 8, 8);
+    hdr_len = 48;
+    skip = 2;
+  } else {
+    put_le(hdr + 40, 2 * (uint64_t)m, 4);
+  }
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return MX_ERR_IO;
+  bool ok = std::fwrite(hdr, 1, hdr_len, f) == hdr_len;
+  if (ok && m > skip) {
+    // int16 little-endian == the in-memory layout on the (little-endian) hosts this runs on
+    const size_t cnt = (size_t)(m - skip);
+    ok = std::fwrite(pcm + skip, sizeof(int16_t), cnt, f) == cnt;
+  }
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? MX_OK : MX_ERR_IO;
+}
+
+}  // namespace mx

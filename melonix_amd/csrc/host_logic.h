@@ -1,0 +1,71 @@
+// host_logic.h — the serial, scalar part of the hot path that stays on the host:
+// marker time maps, grain chain, the cursor recurrence of the export loop and
+// the RIFF writer.  These are the product's own implementations (C++17), used
+// by capi.cpp; they feed the GPU kernels with the per-step schedule.
+//
+// Reference (relative to the reference tree): app.cpp:1020-1122 (time maps),
+// app.cpp:153-235 (grains), app.cpp:294-331 + 1200-1207 (cursor recurrence),
+// save-wav.cpp:17-48 (RIFF writer).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/melonix_amd.h"
+
+namespace mx {
+
+// Piecewise-linear marker maps as cold-cache pure functions.  The reference
+// memoises by int(val*sampleRate) (app.cpp:1027,1059,1093); within one export
+// run equal keys only arise from equal arguments, so the pure functions return
+// the same values (tests/test_host_logic.py checks this against the
+// memo-faithful oracle).
+class TimeMap {
+ public:
+  TimeMap(const mx_marker *markers, int nmarkers, int sampleRate, int64_t nsamples);
+  double sample2time(int val) const;     // app.cpp:1020-1050
+  int time2sample(double val) const;     // app.cpp:1052-1082
+  double duration() const;               // app.cpp:1084-1087
+  float time2pitchbend(double val) const;  // app.cpp:1089-1122
+
+ private:
+  struct Seg {
+    int prevSample, sample;
+    double prevTime, rightTime;
+    double prevPitchBend, pitchBend;
+  };
+  std::vector<Seg> segs_;
+  int sr_;
+  int64_t n_;
+  int lastSample_ = 0;
+  double lastTime_ = 0.0;
+  double lastPitchBend_ = 0.0;
+};
+
+// Zero-crossing predicate bitmaps: bit i of zc[k] set iff the reference's
+// isZeroCrossing lambda with lookAround k accepts index i (app.cpp:167-181 for
+// k = 7, app.cpp:202-216 for k = 3).
+struct ZcBitmaps {
+  int64_t n = 0;
+  std::vector<uint64_t> zc7, zc3;
+};
+void zc_bitmaps_host(const float *wav, int64_t n, ZcBitmaps &out);
+
+// Walks the grain chain over the bitmaps: nearest zc7 to start+1500 within
+// +-749 (ties: the later index first, app.cpp:164-166), else the first zc3 at
+// i >= start+2250 (app.cpp:198-228).
+void grains_from_bitmaps(const ZcBitmaps &zc, std::vector<int32_t> &starts, std::vector<int32_t> &lens);
+
+// The export loop's serial recurrence.  Returns MX_OK or MX_ERR_INVALID.
+int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *gstarts,
+                   const int32_t *glens, int64_t ngrains, const mx_marker *markers, int nmarkers,
+                   std::vector<mx_step> &steps, int64_t &nsamples, std::string &err);
+
+// Number of samples one process() call emits: #{ i >= 0 : floor(float(i)*rate) < L }
+// (app.cpp:313-322), in closed form + exact float correction.  Returns -1 when the
+// count does not fit (rate so small that the reference's int loop would overflow).
+int64_t step_size(float rate, int32_t L);
+
+int write_wav(const char *path, const int16_t *pcm, int64_t m, int sampleRate, bool strict);
+
+}  // namespace mx

@@ -1,0 +1,53 @@
+// kernels.h — internal launch interface between the C-ABI layer (capi.cpp) and
+// the gfx950 kernels (*.hip).  Not part of the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/melonix_amd.h"
+
+namespace mx {
+
+enum StftMode {
+  kBulkAligned = 0,  // uniform hop, even hop: 64-bit sample/weight loads
+  kBulkAny = 1,      // uniform hop, odd hop
+  kRanges = 2,       // per-frame (start,end) list
+};
+
+struct StftArgs {
+  const float *audio;  // padded image: [MX_AUDIO_PAD zeros][n][MX_AUDIO_PAD zeros]
+  int64_t n;
+  const float *wtab;      // bulk: N forward weights
+  const float *wext;      // ranges: d-indexed weights (stft_tables.h)
+  const float2 *tw2;      // pass-2 twiddles
+  const float2 *tw3;      // pass-3 twiddles
+  const float2 *ubase;    // post-split bases
+  const int32_t *ranges;  // ranges mode: count x {start,end} (device)
+  int hop;
+  int64_t first_frame;
+  int64_t count;
+  int kmin, kmax;
+  float *mags;       // count x N/2, may be null
+  mx_pitch *pitch;   // count, may be null
+  uint8_t *rgb;      // count x N/2 x 3 (fused colormap), may be null
+  float cmap_k;
+  int frames_per_block;
+};
+
+hipError_t launch_stft(int N, int mode, const StftArgs &a, hipStream_t s);
+
+struct ResynthArgs {
+  const float *audio;  // padded image
+  const mx_step *steps;
+  int64_t nsteps;
+  int64_t nsamples;    // total incl. trailing zeros
+  float *pcm_f32;      // may be null
+  int16_t *pcm_i16;    // may be null
+};
+hipError_t launch_resynth(const ResynthArgs &a, hipStream_t s);
+
+// Zero-crossing predicate bitmaps for grain segmentation (app.cpp:167-181, 202-216).
+hipError_t launch_zc_bitmaps(const float *audio_padded, int64_t n, uint64_t *zc7, uint64_t *zc3,
+                             hipStream_t s);
+
+}  // namespace mx

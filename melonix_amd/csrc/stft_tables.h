@@ -1,0 +1,96 @@
+// stft_tables.h — host-side builders of the constant tables the STFT kernels
+// read from HBM/L2: pass twiddles, the post-split bases and the window weights.
+// Host code only (plain C++17); the tables are uploaded once per context.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "stft_core.h"
+
+namespace mx {
+
+struct cpx_h {  // layout-compatible with cpx / float2
+  float x, y;
+};
+
+inline cpx_h unit_root(long long num, long long den) {  // exp(-2*pi*i*num/den)
+  num %= den;
+  if (num < 0) num += den;
+  const long double a = 6.283185307179586476925286766559005768L * (long double)num / (long double)den;
+  cpx_h r;
+  r.x = (float)cosl(a);
+  r.y = (float)(-sinl(a));
+  // exact values at the quadrant points
+  if ((4 * num) % den == 0) {
+    const int q = (int)((4 * num) / den);
+    r.x = (float)((q == 0) - (q == 2));
+    r.y = (float)((q == 3) - (q == 1));
+  }
+  return r;
+}
+
+template <int N>
+std::vector<cpx_h> make_tw2() {
+  using C = Cfg<N>;
+  std::vector<cpx_h> t((size_t)C::TW2);
+  for (int r = 1; r < C::R2; ++r)
+    for (int k = 0; k < C::R1; ++k) t[(size_t)(r - 1) * C::R1 + k] = unit_root((long long)r * k, C::R1 * C::R2);
+  return t;
+}
+
+template <int N>
+std::vector<cpx_h> make_tw3() {
+  using C = Cfg<N>;
+  std::vector<cpx_h> t((size_t)C::TW3);
+  for (int r = 1; r < 16; ++r)
+    for (int k = 0; k < C::NS3; ++k) t[(size_t)(r - 1) * C::NS3 + k] = unit_root((long long)r * k, C::M);
+  return t;
+}
+
+// ubase[t] = i * exp(-2*pi*i*t/N), t = 0..T-1
+template <int N>
+std::vector<cpx_h> make_ubase() {
+  using C = Cfg<N>;
+  std::vector<cpx_h> t((size_t)C::T);
+  for (int k = 0; k < C::T; ++k) {
+    const cpx_h w = unit_root(k, N);
+    t[(size_t)k].x = -w.y;  // i*(a+ib) = -b + ia
+    t[(size_t)k].y = w.x;
+  }
+  return t;
+}
+
+// Window weight by distance d = start - i (spec.cpp:55-58):
+//   d <= 0 -> 1;  d >= 1 -> expf(-2.5e-4f * d)   (the host libm's expf, exactly
+//   the call the reference makes; d converts to float exactly for d < 2^24).
+// Stored as wext[d + kWOff], d in [-kWOff, kWDmax]; beyond kWDmax the weight
+// underflows to exactly 0.f (expf(-105) == 0 in binary32), so the table is
+// complete for every representable distance.  A frame's distances are
+// d = D0 - p, p = 0..N-1, D0 = N - (end - start); clamping D0 into
+// [N-1-kWOff, kWDmax+kWTail] keeps every lookup inside the table without
+// changing any weight (below: all ones; above: all zeros).
+constexpr int kWOff = 32768;
+constexpr int kWDmax = 425984;  // 2.5e-4 * 425984 = 106.5 > 103.98 = ln(2^150)
+constexpr int kWTail = 32768;   // zeros past kWDmax so a clamped frame never leaves the table
+
+inline std::vector<float> make_wext() {
+  std::vector<float> w((size_t)kWOff + kWDmax + kWTail + 1, 0.0f);
+  for (int d = -kWOff; d <= 0; ++d) w[(size_t)(d + kWOff)] = 1.0f;
+  for (int d = 1; d <= kWDmax; ++d) w[(size_t)(d + kWOff)] = expf(-2.5e-4f * d);
+  return w;
+}
+
+// Bulk mode (uniform hop): weight of frame position p is that of d = N-hop-p.
+inline std::vector<float> make_wtab(int N, int hop, const std::vector<float> &wext) {
+  std::vector<float> w((size_t)N);
+  for (int p = 0; p < N; ++p) {
+    long long d = (long long)N - hop - p;
+    if (d < -kWOff) d = -kWOff;
+    if (d > kWDmax) d = kWDmax;
+    w[(size_t)p] = wext[(size_t)(d + kWOff)];
+  }
+  return w;
+}
+
+}  // namespace mx

@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SR = 48000
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def accum_sweep(n, sr=SR, f0=110.0, f1=1760.0, amp=0.5):
+    """The survey's known-answer signal: phase accumulation, increment then sample
+    (BASELINE.md §2 facts were recorded on this form)."""
+    i = np.arange(n, dtype=np.float64)
+    inc = 2 * np.pi * (f0 + (f1 - f0) * i / n) / sr
+    return (amp * np.sin(np.cumsum(inc))).astype(np.float32)
+
+
+def noisy(w, seed=0x6D656C6F, level=1e-3):
+    rng = np.random.default_rng(seed)
+    return (w + level * rng.uniform(-1, 1, len(w))).astype(np.float32)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    pyoracle.build()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def mxlib():
+    """The product library, built in-tree if necessary (hipcc cross-compiles without a GPU)."""
+    from melonix_amd import build as mxbuild
+    mxbuild.build()
+    import melonix_amd
+    return melonix_amd
+
+
+@pytest.fixture(scope="session")
+def sweep10():
+    return accum_sweep(10 * SR)
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(mxlib):
+    ctx = mxlib.Context(0)  # raises MxError(MX_ERR_DEVICE) when no gfx950 is visible
+    yield ctx
+    ctx.close()
+
+
+def mag_tol(ref_rows):
+    """max_k |g-r| <= 2e-5 * max_k r + 1e-9 per frame (fp32 LDS FFT vs the f64 path)."""
+    return 2e-5 * ref_rows.max(axis=-1, keepdims=True) + 1e-9

@@ -1,0 +1,72 @@
+"""GPU parity: grain bitmaps, gather-lerp resynthesis, int16, WAV — bit-exact vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SR, accum_sweep, noisy
+
+pytestmark = pytest.mark.gpu
+
+
+def test_grains_dev_equals_oracle(gpu_ctx, oracle, mxlib):
+    for w in (accum_sweep(10 * SR), noisy(accum_sweep(5 * SR), level=0.05), np.zeros(3 * SR, np.float32)):
+        a = gpu_ctx.upload(w)
+        s, l = gpu_ctx.grains_dev(a)
+        rs, rl = oracle.grains(w)
+        assert np.array_equal(s, rs) and np.array_equal(l, rl)
+        a.free()
+
+
+@pytest.mark.parametrize("pb,steps,samples", [(0, 320, 480407), (3, 379, 478903), (-4, 254, 479781), (7.5, 491, 479189)])
+def test_export_known_answers_bit_exact(gpu_ctx, oracle, mxlib, pb, steps, samples, tmp_path):
+    """BASELINE.md §2 facts (recorded from the compiled reference) + bit-exact PCM vs the oracle."""
+    w = accum_sweep(10 * SR)
+    n = len(w)
+    mk = [(1, 0, 0, pb), (n - 1, 0, 0, pb)]
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    assert len(s) == 319
+    st, total = mxlib.schedule_build(w, SR, s, l, mk)
+    assert len(st) + 1 == steps and total == samples
+    f32, i16 = gpu_ctx.resynth(a, st, total)
+    ost, opcm = oracle.export_run(w, SR, mk)
+    assert np.array_equal(f32.view(np.uint32), opcm.view(np.uint32))  # bitwise
+    assert np.array_equal(i16, oracle.pcm_to_i16(opcm))
+    # whole exportWav through the C-ABI, byte-exact incl. the save-wav.cpp:43 quirk
+    path = tmp_path / "out.wav"
+    gpu_ctx.export_wav(w, SR, mk, path, strict=True)
+    got = path.read_bytes()
+    assert got == oracle.wav_bytes(oracle.pcm_to_i16(opcm), SR)
+    assert len(got) == 44 + 2 * samples
+    a.free()
+
+
+def test_resynth_warp_markers_bit_exact(gpu_ctx, oracle, mxlib):
+    w = noisy(accum_sweep(10 * SR), level=0.05)
+    n = len(w)
+    mk = [(1000, 0, 0.0, 2.0), (100000, 0, 0.5, -3.0), (300000, 0, -0.2, 5.0), (n - 1, 0, 0, 0)]
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    st, total = mxlib.schedule_build(w, SR, s, l, mk)
+    f32, i16 = gpu_ctx.resynth(a, st, total)
+    ost, opcm = oracle.export_run(w, SR, mk)
+    assert total == len(opcm)
+    assert np.array_equal(f32.view(np.uint32), opcm.view(np.uint32))
+    assert np.array_equal(i16, oracle.pcm_to_i16(opcm))
+    a.free()
+
+
+def test_identity_resynth_reproduces_source(gpu_ctx, mxlib):
+    """Property at a size the oracle would take long on: with no markers (rate 1) the PCM is the
+    source audio over the grain chain, then 1500 zeros."""
+    w = noisy(accum_sweep(120 * SR), level=0.01)
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    assert (s[1:] == s[:-1] + l[:-1]).all() and s[0] == 0  # chain covers [0, lastEnd) without gaps
+    st, total = mxlib.schedule_build(w, SR, s, l, [])
+    assert total == int(l.sum()) + 1500
+    f32, _ = gpu_ctx.resynth(a, st, total, want_i16=False)
+    assert np.array_equal(f32[:-1500], w[: total - 1500])
+    assert not f32[-1500:].any()
+    a.free()
