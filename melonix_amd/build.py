@@ -24,7 +24,9 @@ CXX = os.environ.get("CXX") or shutil.which("g++") or "g++"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 # (source, compiler, extra flags)
 UNITS = [
-    ("stft_kernels.hip", "hip", []),
+    # packed f32 VALU has no rate advantage on gfx950 (measured: 69 vs 57 T lane-ops/s) and the SLP
+    # vectoriser's v_pk_* forms cost ~200 register-pairing moves per frame: keep the butterflies scalar
+    ("stft_kernels.hip", "hip", ["-fno-slp-vectorize"]),
     # bit-exact PCM: no FMA contraction in the resampler
     ("resynth_kernels.hip", "hip", ["-ffp-contract=off"]),
     ("capi.cpp", "hip", []),

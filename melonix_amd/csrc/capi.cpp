@@ -43,6 +43,8 @@ int fail(int code, const char *fmt, ...) {
 
 struct NTables {
   float2 *tw2 = nullptr, *tw3 = nullptr, *ubase = nullptr;
+  float *wext = nullptr;  // d-indexed window weights, pre-scaled by 1/(2N)
+  std::vector<float> wext_host;
 };
 
 }  // namespace
@@ -51,10 +53,8 @@ struct mx_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  float *wext = nullptr;  // d-indexed window weights
   std::map<int, NTables> tables;
   std::map<std::pair<int, int>, float *> wtabs;  // (N, hop) -> forward weights
-  std::vector<float> wext_host;
   int frames_per_block = 0;  // 0 = per-N default
   std::mutex mu;
 };
@@ -86,6 +86,9 @@ int build_tables(NTables &t) {
   HIP_TRY(hipMemcpy(t.tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(t.tw3, tw3.data(), tw3.size() * sizeof(float2), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(t.ubase, ub.data(), ub.size() * sizeof(float2), hipMemcpyHostToDevice));
+  t.wext_host = make_wext(fold_scale(N));
+  HIP_TRY(hipMalloc(&t.wext, t.wext_host.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(t.wext, t.wext_host.data(), t.wext_host.size() * sizeof(float), hipMemcpyHostToDevice));
   return MX_OK;
 }
 
@@ -110,7 +113,7 @@ int get_tables(mx_ctx *ctx, int N, NTables &out) {
   return MX_OK;
 }
 
-int get_wtab(mx_ctx *ctx, int N, int hop, const float **out) {
+int get_wtab(mx_ctx *ctx, int N, int hop, const NTables &nt, const float **out) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   const auto key = std::make_pair(N, hop);
   auto it = ctx->wtabs.find(key);
@@ -118,7 +121,7 @@ int get_wtab(mx_ctx *ctx, int N, int hop, const float **out) {
     *out = it->second;
     return MX_OK;
   }
-  const std::vector<float> w = make_wtab(N, hop, ctx->wext_host);
+  const std::vector<float> w = make_wtab(N, hop, nt.wext_host);
   float *d = nullptr;
   HIP_TRY(hipMalloc(&d, w.size() * sizeof(float)));
   HIP_TRY(hipMemcpy(d, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -148,7 +151,8 @@ int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_
   StftArgs s{};
   s.audio = a->d_padded;
   s.n = a->n;
-  s.wext = ctx->wext;
+  s.wext = t.wext;
+  s.decay = hop_decay(hop);
   s.tw2 = t.tw2;
   s.tw3 = t.tw3;
   s.ubase = t.ubase;
@@ -164,7 +168,7 @@ int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_
   s.cmap_k = cmap_k;
   s.frames_per_block = ctx->frames_per_block > 0 ? ctx->frames_per_block : default_frames_per_block(N);
   if (mode != kRanges) {
-    rc = get_wtab(ctx, N, hop, &s.wtab);
+    rc = get_wtab(ctx, N, hop, t, &s.wtab);
     if (rc) return rc;
   }
   HIP_TRY(hipSetDevice(ctx->device));
@@ -207,22 +211,6 @@ int mx_ctx_create(int device, mx_ctx **out) {
     return fail(MX_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
   }
   c->stream = c->own_stream;
-  try {
-    c->wext_host = make_wext();
-  } catch (const std::bad_alloc &) {
-    hipStreamDestroy(c->own_stream);
-    delete c;
-    return fail(MX_ERR_NOMEM, "out of host memory");
-  }
-  e = hipMalloc(&c->wext, c->wext_host.size() * sizeof(float));
-  if (e == hipSuccess)
-    e = hipMemcpy(c->wext, c->wext_host.data(), c->wext_host.size() * sizeof(float), hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    if (c->wext) hipFree(c->wext);
-    hipStreamDestroy(c->own_stream);
-    delete c;
-    return fail(MX_ERR_DEVICE, "uploading the window table: %s", hipGetErrorString(e));
-  }
   *out = c;
   return MX_OK;
 }
@@ -235,9 +223,9 @@ void mx_ctx_destroy(mx_ctx *ctx) {
     hipFree(kv.second.tw2);
     hipFree(kv.second.tw3);
     hipFree(kv.second.ubase);
+    hipFree(kv.second.wext);
   }
   for (auto &kv : ctx->wtabs) hipFree(kv.second);
-  hipFree(ctx->wext);
   hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

@@ -17,8 +17,9 @@ enum StftMode {
 struct StftArgs {
   const float *audio;  // padded image: [MX_AUDIO_PAD zeros][n][MX_AUDIO_PAD zeros]
   int64_t n;
-  const float *wtab;      // bulk: N forward weights
-  const float *wext;      // ranges: d-indexed weights (stft_tables.h)
+  const float *wtab;      // bulk: N forward weights, pre-scaled by 1/(2N)
+  const float *wext;      // ranges: d-indexed weights, pre-scaled by 1/(2N) (stft_tables.h)
+  float decay;            // exp(-2.5e-4*hop): per-hop decay of the sliding window
   const float2 *tw2;      // pass-2 twiddles
   const float2 *tw3;      // pass-3 twiddles
   const float2 *ubase;    // post-split bases

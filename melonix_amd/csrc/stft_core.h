@@ -55,6 +55,13 @@ MX_HD cpx cconj(cpx a) { return mk(a.x, -a.y); }
 // by-value select (a conditional on two array lvalues would select addresses and
 // push the register array into scratch)
 MX_HD cpx csel(bool c, cpx a, cpx b) { return mk(c ? a.x : b.x, c ? a.y : b.y); }
+MX_HD float fast_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrtf(x);  // v_sqrt_f32, 1 ulp
+#else
+  return __builtin_sqrtf(x);
+#endif
+}
 
 // a * exp(-2*pi*i*K/64), K a compile-time constant.
 template <int K>
@@ -157,38 +164,111 @@ struct alignas(4) f2u {  // 4-byte aligned pair for frames starting at odd sampl
   float x, y;
 };
 
+// The windowed frame as the thread sees it: Y[e], e = b + NB1*r, is the packed complex
+// point c = t + T*e  (samples 2c, 2c+1 of the frame), i.e. input r of pass-1 butterfly
+// j = t + T*b.  The window tables carry the output scale 1/(2N) (a power of two, so
+// x*(w*2^-k) == (x*w)*2^-k bit for bit): magnitudes come out of the split already
+// scaled and the per-bin multiply disappears.
 template <int N, int WSTEP, bool ALIGNED8>
-MX_HD void pass1(int t, cpx (&v)[32], const float *x, const float *w) {
+MX_HD void load_frame(int t, cpx (&Y)[32], const float *x, const float *w) {
+#pragma clang fp contract(off)  // the windowed sample is a rounded binary32 product (spec.cpp:58)
+  using C = Cfg<N>;
+#pragma unroll
+  for (int e = 0; e < 32; ++e) {
+    const int p = 2 * (t + C::T * e);
+    float x0, x1, w0, w1;
+    if constexpr (ALIGNED8 && WSTEP == 1) {
+      const cpx xs = *reinterpret_cast<const cpx *>(x + p);
+      const cpx ws = *reinterpret_cast<const cpx *>(w + p);
+      x0 = xs.x; x1 = xs.y; w0 = ws.x; w1 = ws.y;
+    } else {
+      const f2u xs = *reinterpret_cast<const f2u *>(x + p);
+      x0 = xs.x; x1 = xs.y;
+      if constexpr (WSTEP == 1) {
+        const f2u ws = *reinterpret_cast<const f2u *>(w + p);
+        w0 = ws.x; w1 = ws.y;
+      } else {
+        const f2u ws = *reinterpret_cast<const f2u *>(w - p - 1);
+        w0 = ws.y; w1 = ws.x;
+      }
+    }
+#ifdef MX_ABL_NOW
+    w0 = 0.75f; w1 = 0.5f;
+#endif
+#ifdef MX_ABL_NOX
+    x0 = (float)p; x1 = 1.0f;
+#endif
+    Y[e] = mk(x0 * w0, x1 * w1);  // float product, as spec.cpp:58 (times the folded 2^-k)
+  }
+}
+
+template <int N>
+MX_HD void pass1(const cpx (&Y)[32], cpx (&v)[32]) {
   using C = Cfg<N>;
 #pragma unroll
   for (int b = 0; b < C::NB1; ++b) {
-    const int j = t + C::T * b;
     cpx in[C::R1], out[C::R1];
 #pragma unroll
-    for (int r = 0; r < C::R1; ++r) {
-      const int p = 2 * (j + r * (C::M / C::R1));
-      float x0, x1, w0, w1;
-      if constexpr (ALIGNED8 && WSTEP == 1) {
-        const cpx xs = *reinterpret_cast<const cpx *>(x + p);
-        const cpx ws = *reinterpret_cast<const cpx *>(w + p);
-        x0 = xs.x; x1 = xs.y; w0 = ws.x; w1 = ws.y;
-      } else {
-        const f2u xs = *reinterpret_cast<const f2u *>(x + p);
-        x0 = xs.x; x1 = xs.y;
-        if constexpr (WSTEP == 1) {
-          const f2u ws = *reinterpret_cast<const f2u *>(w + p);
-          w0 = ws.x; w1 = ws.y;
-        } else {
-          const f2u ws = *reinterpret_cast<const f2u *>(w - p - 1);
-          w0 = ws.y; w1 = ws.x;
-        }
-      }
-      in[r] = mk(x0 * w0, x1 * w1);  // float product, as spec.cpp:58
-    }
+    for (int r = 0; r < C::R1; ++r) in[r] = Y[b + C::NB1 * r];
     Dft<C::R1>::run(in, out);
 #pragma unroll
     for (int r = 0; r < C::R1; ++r) v[b * C::R1 + r] = out[r];
   }
+}
+
+// ---- sliding window (uniform hop) -------------------------------------------
+// Consecutive frames overlap by N-hop samples and the one-sided exponential window
+// is shift-invariant up to a constant: w(p - hop) = w(p) * exp(-2.5e-4*hop).  So the
+// next frame's windowed points are this frame's, moved down by D = (hop/2)/T slots
+// and decayed:  Y'[e] = Y[e+D] * g.  The register move and the decay are the same
+// multiply.  Points that just left the flat (weight 1) tail get their exact table
+// weight instead of g, the newest hop enters with weight 1: each sample is loaded
+// from HBM once per workgroup instead of N/hop times.  A point is decayed at most
+// N/hop - 2 times before it leaves the frame, so the weights stay within
+// (N/hop)*2^-24 relative of the expf table (tests bound the end-to-end effect).
+template <int N, int HOP>
+struct Slide {
+  using C = Cfg<N>;
+  static constexpr int H = HOP / 2;            // packed points per hop
+  static constexpr bool ok = (HOP % 2 == 0) && (H % C::T == 0) && (H / C::T >= 1) && (2 * (H / C::T) <= 32);
+  static constexpr int D = ok ? H / C::T : 1;  // slots per hop
+};
+
+// edge[i] (i < D): table weights (times the folded scale) of the slots [32-2D, 32-D),
+// i.e. of the hop that has just left the weight-1 tail.  sc = folded scale 1/(2N).
+template <int N, int HOP>
+MX_HD void slide_edge(int t, const float *wtab, float inv_sc, cpx (&edge)[Slide<N, HOP>::D]) {
+  using S = Slide<N, HOP>;
+#pragma unroll
+  for (int i = 0; i < S::D; ++i) {
+    const int p = 2 * (t + S::C::T * (32 - 2 * S::D + i));
+    // the slot already carries sc; the table carries it too: take it out once (exact, power of two)
+    edge[i] = mk(wtab[p] * inv_sc, wtab[p + 1] * inv_sc);
+  }
+}
+
+// newest hop of the frame that ends at sample pointer xe (one past the frame's last sample)
+template <int N, int HOP>
+MX_HD void slide_fetch(int t, const float *xe, cpx (&nx)[Slide<N, HOP>::D]) {
+  using S = Slide<N, HOP>;
+#pragma unroll
+  for (int i = 0; i < S::D; ++i) nx[i] = *reinterpret_cast<const cpx *>(xe - HOP + 2 * (t + S::C::T * i));
+}
+
+template <int N, int HOP>
+MX_HD void slide_step(cpx (&Y)[32], const cpx (&nx)[Slide<N, HOP>::D], const cpx (&edge)[Slide<N, HOP>::D],
+                      float g, float sc) {
+#pragma clang fp contract(off)  // keep each windowed point a rounded product, whatever consumes it
+  using S = Slide<N, HOP>;
+#pragma unroll
+  for (int e = 0; e < 32 - 2 * S::D; ++e) Y[e] = mk(Y[e + S::D].x * g, Y[e + S::D].y * g);
+#pragma unroll
+  for (int i = 0; i < S::D; ++i) {
+    const cpx o = Y[32 - S::D + i];  // weight-1 slot (scaled by sc): becomes raw * edge
+    Y[32 - 2 * S::D + i] = mk(o.x * edge[i].x, o.y * edge[i].y);
+  }
+#pragma unroll
+  for (int i = 0; i < S::D; ++i) Y[32 - S::D + i] = mk(nx[i].x * sc, nx[i].y * sc);
 }
 
 // LDS addressing.  Every access below is "per-thread base + compile-time offset"
@@ -234,7 +314,13 @@ MX_HD void pass2(int t, cpx (&v)[32], const cpx *tw2) {
     cpx in[C::R2], out[C::R2];
     in[0] = v[b * C::R2];
 #pragma unroll
-    for (int r = 1; r < C::R2; ++r) in[r] = cmul(v[b * C::R2 + r], tw2[(r - 1) * C::R1 + k]);
+    for (int r = 1; r < C::R2; ++r) {
+#ifdef MX_ABL_NOTW
+      in[r] = cmul(v[b * C::R2 + r], mk(0.5f + r, 0.25f * k));
+#else
+      in[r] = cmul(v[b * C::R2 + r], tw2[(r - 1) * C::R1 + k]);
+#endif
+    }
     Dft<C::R2>::run(in, out);
 #pragma unroll
     for (int r = 0; r < C::R2; ++r) v[b * C::R2 + r] = out[r];
@@ -293,21 +379,40 @@ MX_HD void load_t2(int t, cpx (&v)[32], const cpx *lds) {
 }
 
 // ---- pass 3 ----------------------------------------------------------------
-// tw3[(r-1)*NS3 + k0] = exp(-2*pi*i*r*k0/M), r = 1..15, k0 = 0..NS3-1
+// tw3[(r-1)*NS3 + k0] = exp(-2*pi*i*r*k0/M), r = 1..15, k0 = 0..NS3-1.
+// Butterfly Q sits at k0 = NS3 - t, and exp(-2*pi*i*r*(NS3-t)/M) = W16^r * conj(tw3[r][t]):
+// the conjugate costs nothing inside the complex multiply and the W16^r factor is a
+// one-bin rotation of the 16-point DFT's output (sum_r x_r W16^r W16^(rq) = X[q+1]).  So one
+// table read serves both butterflies; thread 0 (P = 0, Q = NS3/2) reads column NS3/2 for Q
+// and uses 1 for P.
+// On return v[r] = Z[k0p + NS3*r] and v[16 + ((r+1)&15)]... is handled by q_index():
+// Q's natural element r lives in v[16 + ((r + 1) & 15)].
+MX_HD constexpr int q_index(int r) { return 16 + ((r + 1) & 15); }
+
 template <int N>
 MX_HD void pass3(int t, cpx (&v)[32], const cpx *tw3) {
   using C = Cfg<N>;
-  const int kk[2] = {k0p<N>(t), k0q<N>(t)};
+  const int col = t ? t : C::NS3 / 2;
+  const bool t0 = (t == 0);
+  cpx inp[16], inq[16], out[16];
+  inp[0] = v[0];
+  inq[0] = v[16];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    cpx in[16], out[16];
-    in[0] = v[16 * b];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) in[r] = cmul(v[16 * b + r], tw3[(r - 1) * C::NS3 + kk[b]]);
-    Dft<16>::run(in, out);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[16 * b + r] = out[r];
+  for (int r = 1; r < 16; ++r) {
+#ifdef MX_ABL_NOTW
+    const cpx w = mk(0.5f + r, 0.25f * col);
+#else
+    const cpx w = tw3[(r - 1) * C::NS3 + col];
+#endif
+    inp[r] = cmul(v[r], csel(t0, mk(1.0f, 0.0f), w));
+    inq[r] = cmul(v[16 + r], cconj(w));
   }
+  Dft<16>::run(inp, out);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = out[r];
+  Dft<16>::run(inq, out);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[16 + r] = out[r];
 }
 
 // ---- real-FFT split + magnitude ---------------------------------------------
@@ -320,47 +425,38 @@ MX_HD void pass3(int t, cpx (&v)[32], const cpx *tw3) {
 // computed in fp32.  Thread 0's slot 8 second output is bin M/2 (bin M, the
 // Nyquist bin, is not emitted by the reference).
 // ub_lo / ub_hi: i*exp(-2*pi*i*t/N) for t > 0; thread 0: i*exp(-2*pi*i/64), -1.
+// u[s] = i*w_k for the slot's bin (per-thread constants, see post_twiddles()).
 template <int S>
 struct PostSlot {
   template <int N>
-  static MX_HD void run(bool t0, const cpx (&v)[32], cpx ub_lo, cpx ub_hi, float (&mg)[32]) {
-    constexpr float scale = 0.5f / static_cast<float>(N);
+  static MX_HD void run(bool t0, const cpx (&v)[32], const cpx (&u)[16], float (&mg)[32]) {
     cpx A, B;
     if constexpr (S < 8) {
-      A = csel(t0, v[16 + S], v[S]);
-      B = v[16 + 15 - S];
+      A = csel(t0, v[q_index(S)], v[S]);
+      B = v[q_index(15 - S)];
     } else {
       A = csel(t0, v[S - 8], v[S]);
-      B = csel(t0, v[(24 - S) & 15], v[16 + 15 - S]);
+      B = csel(t0, v[(24 - S) & 15], v[q_index(15 - S)]);
     }
     B = cconj(B);
     const cpx Sm = cadd(A, B);
     const cpx Dm = csub(A, B);
-    const cpx D = mulw64<2 * S>(cmul(S < 8 ? ub_lo : ub_hi, Dm));
+    const cpx D = cmul(u[S], Dm);
     const cpx lo = csub(Sm, D), hi = cadd(Sm, D);
-#if defined(__HIP_DEVICE_COMPILE__)
-    mg[2 * S] = __builtin_amdgcn_sqrtf(lo.x * lo.x + lo.y * lo.y) * scale;
-    mg[2 * S + 1] = __builtin_amdgcn_sqrtf(hi.x * hi.x + hi.y * hi.y) * scale;
-#else
-    mg[2 * S] = __builtin_sqrtf(lo.x * lo.x + lo.y * lo.y) * scale;
-    mg[2 * S + 1] = __builtin_sqrtf(hi.x * hi.x + hi.y * hi.y) * scale;
-#endif
+    mg[2 * S] = fast_sqrt(lo.x * lo.x + lo.y * lo.y);
+    mg[2 * S + 1] = fast_sqrt(hi.x * hi.x + hi.y * hi.y);
     if constexpr (S == 8) {  // thread 0: bin M/2 instead of the Nyquist bin; |X[M/2]| = |Z[M/2]|
       const cpx z = v[8];
-#if defined(__HIP_DEVICE_COMPILE__)
-      const float m = __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y) * (2.0f * scale);
-#else
-      const float m = __builtin_sqrtf(z.x * z.x + z.y * z.y) * (2.0f * scale);
-#endif
+      const float m = fast_sqrt(z.x * z.x + z.y * z.y) * 2.0f;
       mg[2 * S + 1] = t0 ? m : mg[2 * S + 1];
     }
-    if constexpr (S + 1 < 16) PostSlot<S + 1>::template run<N>(t0, v, ub_lo, ub_hi, mg);
+    if constexpr (S + 1 < 16) PostSlot<S + 1>::template run<N>(t0, v, u, mg);
   }
 };
 
 template <int N>
-MX_HD void post(int t, const cpx (&v)[32], cpx ub_lo, cpx ub_hi, float (&mg)[32]) {
-  PostSlot<0>::template run<N>(t == 0, v, ub_lo, ub_hi, mg);
+MX_HD void post(int t, const cpx (&v)[32], const cpx (&u)[16], float (&mg)[32]) {
+  PostSlot<0>::template run<N>(t == 0, v, u, mg);
 }
 
 // Bin of output slot o (= 2s or 2s+1) of thread t:
@@ -397,16 +493,27 @@ MX_HD uint32_t band_mask(int t, int kmin, int kmax) {
   return m;
 }
 
-// Post-split twiddle bases of thread t (ubase[t] = i*exp(-2*pi*i*t/N) from the table).
-template <int N>
-MX_HD void post_bases(int t, const cpx *ubase, cpx &ub_lo, cpx &ub_hi) {
-  if (t) {
-    ub_lo = ubase[t];
-    ub_hi = ub_lo;
-  } else {
-    ub_lo = mk(kSin64[1], kCos64[1]);  // i*exp(-2*pi*i/64) = sin + i*cos
-    ub_hi = mk(-1.0f, 0.0f);
+// Post-split twiddles of thread t: u[s] = i*exp(-2*pi*i*k_s/N) for the slot's bin k_s.
+// ubase[t] = i*exp(-2*pi*i*t/N) comes from the table; k_s = t + NS3*s adds exp(-2*pi*i*s/32).
+// Thread 0: s < 8 -> k = NS3/2 + NS3*s (base i*exp(-2*pi*i/64)); s >= 8 -> k = NS3*(s-8) (base -1).
+template <int S>
+struct PostTw {
+  static MX_HD void run(cpx lo, cpx hi, cpx (&u)[16]) {
+    u[S] = mulw64<2 * S>(S < 8 ? lo : hi);
+    if constexpr (S + 1 < 16) PostTw<S + 1>::run(lo, hi, u);
   }
+};
+template <int N>
+MX_HD void post_twiddles(int t, const cpx *ubase, cpx (&u)[16]) {
+  cpx lo, hi;
+  if (t) {
+    lo = ubase[t];
+    hi = lo;
+  } else {
+    lo = mk(kSin64[1], kCos64[1]);  // i*exp(-2*pi*i/64) = sin + i*cos
+    hi = mk(-1.0f, 0.0f);
+  }
+  PostTw<0>::run(lo, hi, u);
 }
 
 }  // namespace mx

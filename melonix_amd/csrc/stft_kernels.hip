@@ -35,10 +35,17 @@ hipError_t launch_n(int mode, const StftArgs &a, hipStream_t s) {
   StftArgs b = a;
   b.frames_per_block = g;
   const dim3 grid((unsigned)blocks), block(C::T);
+  constexpr int W = Tune<N>::WPE;
+  constexpr bool NH = Tune<N>::NOHOIST;
   switch (mode) {
-    case kBulkAligned: hipLaunchKernelGGL((stft_kernel<N, kBulkAligned, Tune<N>::WPE, Tune<N>::NOHOIST>), grid, block, 0, s, b); break;
-    case kBulkAny: hipLaunchKernelGGL((stft_kernel<N, kBulkAny, Tune<N>::WPE, Tune<N>::NOHOIST>), grid, block, 0, s, b); break;
-    case kRanges: hipLaunchKernelGGL((stft_kernel<N, kRanges, Tune<N>::WPE, Tune<N>::NOHOIST>), grid, block, 0, s, b); break;
+    case kBulkAligned:
+      // the headline hops slide the windowed frame through registers (one HBM read per sample)
+      if (N == 4096 && a.hop == 256) hipLaunchKernelGGL((stft_kernel<N, kBulkAligned, (N == 4096 ? 256 : 0), W, NH>), grid, block, 0, s, b);
+      else if (N == 16384 && a.hop == 512) hipLaunchKernelGGL((stft_kernel<N, kBulkAligned, (N == 16384 ? 512 : 0), W, NH>), grid, block, 0, s, b);
+      else hipLaunchKernelGGL((stft_kernel<N, kBulkAligned, 0, W, NH>), grid, block, 0, s, b);
+      break;
+    case kBulkAny: hipLaunchKernelGGL((stft_kernel<N, kBulkAny, 0, W, NH>), grid, block, 0, s, b); break;
+    case kRanges: hipLaunchKernelGGL((stft_kernel<N, kRanges, 0, W, NH>), grid, block, 0, s, b); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -74,12 +74,17 @@ constexpr int kWOff = 32768;
 constexpr int kWDmax = 425984;  // 2.5e-4 * 425984 = 106.5 > 103.98 = ln(2^150)
 constexpr int kWTail = 32768;   // zeros past kWDmax so a clamped frame never leaves the table
 
-inline std::vector<float> make_wext() {
+// sc: output scale folded into the weights (1/(2N), a power of two: w*sc is exact, and
+// x*(w*sc) == (x*w)*sc bit for bit, so the kernel's magnitudes need no final multiply).
+inline std::vector<float> make_wext(float sc = 1.0f) {
   std::vector<float> w((size_t)kWOff + kWDmax + kWTail + 1, 0.0f);
-  for (int d = -kWOff; d <= 0; ++d) w[(size_t)(d + kWOff)] = 1.0f;
-  for (int d = 1; d <= kWDmax; ++d) w[(size_t)(d + kWOff)] = expf(-2.5e-4f * d);
+  for (int d = -kWOff; d <= 0; ++d) w[(size_t)(d + kWOff)] = sc;
+  for (int d = 1; d <= kWDmax; ++d) w[(size_t)(d + kWOff)] = expf(-2.5e-4f * d) * sc;
   return w;
 }
+inline float fold_scale(int N) { return 0.5f / (float)N; }
+// per-hop decay of the sliding window: exp(-2.5e-4*hop), rounded once
+inline float hop_decay(int hop) { return (float)exp(-2.5e-4 * (double)hop); }
 
 // Bulk mode (uniform hop): weight of frame position p is that of d = N-hop-p.
 inline std::vector<float> make_wtab(int N, int hop, const std::vector<float> &wext) {

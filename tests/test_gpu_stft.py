@@ -61,11 +61,17 @@ def test_hop_vs_oracle(gpu_ctx, oracle, N, hop):
     assert (err <= tol).all(), float((err / tol).max())
     _check_pitch(pitch[pick], ref, band, tol)
     assert np.array_equal(pitch["mag"], mags[np.arange(F), pitch["bin"]])
-    # frame indexing is bit-exact: ranges mode on the same (start,end) list gives identical rows
+    # frame indexing is bit-exact: with one frame per workgroup every frame is loaded directly
+    # (no sliding-window carry), and ranges mode on the same (start,end) list gives identical rows
+    gpu_ctx.set_frames_per_block(1)
+    m1, p1 = gpu_ctx.stft_hop(a, N, hop, band=band)
+    gpu_ctx.set_frames_per_block(0)
     rr = np.stack([pick * hop, (pick + 1) * hop], axis=1).astype(np.int32)
     m2, p2 = gpu_ctx.stft_ranges(a, N, rr, band=band)
-    assert np.array_equal(m2, mags[pick])
-    assert np.array_equal(p2, pitch[pick])
+    assert np.array_equal(m2, m1[pick])
+    assert np.array_equal(p2, p1[pick])
+    # the sliding register image (frames_per_block > 1) stays within tolerance of the direct load
+    assert (np.abs(mags - m1) <= mag_tol(m1) / 10).all()
     a.free()
 
 
@@ -98,15 +104,22 @@ def test_linearity_and_silence(gpu_ctx):
 
 
 def test_frames_per_block_invariance(gpu_ctx):
+    """hop 375 has no sliding carry: any workgroup shape gives identical bits; hop 256 slides the
+    register image, which may move results by a few 1e-7 of the frame peak, never more."""
     w = noisy(accum_sweep(2 * SR))
     a = gpu_ctx.upload(w)
-    ref = None
-    for g in (1, 3, 16, 64):
-        gpu_ctx.set_frames_per_block(g)
-        m, p = gpu_ctx.stft_hop(a, 4096, 256)
-        if ref is None:
-            ref = (m, p)
-        assert np.array_equal(m, ref[0]) and np.array_equal(p, ref[1])
+    for hop, exact in ((375, True), (256, False)):
+        ref = None
+        for g in (1, 3, 16, 64, 1000):
+            gpu_ctx.set_frames_per_block(g)
+            m, p = gpu_ctx.stft_hop(a, 4096, hop)
+            if ref is None:
+                ref = (m, p)
+            if exact:
+                assert np.array_equal(m, ref[0]) and np.array_equal(p, ref[1])
+            else:
+                assert (np.abs(m - ref[0]) <= mag_tol(ref[0]) / 10).all()
+                assert (np.abs(p["bin"] - ref[1]["bin"]) <= 1).all()
     gpu_ctx.set_frames_per_block(0)
     a.free()
 

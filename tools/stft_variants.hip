@@ -22,17 +22,17 @@ using namespace mx;
     }                                                                          \
   } while (0)
 
-template <int N, int MODE, int WPE, bool NH>
+template <int N, int MODE, int HOP, int WPE, bool NH, bool XM = true>
 float time_variant(const StftArgs &a, int reps, const char *name) {
   using C = Cfg<N>;
   const int64_t blocks = (a.count + a.frames_per_block - 1) / a.frames_per_block;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<N, MODE, WPE, NH>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<N, MODE, HOP, WPE, NH, XM>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<N, MODE, WPE, NH>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<N, MODE, HOP, WPE, NH, XM>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -172,7 +172,7 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&d_mags, (size_t)F * (N / 2) * 4));
   CK(hipMalloc(&d_pitch, (size_t)F * sizeof(mx_pitch)));
   CK(hipMalloc(&d_out, 256 * 8 * 256 * 4));
-  auto wext = make_wext();
+  auto wext = make_wext(fold_scale(N));
   auto wtab = make_wtab(N, hop, wext);
   auto tw2 = make_tw2<N>();
   auto tw3 = make_tw3<N>();
@@ -196,22 +196,19 @@ int main(int argc, char **argv) {
 
   StftArgs a{};
   a.audio = d_audio; a.n = n; a.wtab = d_wtab; a.tw2 = d_tw2; a.tw3 = d_tw3; a.ubase = d_ub;
+  a.decay = hop_decay(hop);
   a.hop = hop; a.first_frame = 0; a.count = F; a.kmin = 5; a.kmax = 150; a.mags = d_mags; a.pitch = d_pitch;
   const int reps = 5;
-  for (int g : {4, 16, 64}) {
+  for (int g : {4, 8, 16, 32, 64, 128}) {
     a.frames_per_block = g;
-    time_variant<N, kBulkAligned, 1, false>(a, reps, "wpe1 hoist");
-    time_variant<N, kBulkAligned, 2, false>(a, reps, "wpe2 hoist");
-    time_variant<N, kBulkAligned, 1, true>(a, reps, "wpe1 nohoist");
-    time_variant<N, kBulkAligned, 2, true>(a, reps, "wpe2 nohoist");
-    time_variant<N, kBulkAligned, 3, true>(a, reps, "wpe3 nohoist");
-    time_variant<N, kBulkAligned, 4, true>(a, reps, "wpe4 nohoist");
+    time_variant<N, kBulkAligned, 0, 2, true, true>(a, reps, "direct  wpe2");
+    time_variant<N, kBulkAligned, 256, 2, true, true>(a, reps, "sliding wpe2");
   }
-  a.frames_per_block = 16;
+  a.frames_per_block = 32;
   a.mags = nullptr;
-  time_variant<N, kBulkAligned, 2, true>(a, reps, "wpe2 nohoist pitch-only");
+  time_variant<N, kBulkAligned, 256, 2, true, true>(a, reps, "sliding wpe2 pitch-only");
   a.mags = d_mags;
   a.pitch = nullptr;
-  time_variant<N, kBulkAligned, 2, true>(a, reps, "wpe2 nohoist mags-only");
+  time_variant<N, kBulkAligned, 256, 2, true, true>(a, reps, "sliding wpe2 mags-only");
   return 0;
 }
