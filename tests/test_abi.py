@@ -1,0 +1,74 @@
+"""The C-ABI library loads, exports every symbol include/melonix_amd.h declares, and refuses to
+compute without a gfx950 device (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "melonix_amd.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_compiles_as_c_and_cpp(tmp_path):
+    for comp, std in (("gcc", "-std=c99"), ("g++", "-std=c++17")):
+        src = tmp_path / ("t.c" if comp == "gcc" else "t.cpp")
+        src.write_text('#include "melonix_amd.h"\nint main(void){return sizeof(mx_step)==40 && sizeof(mx_pitch)==8 ? 0 : 1;}\n')
+        exe = tmp_path / ("t_" + comp)
+        subprocess.check_call([comp, std, "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+        assert subprocess.call([str(exe)]) == 0
+
+
+def test_every_declared_symbol_is_exported(mxlib):
+    from melonix_amd import _capi
+    names = _declared()
+    assert len(names) >= 30
+    lib = C.CDLL(_capi.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # and the ctypes table binds exactly the declared set
+    assert sorted(_capi.SIGNATURES) == names
+
+
+def test_no_oracle_in_product():
+    """The product never links, loads or imports the oracle."""
+    from melonix_amd import _capi
+    deps = subprocess.check_output(["ldd", _capi.LIB_PATH]).decode()
+    assert "oracle" not in deps
+    syms = subprocess.check_output(["nm", "-D", _capi.LIB_PATH]).decode()
+    assert "mxo_" not in syms
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "melonix_amd")):
+        if "build" in dirpath.split(os.sep):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".hpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in txt and "melonix_oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_fails_loudly_without_gpu(mxlib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(mxlib.MxError) as e:
+        mxlib.Context(0)
+    assert e.value.code == -2 and "no CPU path" in str(e.value)
+
+
+def test_resampler_isa_has_no_fma():
+    """resynth_kernels.hip must not contract (1-f)*a + f*b (bit-exact PCM)."""
+    src = os.path.join(ROOT, "melonix_amd", "csrc", "resynth_kernels.hip")
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                          "--cuda-device-only", "-x", "hip", src, "-o", "-"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    body = out.stdout[out.stdout.index("resynth_kernel"):]
+    body = body[:body.index("s_endpgm")]
+    assert not re.search(r"\bv_(fma|fmac|mad|pk_fma)_f32", body)
+    assert "v_mul_f64" in body and "v_cvt_i32_f64" in body  # app.cpp:1212: double multiply, truncation

@@ -1,0 +1,92 @@
+"""N>1 path on CPU: world_size-2 gloo.  Checks the frame sharding + halo construction + the one
+all-gather (pitch tracks) against an unsharded run.  The per-rank transform is stood in for by the
+oracle here (there is no GPU in this container); on the GPU box bench.py runs the same sharding
+with the HIP kernel."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import SR, accum_sweep, noisy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, N, hop, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import accum_sweep as sweep, noisy as nz
+    from melonix_amd import shard as sh
+    from oracle import pyoracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = nz(sweep(n))
+    s = sh.shard_frames(n, N, hop, rank, world)
+    img, own = sh.padded_shard(w, s)
+    # local indexing: the shard starts on a frame boundary, so local frame f is global frame lo+f;
+    # the padded image (true neighbour samples in the pads) is what the device kernel reads
+    band = O.pitch_band(N, SR)
+    local = img[sh.MX_AUDIO_PAD - (N - hop): sh.MX_AUDIO_PAD + own + hop]  # halo + own (+ right spill)
+    off = N - hop
+    mags = np.stack([O.spec_frame(local, N, off + f * hop, off + (f + 1) * hop) for f in range(s.frames)]) \
+        if s.frames else np.zeros((0, N // 2), np.float32)
+    # the oracle zero-fills outside `local`; the left halo must therefore cover N-hop samples exactly
+    pitch = np.zeros((s.frames, 2), np.int32)
+    for f in range(s.frames):
+        b, m = O.pitch_pick(mags[f], *band)
+        pitch[f] = (b, np.float32(m).view(np.int32))
+    # equal-sized gather: pad to the largest shard, carry true counts
+    fmax = sh.shard_frames(n, N, hop, 0, world).frames
+    buf = torch.zeros((fmax, 2), dtype=torch.int32)
+    buf[: s.frames] = torch.from_numpy(pitch)
+    out = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    counts = [sh.shard_frames(n, N, hop, r, world).frames for r in range(world)]
+    track = np.concatenate([out[r][: counts[r]].numpy() for r in range(world)])
+    if rank == 0:
+        q.put((track, mags[:3].copy(), s))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,hop,n", [(4096, 256, 48000 + 100), (4096, 375, 40000)])
+def test_two_rank_shards_equal_unsharded(oracle, N, hop, n):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, N, hop, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    track, _, s0 = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = noisy(accum_sweep(n))
+    mags, pb, pm = oracle.stft_hop(w, N, hop, band=oracle.pitch_band(N, SR))
+    assert len(track) == len(pb)
+    assert np.array_equal(track[:, 0], pb)                       # bit-exact: shard(2) == unsharded
+    assert np.array_equal(track[:, 1].view(np.float32), pm)
+
+
+def test_shard_arithmetic():
+    from melonix_amd import shard as sh
+
+    for n, N, hop in ((172_800_000, 4096, 256), (1000, 4096, 256), (480_000, 32768, 375), (7, 4096, 3)):
+        F = sh.frame_count(n, hop)
+        for world in (1, 2, 3, 4, 8):
+            parts = [sh.shard_frames(n, N, hop, r, world) for r in range(world)]
+            assert parts[0].lo == 0 and parts[-1].hi == F
+            assert all(a.hi == b.lo for a, b in zip(parts, parts[1:]))
+            assert max(p.frames for p in parts) - min(p.frames for p in parts) <= 1
+            assert all(p.sample_lo == p.lo * hop and p.halo_left == min(N - hop, p.sample_lo) for p in parts)
+    for nsteps in (0, 1, 7, 137_000):
+        for world in (1, 2, 8):
+            r = [sh.shard_steps(nsteps, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == nsteps and all(a[1] == b[0] for a, b in zip(r, r[1:]))

@@ -1,0 +1,128 @@
+"""Product host logic (time maps, grain chain, schedule recurrence, RIFF writer — melonix_amd/csrc/
+host_logic.cpp through the C-ABI) against the oracle.  No GPU involved."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from conftest import SR, accum_sweep, noisy
+
+FIELDS = ("cursor", "grain_start", "grain_len", "rate", "next_first", "sz", "out_offset")
+
+
+def _same_steps(a, b):
+    return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in FIELDS)
+
+
+def test_grains_match_oracle(mxlib, oracle, sweep10):
+    for w in (sweep10, noisy(sweep10, level=0.05), np.zeros(SR, np.float32), -np.abs(sweep10[:SR]),
+              np.abs(sweep10[:SR]), sweep10[:1501], sweep10[:1502], sweep10[:3000]):
+        s, l = mxlib.grains_host(w)
+        rs, rl = oracle.grains(w)
+        assert np.array_equal(s, rs) and np.array_equal(l, rl)
+
+
+def test_grains_fallback_lookaround3(mxlib, oracle):
+    """A signal whose sign runs are 4 samples long: never 7 in a row, so only the lookAround-3
+    fallback (app.cpp:198-228) can cut grains."""
+    n = 60000
+    w = np.where((np.arange(n) // 4) % 2 == 0, -0.3, 0.3).astype(np.float32)
+    s, l = mxlib.grains_host(w)
+    rs, rl = oracle.grains(w)
+    assert len(rs) > 5 and (rl >= 2250).all()
+    assert np.array_equal(s, rs) and np.array_equal(l, rl)
+
+
+@pytest.mark.parametrize("pb,calls,samples", [(0, 320, 480407), (3, 379, 478903), (-4, 254, 479781), (7.5, 491, 479189)])
+def test_schedule_known_answers(mxlib, oracle, sweep10, pb, calls, samples):
+    n = len(sweep10)
+    mk = [(1, 0, 0, pb), (n - 1, 0, 0, pb)]
+    s, l = mxlib.grains_host(sweep10)
+    steps, total = mxlib.schedule_build(sweep10, SR, s, l, mk)
+    assert len(steps) + 1 == calls and total == samples
+    osteps, opcm = oracle.export_run(sweep10, SR, mk)
+    assert _same_steps(steps, osteps) and total == len(opcm)
+
+
+def test_schedule_warp_markers(mxlib, oracle, sweep10):
+    w = noisy(sweep10, level=0.05)
+    n = len(w)
+    mk = [(1000, 0, 0.0, 2.0), (100000, 0, 0.5, -3.0), (300000, 0, -0.2, 5.0), (n - 1, 0, 0, 0)]
+    s, l = mxlib.grains_host(w)
+    steps, total = mxlib.schedule_build(w, SR, s, l, mk)
+    osteps, opcm = oracle.export_run(w, SR, mk, memo=True)  # memo-faithful oracle
+    assert _same_steps(steps, osteps) and total == len(opcm)
+    assert (steps["out_offset"][1:] == np.cumsum(steps["sz"])[:-1]).all()
+    assert total == int(steps["sz"].sum()) + 1500
+
+
+def test_schedule_rejects_bad_input(mxlib, sweep10):
+    s, l = mxlib.grains_host(sweep10)
+    with pytest.raises(mxlib.MxError):
+        mxlib.schedule_build(sweep10, SR, s, l, [(5000, 0, 0, 0), (10, 0, 0, 0)])  # unsorted markers
+    with pytest.raises(mxlib.MxError):
+        mxlib.schedule_build(sweep10, SR, s, l, [(1, 0, 0, -2000.0), (len(sweep10) - 1, 0, 0, -2000.0)])  # rate -> 0
+
+
+markers_st = st.lists(
+    st.tuples(st.integers(1, 479_999), st.just(0.0), st.floats(-0.3, 0.5), st.floats(-12, 12)),
+    min_size=0, max_size=5).map(lambda m: sorted(m, key=lambda x: x[0]))
+
+
+@settings(max_examples=60, deadline=None)
+@given(markers_st, st.lists(st.floats(-1.0, 12.0), min_size=1, max_size=20))
+def test_time_maps_match_oracle(mxlib, oracle, mk, vals):
+    n = 480_000
+    tm = oracle.TimeMap(mk, SR, n, memo=False)
+    assert mxlib.duration(mk, SR, n) == tm.duration()
+    for v in vals:
+        assert mxlib.time2sample(mk, SR, v) == tm.time2sample(v)
+        assert mxlib.time2pitchbend(mk, SR, n, v) == tm.time2pitchbend(v)
+        sv = int(v * SR)
+        assert mxlib.sample2time(mk, SR, sv) == tm.sample2time(sv)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.floats(0.0, 20.0), st.integers(64, 4000), st.floats(0.5, 30.0))
+def test_column_range_matches_oracle(mxlib, oracle, t, width, range_time):
+    assert mxlib.column_range([], SR, t, width, range_time) == oracle.TimeMap([], SR, 480000).column_range(t, width, range_time)
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(0, 2**31 - 1), st.floats(-9.0, 9.0))
+def test_schedule_property(mxlib, oracle, seed, pb):
+    """Random signal + constant bend: schedule equals the oracle's, chain covers the PCM without gaps."""
+    rng = np.random.default_rng(seed)
+    n = 3 * SR
+    t = np.arange(n) / SR
+    w = (0.4 * np.sin(2 * np.pi * rng.uniform(60, 900) * t + rng.uniform(0, 6)) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    mk = [(1, 0, 0, pb), (n - 1, 0, 0, pb)]
+    s, l = mxlib.grains_host(w)
+    rs, rl = oracle.grains(w)
+    assert np.array_equal(s, rs) and np.array_equal(l, rl)
+    steps, total = mxlib.schedule_build(w, SR, s, l, mk)
+    osteps, opcm = oracle.export_run(w, SR, mk)
+    assert _same_steps(steps, osteps) and total == len(opcm)
+
+
+@pytest.mark.parametrize("m", [0, 1, 2, 3, 999, 70001])
+def test_save_wav_strict_matches_reference(mxlib, oracle, tmp_path, m):
+    rng = np.random.default_rng(m)
+    pcm = rng.integers(-32768, 32767, m, dtype=np.int16)
+    p = tmp_path / "a.wav"
+    mxlib.save_wav(p, pcm, SR, strict=True)
+    got = p.read_bytes()
+    assert got == oracle.wav_bytes(pcm, SR)
+    ref = oracle.ref_wav_bytes(pcm, SR, tmp_path / "r.wav")  # the reference's own save-wav.cpp
+    if ref is not None:
+        assert got == ref
+
+
+def test_save_wav_correct_header(mxlib, tmp_path):
+    pcm = np.arange(-5, 5, dtype=np.int16)
+    p = tmp_path / "b.wav"
+    mxlib.save_wav(p, pcm, 44100, strict=False)
+    b = p.read_bytes()
+    assert len(b) == 44 + 20 and b[:4] == b"RIFF" and b[8:16] == b"WAVEfmt " and b[36:40] == b"data"
+    assert int.from_bytes(b[40:44], "little") == 20 and int.from_bytes(b[4:8], "little") == len(b) - 8
+    assert np.array_equal(np.frombuffer(b[44:], dtype="<i2"), pcm)
+    assert int.from_bytes(b[24:28], "little") == 44100 and int.from_bytes(b[28:32], "little") == 88200
