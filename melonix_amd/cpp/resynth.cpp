@@ -1,0 +1,71 @@
+#include "resynth.hpp"
+
+#include <cstring>
+
+#include "melonix_amd.h"
+#include "save-wav.hpp"
+
+static_assert(sizeof(Marker) == sizeof(mx_marker), "Marker must stay layout-compatible with mx_marker");
+
+namespace melonix {
+
+Resynth::Resynth(std::span<const float> wav, int sampleRate, int device)
+    : host(wav.begin(), wav.end()), sampleRate(sampleRate) {
+  if (mx_ctx_create(device, &ctx) != MX_OK) {
+    ctx = nullptr;
+    return;
+  }
+  if (mx_audio_upload(ctx, host.data(), (int64_t)host.size(), &audio) != MX_OK) {
+    audio = nullptr;
+    return;
+  }
+  int32_t *s = nullptr, *l = nullptr;
+  int64_t n = 0;
+  if (mx_grains_dev(ctx, audio, &s, &l, &n) == MX_OK) {
+    starts.assign(s, s + n);
+    lens.assign(l, l + n);
+    mx_free(s);
+    mx_free(l);
+  }
+}
+
+Resynth::~Resynth() {
+  if (audio) mx_audio_free(ctx, audio);
+  if (ctx) mx_ctx_destroy(ctx);
+}
+
+bool Resynth::run(const std::vector<Marker> &markers, std::vector<float> *f32, std::vector<int16_t> *i16) const {
+  if (!ok()) return false;
+  mx_step *steps = nullptr;
+  int64_t nsteps = 0, nsamples = 0;
+  const mx_marker *mk = reinterpret_cast<const mx_marker *>(markers.data());
+  if (mx_schedule_build(host.data(), (int64_t)host.size(), sampleRate, starts.data(), lens.data(),
+                        (int64_t)starts.size(), mk, (int)markers.size(), &steps, &nsteps, &nsamples) != MX_OK)
+    return false;
+  if (f32) f32->resize((size_t)nsamples);
+  if (i16) i16->resize((size_t)nsamples);
+  const int rc = mx_resynth(ctx, audio, steps, nsteps, nsamples, f32 ? f32->data() : nullptr, i16 ? i16->data() : nullptr);
+  mx_free(steps);
+  return rc == MX_OK;
+}
+
+std::vector<float> Resynth::render(const std::vector<Marker> &markers) const {
+  std::vector<float> pcm;
+  if (!run(markers, &pcm, nullptr)) pcm.clear();
+  return pcm;
+}
+
+std::vector<int16_t> Resynth::render16(const std::vector<Marker> &markers) const {
+  std::vector<int16_t> pcm;
+  if (!run(markers, nullptr, &pcm)) pcm.clear();
+  return pcm;
+}
+
+bool Resynth::exportWav(const std::string &fileName, const std::vector<Marker> &markers) const {
+  std::vector<int16_t> pcm16;
+  if (!run(markers, nullptr, &pcm16)) return false;
+  saveWav(fileName, pcm16, sampleRate);  // app.cpp:1214
+  return true;
+}
+
+}  // namespace melonix

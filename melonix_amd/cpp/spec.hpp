@@ -1,0 +1,39 @@
+// spec.hpp — drop-in for the reference's Spec (spec.hpp:11-16): identical public surface and
+// caller-visible semantics; the transform runs on an MI355X through the C-ABI (melonix_amd.h).
+//
+//   Spec(std::span<float> wav)   the samples are copied to HBM once (the reference keeps a span
+//                                into App::wavData for its whole life, app.cpp:251)
+//   getSpec(start, end) const    NEVER blocks on compute.  First touch of a (start,end) key
+//                                queues it and returns {}; a later call returns the N/2
+//                                magnitudes (spec.cpp:18-42).  At most MaxRanges keys are kept,
+//                                least recently used first out.
+//
+// Observable difference: one GPU launch drains the WHOLE pending set (the reference computes one
+// column per worker iteration, spec.cpp:68-97), so a cold 1280-column view fills within a vsync or
+// two instead of ~0.5 s.  Without a usable MI355X the object still constructs and every column
+// simply stays empty — the reference's own failure mode (black columns), there is no CPU path.
+#pragma once
+#include <memory>
+#include <span>
+#include <vector>
+
+#include "range.hpp"
+
+class Spec {
+public:
+  Spec(std::span<float> wav);
+  // fftSize 32768 is the reference's SpectrSize (spec.cpp:8); 4096 and 16384 are also available.
+  Spec(std::span<float> wav, int fftSize, int device = 0);
+  ~Spec();
+  Spec(const Spec &) = delete;
+  Spec &operator=(const Spec &) = delete;
+
+  auto getSpec(int start, int end) const -> std::vector<float>;
+
+  int fftSize() const;
+  bool ok() const;  // false when no MI355X context / upload failed
+
+private:
+  struct Impl;
+  std::unique_ptr<Impl> impl;
+};

@@ -1,0 +1,115 @@
+// facade_driver.cpp — TEST INFRASTRUCTURE: drives the C++ drop-in facade (Spec, SpecCache, saveWav,
+// melonix::Resynth) the way App does (app.cpp:251, 881-884, 1214) with the GL calls captured, and
+// dumps what it produced for tests/test_gpu_facade.py to compare with the oracle.
+//   facade_driver <audio.f32> <outdir> <fftSize>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "resynth.hpp"
+#include "save-wav.hpp"
+#include "spec-cache.hpp"
+
+// ---- captured GL (MELONIX_AMD_NO_GL) ----
+static GLuint g_next = 1, g_bound = 0;
+static int g_live = 0;
+static std::map<GLuint, std::vector<unsigned char>> g_tex;
+extern "C" {
+void glGenTextures(GLsizei n, GLuint *t) { for (int i = 0; i < n; ++i) { t[i] = g_next++; ++g_live; } }
+void glDeleteTextures(GLsizei n, const GLuint *t) { for (int i = 0; i < n; ++i) { g_tex.erase(t[i]); --g_live; } }
+void glBindTexture(GLenum, GLuint t) { g_bound = t; }
+void glTexParameteri(GLenum, GLenum, GLint) {}
+void glTexImage1D(GLenum, GLint, GLint, GLsizei w, GLint, GLenum, GLenum, const void *p) {
+  g_tex[g_bound].assign((const unsigned char *)p, (const unsigned char *)p + 3 * (size_t)w);
+}
+}
+
+template <class T>
+static void dump(const std::string &path, const std::vector<T> &v) {
+  std::ofstream f(path, std::ios::binary);
+  f.write((const char *)v.data(), (std::streamsize)(v.size() * sizeof(T)));
+}
+
+int main(int argc, char **argv) {
+  if (argc < 4) return 2;
+  const std::string out = argv[2];
+  const int N = atoi(argv[3]);
+  std::vector<float> wav;
+  {
+    std::ifstream f(argv[1], std::ios::binary | std::ios::ate);
+    wav.resize((size_t)f.tellg() / sizeof(float));
+    f.seekg(0);
+    f.read((char *)wav.data(), (std::streamsize)(wav.size() * sizeof(float)));
+  }
+  const int sr = 48000;
+  int fails = 0;
+  auto check = [&](bool ok, const char *what) { if (!ok) { ++fails; fprintf(stderr, "FAIL: %s\n", what); } };
+
+  {
+    Spec spec(std::span<float>{wav.data(), wav.size()}, N);
+    check(spec.ok(), "Spec has a device context");
+    // getSpec never blocks: first touch is empty, later the row appears (spec.cpp:18-42)
+    const std::vector<std::pair<int, int>> keys = {{47000, 47375}, {0, 256}, {-500, -100}, {100000, 100001}};
+    for (auto k : keys) check(spec.getSpec(k.first, k.second).empty(), "first getSpec returns {}");
+    std::vector<float> rows;
+    for (auto k : keys) {
+      std::vector<float> r;
+      for (int spin = 0; spin < 2000 && r.empty(); ++spin) {
+        r = spec.getSpec(k.first, k.second);
+        if (r.empty()) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
+      check(r.size() == (size_t)N / 2, "row arrives with N/2 bins");
+      rows.insert(rows.end(), r.begin(), r.end());
+    }
+    dump(out + "/rows.f32", rows);
+
+    // SpecCache exactly as App::getTex builds it (app.cpp:881-884), identity time map
+    const float kk = 512.f * 64;  // brightness 60 -> k = 2^(b/10+9) (app.cpp:75)
+    SpecCache cache(spec, kk, 1280, 10.0, [&](double v) { return (int)(v * sr); });
+    const double times[] = {1.0, 2.5, 0.0, 7.123};
+    std::vector<unsigned char> texels;
+    std::vector<float> texrows;
+    for (double t : times) {
+      GLuint name = cache.getTex(t);
+      check(g_tex[name].size() == 16 * 3, "cold column is 16 black texels");
+      for (int spin = 0; spin < 2000 && g_tex[name].size() != (size_t)N / 2 * 3; ++spin) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        name = cache.getTex(t);
+      }
+      check(g_tex[name].size() == (size_t)N / 2 * 3, "column texture has N/2 texels");
+      texels.insert(texels.end(), g_tex[name].begin(), g_tex[name].end());
+      const int key = (int)(t * 1280 / 10.0);
+      const double left = key * 10.0 / 1280;
+      const auto r = spec.getSpec((int)(left * sr), (int)((left + 10.0 / 1280) * sr));
+      texrows.insert(texrows.end(), r.begin(), r.end());
+      check(cache.getTex(t) == name, "clean column returns the same texture");
+    }
+    dump(out + "/tex.u8", texels);
+    dump(out + "/texrows.f32", texrows);
+    const int before = g_live;
+    cache.clear();
+    check(g_live == before - 4, "clear() releases the textures");
+  }
+
+  {  // saveWav: reference signature, strict header
+    std::vector<int16_t> pcm(1000);
+    for (int i = 0; i < 1000; ++i) pcm[i] = (int16_t)(i * 37 - 12000);
+    saveWav(out + "/plain.wav", pcm, sr);
+  }
+  {  // exportWav-equivalent at +3 semitones (SURVEY C1 markers)
+    melonix::Resynth rs(std::span<const float>{wav.data(), wav.size()}, sr);
+    check(rs.ok(), "Resynth has a device context");
+    std::vector<Marker> mk = {{1, 0, 0, 3.0}, {(int)wav.size() - 1, 0, 0, 3.0}};
+    check(rs.exportWav(out + "/export.wav", mk), "exportWav");
+    dump(out + "/pcm.f32", rs.render(mk));
+    std::vector<int32_t> g = rs.grainStarts();
+    dump(out + "/grains.i32", g);
+  }
+  printf("facade_driver: %d failure(s)\n", fails);
+  return fails ? 1 : 0;
+}
