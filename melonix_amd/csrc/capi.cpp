@@ -75,11 +75,12 @@ int default_frames_per_block(int N) {
   return N == 4096 ? 16 : (N == 16384 ? 8 : 4);
 }
 
-template <int N>
+template <class P>
 int build_tables(NTables &t) {
-  const auto tw2 = make_tw2<N>();
-  const auto tw3 = make_tw3<N>();
-  const auto ub = make_ubase<N>();
+  constexpr int N = P::N;
+  const auto tw2 = make_tw2<P>();
+  const auto tw3 = make_tw3<P>();
+  const auto ub = make_ubase<P>();
   HIP_TRY(hipMalloc(&t.tw2, tw2.size() * sizeof(float2)));
   HIP_TRY(hipMalloc(&t.tw3, tw3.size() * sizeof(float2)));
   HIP_TRY(hipMalloc(&t.ubase, ub.size() * sizeof(float2)));
@@ -102,9 +103,9 @@ int get_tables(mx_ctx *ctx, int N, NTables &out) {
   NTables t;
   int rc;
   switch (N) {
-    case 4096: rc = build_tables<4096>(t); break;
-    case 16384: rc = build_tables<16384>(t); break;
-    case 32768: rc = build_tables<32768>(t); break;
+    case 4096: rc = build_tables<Plan<4096, kPlan4096E>>(t); break;
+    case 16384: rc = build_tables<Plan<16384, 32>>(t); break;
+    case 32768: rc = build_tables<Plan<32768, 32>>(t); break;
     default: return fail(MX_ERR_INVALID, "unsupported FFT size %d (supported: 4096, 16384, 32768)", N);
   }
   if (rc) return rc;

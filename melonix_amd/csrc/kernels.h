@@ -36,6 +36,12 @@ struct StftArgs {
 };
 
 hipError_t launch_stft(int N, int mode, const StftArgs &a, hipStream_t s);
+// Points per thread of the plan launch_stft uses for N (selects the twiddle tables to upload).
+#ifndef MX_PLAN_4096_E
+#define MX_PLAN_4096_E 16
+#endif
+constexpr int kPlan4096E = MX_PLAN_4096_E;
+int stft_points_per_thread(int N);
 
 struct ResynthArgs {
   const float *audio;  // padded image

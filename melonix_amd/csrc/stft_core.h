@@ -7,19 +7,21 @@
 // involved.  Nothing here is a CPU fallback: the product only instantiates
 // these templates inside __global__ kernels (stft_kernels.hip).
 //
-// Scheme (N real samples, M = N/2 packed complex points, 32 points per thread,
-// T = M/32 threads per frame = one workgroup per hop):
-//   pass 1  radix R1, straight from the windowed samples in HBM
+// Scheme (N real samples, M = N/2 packed complex points z[m] = x[2m] + i*x[2m+1],
+// E points per thread, T = M/E threads per frame = one workgroup per hop):
+//   pass 1  radix R1, on the windowed samples (register image Y, see Slide)
 //   -- transposition T1 through LDS (in place, XOR-swizzled) --
 //   pass 2  radix R2 with twiddles exp(-2*pi*i*r*k/(R1*R2))
 //   -- transposition T2 through LDS --
-//   pass 3  radix 16 with twiddles exp(-2*pi*i*r*k0/M); thread t owns the
+//   pass 3  radix R3 = E/2 with twiddles exp(-2*pi*i*r*k0/M); thread t owns the
 //           butterflies k0 = t and NS3 - t, i.e. both members of every
 //           (k, M-k) pair the real-FFT split needs, so the split, the
 //           magnitude and the pitch pick never leave registers.
-//   N = 4096 : R = 8,16,16  T = 64  (one wavefront per frame, 16 KiB LDS)
-//   N = 16384: R = 32,16,16 T = 256 (64 KiB LDS)
-//   N = 32768: R = 32,32,16 T = 512 (128 KiB LDS; the reference's SpectrSize)
+// Plans (Plan<N, E>):
+//   N = 4096,  E = 32: R = 8,16,16   T = 64   one wavefront per frame
+//   N = 4096,  E = 16: R = 16,16,8   T = 128  two wavefronts per frame, half the registers
+//   N = 16384, E = 32: R = 32,16,16  T = 256
+//   N = 32768, E = 32: R = 32,32,16  T = 512  (the reference's SpectrSize)
 #pragma once
 #include <stdint.h>
 
@@ -56,12 +58,16 @@ MX_HD cpx cconj(cpx a) { return mk(a.x, -a.y); }
 // push the register array into scratch)
 MX_HD cpx csel(bool c, cpx a, cpx b) { return mk(c ? a.x : b.x, c ? a.y : b.y); }
 MX_HD float fast_sqrt(float x) {
+#ifdef MX_ABL_NOSQRT
+  return x * 0.5f;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_sqrtf(x);  // v_sqrt_f32, 1 ulp
 #else
   return __builtin_sqrtf(x);
 #endif
 }
+MX_HD constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
 
 // a * exp(-2*pi*i*K/64), K a compile-time constant.
 template <int K>
@@ -120,22 +126,24 @@ struct Dft<1> {
 };
 
 // ---- geometry -------------------------------------------------------------
-template <int N_>
-struct Cfg {
+template <int N_, int E_>
+struct Plan {
   static constexpr int N = N_;
   static constexpr int M = N / 2;   // packed complex points
-  static constexpr int E = 32;      // points per thread
+  static constexpr int E = E_;      // points per thread
   static constexpr int T = M / E;   // threads per frame
-  static constexpr int R1 = (N == 4096) ? 8 : 32;
-  static constexpr int R2 = (N == 32768) ? 32 : 16;
-  static constexpr int R3 = 16;
-  static constexpr int NS3 = R1 * R2;  // finished sub-transform size entering pass 3 (= M/16)
+  static constexpr int R3 = E / 2;  // last pass: one butterfly pair per thread
+  static constexpr int R1 = (N == 4096) ? (E == 32 ? 8 : 16) : 32;
+  static constexpr int R2 = M / (R1 * R3);
+  static constexpr int NS3 = R1 * R2;  // finished sub-transform size entering pass 3 (= M/R3)
   static constexpr int NB1 = E / R1;   // butterflies per thread in pass 1
   static constexpr int NB2 = E / R2;
   static constexpr int TW2 = (R2 - 1) * R1;   // entries of the pass-2 twiddle table
   static constexpr int TW3 = (R3 - 1) * NS3;  // entries of the pass-3 twiddle table
+  static constexpr int L1 = ilog2(R1);
   static_assert(N == 4096 || N == 16384 || N == 32768, "supported FFT sizes");
-  static_assert(R1 * R2 * R3 == M, "radix plan must cover M");
+  static_assert(E == 32 || (E == 16 && N == 4096), "supported points per thread");
+  static_assert(R1 * R2 * R3 == M && R2 <= E && R1 <= E && T % 64 == 0, "radix plan must cover M");
 };
 
 // XOR swizzles of the complex index (8-byte granules) inside the LDS image.
@@ -143,39 +151,33 @@ struct Cfg {
 // T2 is written in runs of R1 and read contiguously.  Both keep every aligned
 // block of 32 complex points a permutation of itself, so contiguous reads stay
 // conflict-free while the strided writes spread over all banks
-// (tools/lds_sim.py checks this against the gfx950 lane-group model).
-template <int N>
-MX_HD int swz1(int i) {
-  if constexpr (Cfg<N>::R1 == 8) return i ^ ((i >> 3) & 15);
-  else return i ^ ((i >> 5) & 15);
-}
-template <int N>
+// (SQ_LDS_BANK_CONFLICT = 0 in profiles/).
+template <class P>
+MX_HD int swz1(int i) { return i ^ ((i >> P::L1) & 15); }
+template <class P>
 MX_HD int swz2(int i) {
-  if constexpr (Cfg<N>::R1 == 8) return i ^ (((i >> 7) & 1) << 3);
+  if constexpr (P::R1 == 8) return i ^ (((i >> 7) & 1) << 3);
   else return i;
 }
 
-// ---- pass 1: windowed samples -> radix-R1 butterflies ----------------------
-// x points at the frame's first sample (file index end-N); w at the weight of
-// that sample.  WSTEP = +1: w[p] (bulk table, forward); WSTEP = -1: w[-p]
-// (the d-indexed table walked downwards, ranges mode).  ALIGNED8: x and w are
-// 8-byte aligned so the pair (2m, 2m+1) is one 64-bit load.
+// ---- the windowed frame -----------------------------------------------------
+// Y[e], e = b + NB1*r, is the packed complex point c = t + T*e (samples 2c, 2c+1 of the
+// frame), i.e. input r of pass-1 butterfly j = t + T*b.  The window tables carry the
+// output scale 1/(2N) (a power of two, so x*(w*2^-k) == (x*w)*2^-k bit for bit):
+// magnitudes come out of the split already scaled and the per-bin multiply disappears.
+// x points at the frame's first sample (file index end-N); w at the weight of that sample.
+// WSTEP = +1: w[p] (bulk table, forward); WSTEP = -1: w[-p] (the d-indexed table walked
+// downwards, ranges mode).  ALIGNED8: x and w are 8-byte aligned (one 64-bit load per pair).
 struct alignas(4) f2u {  // 4-byte aligned pair for frames starting at odd samples
   float x, y;
 };
 
-// The windowed frame as the thread sees it: Y[e], e = b + NB1*r, is the packed complex
-// point c = t + T*e  (samples 2c, 2c+1 of the frame), i.e. input r of pass-1 butterfly
-// j = t + T*b.  The window tables carry the output scale 1/(2N) (a power of two, so
-// x*(w*2^-k) == (x*w)*2^-k bit for bit): magnitudes come out of the split already
-// scaled and the per-bin multiply disappears.
-template <int N, int WSTEP, bool ALIGNED8>
-MX_HD void load_frame(int t, cpx (&Y)[32], const float *x, const float *w) {
+template <class P, int WSTEP, bool ALIGNED8>
+MX_HD void load_frame(int t, cpx (&Y)[P::E], const float *x, const float *w) {
 #pragma clang fp contract(off)  // the windowed sample is a rounded binary32 product (spec.cpp:58)
-  using C = Cfg<N>;
 #pragma unroll
-  for (int e = 0; e < 32; ++e) {
-    const int p = 2 * (t + C::T * e);
+  for (int e = 0; e < P::E; ++e) {
+    const int p = 2 * (t + P::T * e);
     float x0, x1, w0, w1;
     if constexpr (ALIGNED8 && WSTEP == 1) {
       const cpx xs = *reinterpret_cast<const cpx *>(x + p);
@@ -202,17 +204,17 @@ MX_HD void load_frame(int t, cpx (&Y)[32], const float *x, const float *w) {
   }
 }
 
-template <int N>
-MX_HD void pass1(const cpx (&Y)[32], cpx (&v)[32]) {
-  using C = Cfg<N>;
+// ---- pass 1 ------------------------------------------------------------------
+template <class P>
+MX_HD void pass1(const cpx (&Y)[P::E], cpx (&v)[P::E]) {
 #pragma unroll
-  for (int b = 0; b < C::NB1; ++b) {
-    cpx in[C::R1], out[C::R1];
+  for (int b = 0; b < P::NB1; ++b) {
+    cpx in[P::R1], out[P::R1];
 #pragma unroll
-    for (int r = 0; r < C::R1; ++r) in[r] = Y[b + C::NB1 * r];
-    Dft<C::R1>::run(in, out);
+    for (int r = 0; r < P::R1; ++r) in[r] = Y[b + P::NB1 * r];
+    Dft<P::R1>::run(in, out);
 #pragma unroll
-    for (int r = 0; r < C::R1; ++r) v[b * C::R1 + r] = out[r];
+    for (int r = 0; r < P::R1; ++r) v[b * P::R1 + r] = out[r];
   }
 }
 
@@ -226,217 +228,265 @@ MX_HD void pass1(const cpx (&Y)[32], cpx (&v)[32]) {
 // from HBM once per workgroup instead of N/hop times.  A point is decayed at most
 // N/hop - 2 times before it leaves the frame, so the weights stay within
 // (N/hop)*2^-24 relative of the expf table (tests bound the end-to-end effect).
-template <int N, int HOP>
+template <class P, int HOP>
 struct Slide {
-  using C = Cfg<N>;
-  static constexpr int H = HOP / 2;            // packed points per hop
-  static constexpr bool ok = (HOP % 2 == 0) && (H % C::T == 0) && (H / C::T >= 1) && (2 * (H / C::T) <= 32);
-  static constexpr int D = ok ? H / C::T : 1;  // slots per hop
+  static constexpr int H = HOP / 2;  // packed points per hop
+  static constexpr bool ok = (HOP > 0) && (HOP % 2 == 0) && (H % P::T == 0) && (2 * (H / P::T) <= P::E);
+  static constexpr int D = ok ? H / P::T : 1;  // slots per hop
 };
 
-// edge[i] (i < D): table weights (times the folded scale) of the slots [32-2D, 32-D),
-// i.e. of the hop that has just left the weight-1 tail.  sc = folded scale 1/(2N).
-template <int N, int HOP>
-MX_HD void slide_edge(int t, const float *wtab, float inv_sc, cpx (&edge)[Slide<N, HOP>::D]) {
-  using S = Slide<N, HOP>;
+// edge[i] (i < D): table weights of the slots [E-2D, E-D), i.e. of the hop that has just left
+// the weight-1 tail.  The slot already carries the folded scale and so does the table: take it
+// out once (exact, power of two).
+template <class P, int HOP>
+MX_HD void slide_edge(int t, const float *wtab, float inv_sc, cpx (&edge)[Slide<P, HOP>::D]) {
+  using S = Slide<P, HOP>;
 #pragma unroll
   for (int i = 0; i < S::D; ++i) {
-    const int p = 2 * (t + S::C::T * (32 - 2 * S::D + i));
-    // the slot already carries sc; the table carries it too: take it out once (exact, power of two)
+    const int p = 2 * (t + P::T * (P::E - 2 * S::D + i));
     edge[i] = mk(wtab[p] * inv_sc, wtab[p + 1] * inv_sc);
   }
 }
 
 // newest hop of the frame that ends at sample pointer xe (one past the frame's last sample)
-template <int N, int HOP>
-MX_HD void slide_fetch(int t, const float *xe, cpx (&nx)[Slide<N, HOP>::D]) {
-  using S = Slide<N, HOP>;
+template <class P, int HOP>
+MX_HD void slide_fetch(int t, const float *xe, cpx (&nx)[Slide<P, HOP>::D]) {
+  using S = Slide<P, HOP>;
 #pragma unroll
-  for (int i = 0; i < S::D; ++i) nx[i] = *reinterpret_cast<const cpx *>(xe - HOP + 2 * (t + S::C::T * i));
+  for (int i = 0; i < S::D; ++i) nx[i] = *reinterpret_cast<const cpx *>(xe - HOP + 2 * (t + P::T * i));
 }
 
-template <int N, int HOP>
-MX_HD void slide_step(cpx (&Y)[32], const cpx (&nx)[Slide<N, HOP>::D], const cpx (&edge)[Slide<N, HOP>::D],
+template <class P, int HOP>
+MX_HD void slide_step(cpx (&Y)[P::E], const cpx (&nx)[Slide<P, HOP>::D], const cpx (&edge)[Slide<P, HOP>::D],
                       float g, float sc) {
 #pragma clang fp contract(off)  // keep each windowed point a rounded product, whatever consumes it
-  using S = Slide<N, HOP>;
+  using S = Slide<P, HOP>;
 #pragma unroll
-  for (int e = 0; e < 32 - 2 * S::D; ++e) Y[e] = mk(Y[e + S::D].x * g, Y[e + S::D].y * g);
+  for (int e = 0; e < P::E - 2 * S::D; ++e) Y[e] = mk(Y[e + S::D].x * g, Y[e + S::D].y * g);
 #pragma unroll
   for (int i = 0; i < S::D; ++i) {
-    const cpx o = Y[32 - S::D + i];  // weight-1 slot (scaled by sc): becomes raw * edge
-    Y[32 - 2 * S::D + i] = mk(o.x * edge[i].x, o.y * edge[i].y);
+    const cpx o = Y[P::E - S::D + i];  // weight-1 slot (scaled by sc): becomes raw * edge
+    Y[P::E - 2 * S::D + i] = mk(o.x * edge[i].x, o.y * edge[i].y);
   }
 #pragma unroll
-  for (int i = 0; i < S::D; ++i) Y[32 - S::D + i] = mk(nx[i].x * sc, nx[i].y * sc);
+  for (int i = 0; i < S::D; ++i) Y[P::E - S::D + i] = mk(nx[i].x * sc, nx[i].y * sc);
 }
 
-// LDS addressing.  Every access below is "per-thread base + compile-time offset"
-// (or base ^ constant for the T1 store), so a frame needs a dozen address registers
-// instead of one per access; the closed forms are the swizzles above evaluated
-// symbolically (tests/test_emu.py checks them against swz1/swz2 for every thread).
-template <int N>
-MX_HD void store_t1(int t, const cpx (&v)[32], cpx *lds) {
-  using C = Cfg<N>;
-  // swz1((t + T*b)*R1 + r) = (((t*R1) ^ (t & 15)) ^ r) + b*T*R1
-  const int B = (t * C::R1) ^ (t & 15);
+// ---- LDS transpositions -------------------------------------------------------
+// Every access below is "per-thread base + compile-time offset" (or base ^ constant for
+// the T1 store), so a frame needs a dozen address registers instead of one per access;
+// the closed forms are the swizzles above evaluated symbolically (tests/emu checks them
+// against swz1/swz2 for every thread).
+template <class P>
+MX_HD void store_t1(int t, const cpx (&v)[P::E], cpx *lds) {
+  // swz1((t + T*b)*R1 + r) = (((t*R1) ^ (t & 15)) ^ r) + b*T*R1   (T is a multiple of 16)
+  const int B = (t * P::R1) ^ (t & 15);
 #pragma unroll
-  for (int r = 0; r < C::R1; ++r) {
+  for (int r = 0; r < P::R1; ++r) {
     cpx *p = lds + (B ^ r);
 #pragma unroll
-    for (int b = 0; b < C::NB1; ++b) p[b * C::T * C::R1] = v[b * C::R1 + r];
+    for (int b = 0; b < P::NB1; ++b) p[b * P::T * P::R1] = v[b * P::R1 + r];
   }
 }
 
-template <int N>
-MX_HD void load_t1(int t, cpx (&v)[32], const cpx *lds) {
-  using C = Cfg<N>;
-  // swz1(j + r*S) = swz1(j) + r*S: S = M/R2 only touches bits above the swizzle's source field
-  constexpr int S = C::M / C::R2;
-  static_assert((C::R1 == 8 && S % 128 == 0) || (C::R1 == 32 && S % 512 == 0), "T1 read is base+offset");
+template <class P>
+MX_HD void load_t1(int t, cpx (&v)[P::E], const cpx *lds) {
+  // swz1(j + r*S) = (swz1(j) ^ c_r) + r*S with c_r = (r * (S >> L1)) & 15: the stride S = M/R2
+  // only reaches the swizzle's source field [L1, L1+4) through its top bit (c_r in {0, 8}) or not at all
+  constexpr int S = P::M / P::R2;
+  constexpr int step = (S >> P::L1) & 15;
+  static_assert(step == 0 || step == 8, "T1 read is base(+alt base) + offset");
 #pragma unroll
-  for (int b = 0; b < C::NB2; ++b) {
-    const cpx *p = lds + swz1<N>(t + C::T * b);
+  for (int b = 0; b < P::NB2; ++b) {
+    const int s1 = swz1<P>(t + P::T * b);
+    const cpx *pe = lds + s1, *po = lds + (s1 ^ step);
 #pragma unroll
-    for (int r = 0; r < C::R2; ++r) v[b * C::R2 + r] = p[r * S];
+    for (int r = 0; r < P::R2; ++r) v[b * P::R2 + r] = ((r & 1) ? po : pe)[r * S];
   }
 }
 
 // ---- pass 2 ----------------------------------------------------------------
 // tw2[(r-1)*R1 + k] = exp(-2*pi*i*r*k/(R1*R2)), r = 1..R2-1, k = 0..R1-1
-template <int N>
-MX_HD void pass2(int t, cpx (&v)[32], const cpx *tw2) {
-  using C = Cfg<N>;
+template <class P>
+MX_HD void pass2(int t, cpx (&v)[P::E], const cpx *tw2) {
 #pragma unroll
-  for (int b = 0; b < C::NB2; ++b) {
-    const int j = t + C::T * b;
-    const int k = j & (C::R1 - 1);
-    cpx in[C::R2], out[C::R2];
-    in[0] = v[b * C::R2];
+  for (int b = 0; b < P::NB2; ++b) {
+    const int j = t + P::T * b;
+    const int k = j & (P::R1 - 1);
+    cpx in[P::R2], out[P::R2];
+    in[0] = v[b * P::R2];
 #pragma unroll
-    for (int r = 1; r < C::R2; ++r) {
+    for (int r = 1; r < P::R2; ++r) {
 #ifdef MX_ABL_NOTW
-      in[r] = cmul(v[b * C::R2 + r], mk(0.5f + r, 0.25f * k));
+      in[r] = cmul(v[b * P::R2 + r], mk(0.5f + r, 0.25f * k));
 #else
-      in[r] = cmul(v[b * C::R2 + r], tw2[(r - 1) * C::R1 + k]);
+      in[r] = cmul(v[b * P::R2 + r], tw2[(r - 1) * P::R1 + k]);
 #endif
     }
-    Dft<C::R2>::run(in, out);
+    Dft<P::R2>::run(in, out);
 #pragma unroll
-    for (int r = 0; r < C::R2; ++r) v[b * C::R2 + r] = out[r];
+    for (int r = 0; r < P::R2; ++r) v[b * P::R2 + r] = out[r];
   }
 }
 
-template <int N>
-MX_HD void store_t2(int t, const cpx (&v)[32], cpx *lds) {
-  using C = Cfg<N>;
+// Twiddles of a thread are frame-invariant: with registers to spare (the two-wave plan) they
+// are fetched once per workgroup instead of once per frame.
+template <class P>
+MX_HD void fetch_tw2(int t, const cpx *tw2, cpx (&w)[P::NB2][P::R2 - 1]) {
 #pragma unroll
-  for (int b = 0; b < C::NB2; ++b) {
-    const int j = t + C::T * b;
-    const int k = j & (C::R1 - 1);
-    const int base = (j - k) * C::R2 + k;  // (j / R1) * R1 * R2 + k
-    if constexpr (C::R1 == 8) {
+  for (int b = 0; b < P::NB2; ++b) {
+    const int k = (t + P::T * b) & (P::R1 - 1);
+#pragma unroll
+    for (int r = 1; r < P::R2; ++r) w[b][r - 1] = tw2[(r - 1) * P::R1 + k];
+  }
+}
+template <class P>
+MX_HD void pass2_reg(cpx (&v)[P::E], const cpx (&w)[P::NB2][P::R2 - 1]) {
+#pragma unroll
+  for (int b = 0; b < P::NB2; ++b) {
+    cpx in[P::R2], out[P::R2];
+    in[0] = v[b * P::R2];
+#pragma unroll
+    for (int r = 1; r < P::R2; ++r) in[r] = cmul(v[b * P::R2 + r], w[b][r - 1]);
+    Dft<P::R2>::run(in, out);
+#pragma unroll
+    for (int r = 0; r < P::R2; ++r) v[b * P::R2 + r] = out[r];
+  }
+}
+
+template <class P>
+MX_HD void store_t2(int t, const cpx (&v)[P::E], cpx *lds) {
+#pragma unroll
+  for (int b = 0; b < P::NB2; ++b) {
+    const int j = t + P::T * b;
+    const int k = j & (P::R1 - 1);
+    const int base = (j - k) * P::R2 + k;  // (j / R1) * R1 * R2 + k
+    if constexpr (P::R1 == 8) {
       // swz2 flips bit 3 (= r & 1 here) by bit 7 (= (j >> 3) & 1): even r go to +8f, odd r to -8f
       const int f8 = ((j >> 3) & 1) << 3;
       cpx *pe = lds + base + f8, *po = lds + base - f8;
 #pragma unroll
-      for (int r = 0; r < C::R2; ++r) ((r & 1) ? po : pe)[r * C::R1] = v[b * C::R2 + r];
+      for (int r = 0; r < P::R2; ++r) ((r & 1) ? po : pe)[r * P::R1] = v[b * P::R2 + r];
     } else {
       cpx *p = lds + base;
 #pragma unroll
-      for (int r = 0; r < C::R2; ++r) p[r * C::R1] = v[b * C::R2 + r];
+      for (int r = 0; r < P::R2; ++r) p[r * P::R1] = v[b * P::R2 + r];
     }
   }
 }
 
-// Butterfly indices of pass 3: P = k0p(t), Q = k0q(t); {P,Q} = {t, NS3-t},
+// Butterfly indices of pass 3: P-butterfly = k0p(t), Q-butterfly = k0q(t); {P,Q} = {t, NS3-t},
 // thread 0 takes the two self-paired ones {0, NS3/2}.
-template <int N>
+template <class P>
 MX_HD int k0p(int t) { return t; }
-template <int N>
-MX_HD int k0q(int t) { return t ? Cfg<N>::NS3 - t : Cfg<N>::NS3 / 2; }
+template <class P>
+MX_HD int k0q(int t) { return t ? P::NS3 - t : P::NS3 / 2; }
 
-template <int N>
-MX_HD void load_t2(int t, cpx (&v)[32], const cpx *lds) {
-  using C = Cfg<N>;
-  const int p = k0p<N>(t), q = k0q<N>(t);
-  if constexpr (C::R1 == 8) {
+template <class P>
+MX_HD void load_t2(int t, cpx (&v)[P::E], const cpx *lds) {
+  const int p = k0p<P>(t), q = k0q<P>(t);
+  if constexpr (P::R1 == 8) {
     // NS3 = 128: bit 7 of (k0 + 128 r) is r & 1 (k0 < 128), so odd r read from k0 ^ 8
     const cpx *pe = lds + p, *po = lds + (p ^ 8), *qe = lds + q, *qo = lds + (q ^ 8);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      v[r] = ((r & 1) ? po : pe)[C::NS3 * r];
-      v[16 + r] = ((r & 1) ? qo : qe)[C::NS3 * r];
+    for (int r = 0; r < P::R3; ++r) {
+      v[r] = ((r & 1) ? po : pe)[P::NS3 * r];
+      v[P::R3 + r] = ((r & 1) ? qo : qe)[P::NS3 * r];
     }
   } else {
     const cpx *pp = lds + p, *qq = lds + q;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      v[r] = pp[C::NS3 * r];
-      v[16 + r] = qq[C::NS3 * r];
+    for (int r = 0; r < P::R3; ++r) {
+      v[r] = pp[P::NS3 * r];
+      v[P::R3 + r] = qq[P::NS3 * r];
     }
   }
 }
 
 // ---- pass 3 ----------------------------------------------------------------
-// tw3[(r-1)*NS3 + k0] = exp(-2*pi*i*r*k0/M), r = 1..15, k0 = 0..NS3-1.
-// Butterfly Q sits at k0 = NS3 - t, and exp(-2*pi*i*r*(NS3-t)/M) = W16^r * conj(tw3[r][t]):
-// the conjugate costs nothing inside the complex multiply and the W16^r factor is a
-// one-bin rotation of the 16-point DFT's output (sum_r x_r W16^r W16^(rq) = X[q+1]).  So one
-// table read serves both butterflies; thread 0 (P = 0, Q = NS3/2) reads column NS3/2 for Q
-// and uses 1 for P.
-// On return v[r] = Z[k0p + NS3*r] and v[16 + ((r+1)&15)]... is handled by q_index():
-// Q's natural element r lives in v[16 + ((r + 1) & 15)].
-MX_HD constexpr int q_index(int r) { return 16 + ((r + 1) & 15); }
+// tw3[(r-1)*NS3 + k0] = exp(-2*pi*i*r*k0/M), r = 1..R3-1, k0 = 0..NS3-1.
+// Butterfly Q sits at k0 = NS3 - t, and exp(-2*pi*i*r*(NS3-t)/M) = W_R3^r * conj(tw3[r][t]):
+// the conjugate costs nothing inside the complex multiply and the W_R3^r factor is a one-bin
+// rotation of the R3-point DFT's output (sum_r x_r W^r W^(rq) = X[q+1]).  So one table read
+// serves both butterflies; thread 0 (P = 0, Q = NS3/2) reads column NS3/2 for Q and uses 1 for P.
+// Q's natural element r therefore lives in v[q_index(r)].
+template <class P>
+MX_HD constexpr int q_index(int r) { return P::R3 + ((r + 1) & (P::R3 - 1)); }
 
-template <int N>
-MX_HD void pass3(int t, cpx (&v)[32], const cpx *tw3) {
-  using C = Cfg<N>;
-  const int col = t ? t : C::NS3 / 2;
+template <class P>
+MX_HD void pass3(int t, cpx (&v)[P::E], const cpx *tw3) {
+  constexpr int R = P::R3;
+  const int col = t ? t : P::NS3 / 2;
   const bool t0 = (t == 0);
-  cpx inp[16], inq[16], out[16];
+  cpx inp[R], inq[R], out[R];
   inp[0] = v[0];
-  inq[0] = v[16];
+  inq[0] = v[R];
 #pragma unroll
-  for (int r = 1; r < 16; ++r) {
+  for (int r = 1; r < R; ++r) {
 #ifdef MX_ABL_NOTW
     const cpx w = mk(0.5f + r, 0.25f * col);
 #else
-    const cpx w = tw3[(r - 1) * C::NS3 + col];
+    const cpx w = tw3[(r - 1) * P::NS3 + col];
 #endif
     inp[r] = cmul(v[r], csel(t0, mk(1.0f, 0.0f), w));
-    inq[r] = cmul(v[16 + r], cconj(w));
+    inq[r] = cmul(v[R + r], cconj(w));
   }
-  Dft<16>::run(inp, out);
+  Dft<R>::run(inp, out);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = out[r];
-  Dft<16>::run(inq, out);
+  for (int r = 0; r < R; ++r) v[r] = out[r];
+  Dft<R>::run(inq, out);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[16 + r] = out[r];
+  for (int r = 0; r < R; ++r) v[R + r] = out[r];
+}
+
+template <class P>
+MX_HD void fetch_tw3(int t, const cpx *tw3, cpx (&w)[P::R3 - 1]) {
+  const int col = t ? t : P::NS3 / 2;
+#pragma unroll
+  for (int r = 1; r < P::R3; ++r) w[r - 1] = tw3[(r - 1) * P::NS3 + col];
+}
+template <class P>
+MX_HD void pass3_reg(int t, cpx (&v)[P::E], const cpx (&w)[P::R3 - 1]) {
+  constexpr int R = P::R3;
+  const bool t0 = (t == 0);
+  cpx inp[R], inq[R], out[R];
+  inp[0] = v[0];
+  inq[0] = v[R];
+#pragma unroll
+  for (int r = 1; r < R; ++r) {
+    inp[r] = cmul(v[r], csel(t0, mk(1.0f, 0.0f), w[r - 1]));
+    inq[r] = cmul(v[R + r], cconj(w[r - 1]));
+  }
+  Dft<R>::run(inp, out);
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = out[r];
+  Dft<R>::run(inq, out);
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[R + r] = out[r];
 }
 
 // ---- real-FFT split + magnitude ---------------------------------------------
-// After pass 3: v[r] = Z[k0p + NS3*r], v[16+r] = Z[k0q + NS3*r] (natural order).
+// After pass 3: v[r] = Z[k0p + NS3*r], v[q_index(r)] = Z[k0q + NS3*r] (natural order).
 // Slot s pairs A = Z[k_s] with B = conj(Z[M-k_s]):
 //   X[k]   = ((A+B) - i*w_k*(A-B)) / 2,  X[M-k] = conj(((A+B) + i*w_k*(A-B)) / 2),
 //   w_k = exp(-2*pi*i*k/N).
-// Output: mg[2s] = |X[k_s]|/N at bin kb[2s] = k_s; mg[2s+1] = |X[M-k_s]|/N at
-// bin kb[2s+1] = M-k_s  — exactly (float)(sqrt(re^2+im^2)/N) of spec.cpp:62-64,
-// computed in fp32.  Thread 0's slot 8 second output is bin M/2 (bin M, the
-// Nyquist bin, is not emitted by the reference).
-// ub_lo / ub_hi: i*exp(-2*pi*i*t/N) for t > 0; thread 0: i*exp(-2*pi*i/64), -1.
+// Output: mg[2s] = |X[k_s]|/N at bin k_s; mg[2s+1] = |X[M-k_s]|/N at bin M-k_s — the
+// (float)(sqrt(re^2+im^2)/N) of spec.cpp:62-64 in fp32; the 1/(2N) is already in the data.
+// Thread 0 owns the two self-paired butterflies: its slots s < R3/2 pair Q[s] with Q[R3-1-s],
+// its slots s >= R3/2 pair P[s-R3/2] with P[(3*R3/2 - s) mod R3]; its slot R3/2 yields bin 0
+// and — instead of the Nyquist bin, which the reference does not emit — bin M/2 = |Z[M/2]|.
 // u[s] = i*w_k for the slot's bin (per-thread constants, see post_twiddles()).
-template <int S>
+template <class P, int S>
 struct PostSlot {
-  template <int N>
-  static MX_HD void run(bool t0, const cpx (&v)[32], const cpx (&u)[16], float (&mg)[32]) {
+  static MX_HD void run(bool t0, const cpx (&v)[P::E], const cpx (&u)[P::R3], float (&mg)[P::E]) {
+    constexpr int R = P::R3, H = R / 2;
     cpx A, B;
-    if constexpr (S < 8) {
-      A = csel(t0, v[q_index(S)], v[S]);
-      B = v[q_index(15 - S)];
+    if constexpr (S < H) {
+      A = csel(t0, v[q_index<P>(S)], v[S]);
+      B = v[q_index<P>(R - 1 - S)];
     } else {
-      A = csel(t0, v[S - 8], v[S]);
-      B = csel(t0, v[(24 - S) & 15], v[q_index(15 - S)]);
+      A = csel(t0, v[S - H], v[S]);
+      B = csel(t0, v[(3 * H - S) & (R - 1)], v[q_index<P>(R - 1 - S)]);
     }
     B = cconj(B);
     const cpx Sm = cadd(A, B);
@@ -445,75 +495,74 @@ struct PostSlot {
     const cpx lo = csub(Sm, D), hi = cadd(Sm, D);
     mg[2 * S] = fast_sqrt(lo.x * lo.x + lo.y * lo.y);
     mg[2 * S + 1] = fast_sqrt(hi.x * hi.x + hi.y * hi.y);
-    if constexpr (S == 8) {  // thread 0: bin M/2 instead of the Nyquist bin; |X[M/2]| = |Z[M/2]|
-      const cpx z = v[8];
+    if constexpr (S == H) {  // thread 0: bin M/2 instead of the Nyquist bin; |X[M/2]| = |Z[M/2]|
+      const cpx z = v[H];
       const float m = fast_sqrt(z.x * z.x + z.y * z.y) * 2.0f;
       mg[2 * S + 1] = t0 ? m : mg[2 * S + 1];
     }
-    if constexpr (S + 1 < 16) PostSlot<S + 1>::template run<N>(t0, v, u, mg);
+    if constexpr (S + 1 < R) PostSlot<P, S + 1>::run(t0, v, u, mg);
   }
 };
 
-template <int N>
-MX_HD void post(int t, const cpx (&v)[32], const cpx (&u)[16], float (&mg)[32]) {
-  PostSlot<0>::template run<N>(t == 0, v, u, mg);
+template <class P>
+MX_HD void post(int t, const cpx (&v)[P::E], const cpx (&u)[P::R3], float (&mg)[P::E]) {
+  PostSlot<P, 0>::run(t == 0, v, u, mg);
 }
 
 // Bin of output slot o (= 2s or 2s+1) of thread t:
-//   even o: k_s = (s < 8 ? lo : hi) + NS3*s;  odd o: M - k_s  (thread 0, s = 8: M/2)
-// with lo = hi = t for t > 0 and lo = NS3/2, hi = -8*NS3 for thread 0.
-template <int N>
+//   even o: k_s = (s < R3/2 ? lo : hi) + NS3*s;  odd o: M - k_s  (thread 0, s = R3/2: M/2)
+// with lo = hi = t for t > 0 and lo = NS3/2, hi = -(R3/2)*NS3 for thread 0.
+template <class P>
 MX_HD void out_bases(int t, int &lo, int &hi) {
-  using C = Cfg<N>;
-  lo = t ? t : C::NS3 / 2;
-  hi = t ? t : -8 * C::NS3;
+  lo = t ? t : P::NS3 / 2;
+  hi = t ? t : -(P::R3 / 2) * P::NS3;
 }
-template <int N>
+template <class P>
 MX_HD int out_bin(int t, int o) {
-  using C = Cfg<N>;
   int lo, hi;
-  out_bases<N>(t, lo, hi);
+  out_bases<P>(t, lo, hi);
   const int s = o >> 1;
-  int k = (s < 8 ? lo : hi) + C::NS3 * s;
+  int k = (s < P::R3 / 2 ? lo : hi) + P::NS3 * s;
   if (o & 1) {
-    k = C::M - k;
-    if (k == C::M) k = C::M / 2;
+    k = P::M - k;
+    if (k == P::M) k = P::M / 2;
   }
   return k;
 }
 // bit o set iff out_bin(t, o) lies in [kmin, kmax]
-template <int N>
+template <class P>
 MX_HD uint32_t band_mask(int t, int kmin, int kmax) {
   uint32_t m = 0;
 #pragma unroll
-  for (int o = 0; o < 32; ++o) {
-    const int k = out_bin<N>(t, o);
+  for (int o = 0; o < P::E; ++o) {
+    const int k = out_bin<P>(t, o);
     m |= (k >= kmin && k <= kmax) ? (1u << o) : 0u;
   }
   return m;
 }
 
 // Post-split twiddles of thread t: u[s] = i*exp(-2*pi*i*k_s/N) for the slot's bin k_s.
-// ubase[t] = i*exp(-2*pi*i*t/N) comes from the table; k_s = t + NS3*s adds exp(-2*pi*i*s/32).
-// Thread 0: s < 8 -> k = NS3/2 + NS3*s (base i*exp(-2*pi*i/64)); s >= 8 -> k = NS3*(s-8) (base -1).
-template <int S>
+// ubase[t] = i*exp(-2*pi*i*t/N) comes from the table; k_s = t + NS3*s adds exp(-2*pi*i*s/(2*R3)).
+// Thread 0: s < R3/2 -> k = NS3/2 + NS3*s (base i*exp(-2*pi*i/(4*R3))); s >= R3/2 -> k = NS3*(s-R3/2) (base -1).
+template <class P, int S>
 struct PostTw {
-  static MX_HD void run(cpx lo, cpx hi, cpx (&u)[16]) {
-    u[S] = mulw64<2 * S>(S < 8 ? lo : hi);
-    if constexpr (S + 1 < 16) PostTw<S + 1>::run(lo, hi, u);
+  static MX_HD void run(cpx lo, cpx hi, cpx (&u)[P::R3]) {
+    u[S] = mulw64<(32 / P::R3) * S>(S < P::R3 / 2 ? lo : hi);
+    if constexpr (S + 1 < P::R3) PostTw<P, S + 1>::run(lo, hi, u);
   }
 };
-template <int N>
-MX_HD void post_twiddles(int t, const cpx *ubase, cpx (&u)[16]) {
+template <class P>
+MX_HD void post_twiddles(int t, const cpx *ubase, cpx (&u)[P::R3]) {
   cpx lo, hi;
   if (t) {
     lo = ubase[t];
     hi = lo;
   } else {
-    lo = mk(kSin64[1], kCos64[1]);  // i*exp(-2*pi*i/64) = sin + i*cos
+    constexpr int k = 16 / P::R3;   // exp(-2*pi*i/(4*R3)) in 64ths of a turn
+    lo = mk(kSin64[k], kCos64[k]);  // i*exp(-i*a) = sin a + i*cos a
     hi = mk(-1.0f, 0.0f);
   }
-  PostTw<0>::run(lo, hi, u);
+  PostTw<P, 0>::run(lo, hi, u);
 }
 
 }  // namespace mx

@@ -10,39 +10,66 @@
 
 namespace mx {
 
+// Wavefront max of a 64-bit key through the DPP crossbar (no LDS round trips, unlike __shfl_xor
+// which lowers to ds_bpermute): xor-1, xor-2 (quad_perm), row_half_mirror, row_mirror leave every
+// 16-lane row with its maximum; row_bcast:15 / row_bcast:31 fold the rows; lane 63 holds the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long k) {
+  const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+  // lanes the control does not reach keep their own value (old = src): identity for max
+  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
+  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+  const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+  return o > k ? o : k;
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const unsigned long long o = __shfl_xor(k, m, 64);
-    k = o > k ? o : k;
-  }
-  return k;
+  k = dpp_max_step<0xB1, 0xf>(k);   // quad_perm [1,0,3,2]
+  k = dpp_max_step<0x4E, 0xf>(k);   // quad_perm [2,3,0,1]
+  k = dpp_max_step<0x141, 0xf>(k);  // row_half_mirror
+  k = dpp_max_step<0x140, 0xf>(k);  // row_mirror
+  k = dpp_max_step<0x142, 0xa>(k);  // row_bcast:15 into rows 1 and 3
+  k = dpp_max_step<0x143, 0xc>(k);  // row_bcast:31 into rows 2 and 3
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 // WPE: waves per SIMD the register allocator must leave room for (amdgpu_waves_per_eu);
 // NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
 // and window loads are not hoisted out of the frame loop into hundreds of registers.
-template <int N, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true>
-__global__ __launch_bounds__(Cfg<N>::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, bool TWREG = false, bool OUTSEP = false>
+__global__ __launch_bounds__(P::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void stft_kernel(const StftArgs a0) {
   const StftArgs &a = a0;
-  using C = Cfg<N>;
+  using C = P;
+  constexpr int N = P::N;
   constexpr int NW = C::T / 64;  // wavefronts per frame
   // one LDS object: the M-point image, then NW 8-byte reduction slots
-  __shared__ __attribute__((aligned(16))) float2 lds[C::M + (NW > 1 ? NW : 0)];
+  // one LDS object: the M-point image, NW 8-byte reduction slots (padded to 16 B), and — OUTSEP — a
+  // separate M-float region for the magnitude transposition, so that the image can be refilled by
+  // the next frame without an extra barrier
+  constexpr int kRed = (NW > 1) ? ((NW + 1) / 2) * 2 : 0;
+  __shared__ __attribute__((aligned(16))) float2 lds[C::M + kRed + (OUTSEP ? C::M / 2 : 0)];
+  float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + C::M + kRed : lds);
 
   const int t_ = threadIdx.x;
-  cpx u[16];  // post-split twiddles: 32 registers that replace 16 complex multiplies per frame
-  post_twiddles<N>(t_, a.ubase, u);
-  const uint32_t bmask_ = band_mask<N>(t_, a.kmin, a.kmax);
+  cpx u[P::R3];  // post-split twiddles: E registers that replace R3 complex multiplies per frame
+  post_twiddles<P>(t_, a.ubase, u);
+  const uint32_t bmask_ = band_mask<P>(t_, a.kmin, a.kmax);
   // output slots some lane of this wavefront needs for the pitch pick (wave-uniform)
   uint32_t umask = 0;
 #pragma unroll
-  for (int o = 0; o < 32; ++o) umask |= (__ballot((bmask_ >> o) & 1u) != 0ull) ? (1u << o) : 0u;
+  for (int o = 0; o < P::E; ++o) umask |= (__ballot((bmask_ >> o) & 1u) != 0ull) ? (1u << o) : 0u;
   umask = __builtin_amdgcn_readfirstlane(umask);
-  constexpr bool kSlide = (MODE == kBulkAligned) && (HOP > 0) && Slide<N, (HOP > 0 ? HOP : 2)>::ok;
-  constexpr int SD = Slide<N, (HOP > 0 ? HOP : 2)>::D;
+  constexpr bool kSlide = (MODE == kBulkAligned) && (HOP > 0) && Slide<P, (HOP > 0 ? HOP : 2)>::ok;
+  constexpr int SD = Slide<P, (HOP > 0 ? HOP : 2)>::D;
   constexpr float kSc = 0.5f / (float)N;
+  // TWREG: this thread's pass-2/pass-3 twiddles live in registers for the whole workgroup
+  cpx w2r[TWREG ? P::NB2 : 1][P::R2 - 1], w3r[P::R3 - 1];
+  if constexpr (TWREG) {
+    fetch_tw2<P>(t_, a.tw2, w2r);
+    fetch_tw3<P>(t_, a.tw3, w3r);
+  }
 
   // XCD-aware block -> frame-range map: the dispatcher places block b on XCD b % 8 and each
   // XCD has a private L2, so hand every XCD one contiguous eighth of the frame range: the
@@ -56,12 +83,12 @@ void stft_kernel(const StftArgs a0) {
   const int64_t f0 = (int64_t)lb * a.frames_per_block;
   const int64_t f1 = (f0 + a.frames_per_block < a.count) ? f0 + a.frames_per_block : a.count;
 
-  cpx Y[32];        // the windowed frame (sliding mode: carried from frame to frame)
+  cpx Y[P::E];      // the windowed frame (sliding mode: carried from frame to frame)
   cpx edge[SD], nx[SD];
   if constexpr (kSlide) {
     const int64_t e0 = (a.first_frame + f0 + 1) * (int64_t)HOP;
-    if (f0 < f1) load_frame<N, 1, true>(t_, Y, a.audio + MX_AUDIO_PAD + (e0 - N), a.wtab);
-    slide_edge<N, HOP>(t_, a.wtab, 2.0f * (float)N, edge);
+    if (f0 < f1) load_frame<P, 1, true>(t_, Y, a.audio + MX_AUDIO_PAD + (e0 - N), a.wtab);
+    slide_edge<P, HOP>(t_, a.wtab, 2.0f * (float)N, edge);
   }
 
   for (int64_t f = f0; f < f1; ++f) {
@@ -77,11 +104,11 @@ void stft_kernel(const StftArgs a0) {
     }
     const float2 *tw2 = a.tw2 + zoff, *tw3 = a.tw3 + zoff;
     int out_lo, out_hi;
-    out_bases<N>(t, out_lo, out_hi);
+    out_bases<P>(t, out_lo, out_hi);
 
     if constexpr (kSlide) {
       // prefetch the next frame's newest hop (1 KiB per wavefront) under this frame's math
-      if (f + 1 < f1) slide_fetch<N, HOP>(t, a.audio + MX_AUDIO_PAD + (a.first_frame + f + 2) * (int64_t)HOP, nx);
+      if (f + 1 < f1) slide_fetch<P, HOP>(t, a.audio + MX_AUDIO_PAD + (a.first_frame + f + 2) * (int64_t)HOP, nx);
     } else {
       const float *x;
       const float *w;
@@ -99,67 +126,49 @@ void stft_kernel(const StftArgs a0) {
         x = a.audio + MX_AUDIO_PAD + (e - N);
         w = a.wtab + zoff;
       }
-      load_frame<N, (MODE == kRanges ? -1 : 1), (MODE == kBulkAligned)>(t, Y, x, w);
+      load_frame<P, (MODE == kRanges ? -1 : 1), (MODE == kBulkAligned)>(t, Y, x, w);
     }
 
-    cpx v[32];
-    pass1<N>(Y, v);
+    cpx v[P::E];
+    pass1<P>(Y, v);
     if constexpr (kSlide) {
-      if (f + 1 < f1) slide_step<N, HOP>(Y, nx, edge, a.decay, kSc);
+      if (f + 1 < f1) slide_step<P, HOP>(Y, nx, edge, a.decay, kSc);
     }
-    store_t1<N>(t, v, lds);
+#ifndef MX_ABL_NOLDS
+    store_t1<P>(t, v, lds);
     __syncthreads();
-    load_t1<N>(t, v, lds);
+    load_t1<P>(t, v, lds);
     __syncthreads();
-    pass2<N>(t, v, tw2);
-    store_t2<N>(t, v, lds);
+#endif
+    if constexpr (TWREG) pass2_reg<P>(v, w2r);
+    else pass2<P>(t, v, tw2);
+#ifndef MX_ABL_NOLDS
+    store_t2<P>(t, v, lds);
     __syncthreads();
-    load_t2<N>(t, v, lds);
-    __syncthreads();  // image free for the next frame's T1
-    pass3<N>(t, v, tw3);
-    float mg[32];
-    post<N>(t, v, u, mg);
+    load_t2<P>(t, v, lds);
+    if constexpr (!OUTSEP) __syncthreads();  // image free: the magnitude scatter below reuses it
+#endif
+    if constexpr (TWREG) pass3_reg<P>(t, v, w3r);
+    else pass3<P>(t, v, tw3);
+    float mg[P::E];
+    post<P>(t, v, u, mg);
 
-    // ---- outputs ----
-    // bins: even o -> (s<8 ? lo : hi) + NS3*s, odd o -> M - that (thread 0, s = 8: M/2)
+    // ---- pitch pick: per-thread best, then wavefront max (registers only) ----
+    // key = (magnitude bits << 32) | (0x7fffffff - bin): non-negative floats order like their
+    // bit patterns, so max(key) = largest magnitude, lowest bin on ties; out-of-band -> 0.
+    // bins: even o -> (s < R3/2 ? lo : hi) + NS3*s, odd o -> M - that (thread 0, s = R3/2: M/2)
     unsigned long long best = 0ull;
-    if (a.mags) {
-      // Transpose the magnitudes through the LDS image (idle between load_t2 and the next frame's
-      // T1): each lane scatters its 32 bins as dwords (consecutive lanes -> consecutive bins, so
-      // conflict-free), then every lane owns 4 consecutive bins and the row leaves as 8
-      // global_store_dwordx4 per lane, 1 KiB contiguous per wavefront instruction, instead of 32
-      // dword stores with one stray element each (thread 0's self-paired bins).
-      float *lf = reinterpret_cast<float *>(lds);
-      float *plo = lf + out_lo, *phi = lf + out_hi;
-      float *mlo = lf + (C::M - out_lo), *mhi = lf + (C::M - out_hi);
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        (s < 8 ? plo : phi)[C::NS3 * s] = mg[2 * s];
-        if (s == 8) (t == 0 ? lf + C::M / 2 : mhi - C::NS3 * 8)[0] = mg[2 * s + 1];
-        else (s < 8 ? mlo : mhi)[-C::NS3 * s] = mg[2 * s + 1];
-      }
-      __syncthreads();
-      using f32x4 = float __attribute__((ext_vector_type(4)));
-      const f32x4 *l4 = reinterpret_cast<const f32x4 *>(lds) + t;
-      f32x4 *row4 = reinterpret_cast<f32x4 *>(a.mags + (size_t)f * (size_t)(N / 2)) + t;
-      f32x4 q[C::M / 4 / C::T];
-#pragma unroll
-      for (int i = 0; i < C::M / 4 / C::T; ++i) q[i] = l4[C::T * i];
-#pragma unroll
-      for (int i = 0; i < C::M / 4 / C::T; ++i) __builtin_nontemporal_store(q[i], &row4[C::T * i]);
-      __syncthreads();  // image free again
-    }
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(lds + C::M);
     if (a.pitch) {
-      // key = (magnitude bits << 32) | (0x7fffffff - bin): non-negative floats order like their
-      // bit patterns, so max(key) = largest magnitude, lowest bin on ties; out-of-band -> 0
       const unsigned klo = 0x7fffffffu - (unsigned)out_lo, khi = 0x7fffffffu - (unsigned)out_hi;
       const unsigned nlo = 0x7fffffffu - (unsigned)(C::M - out_lo), nhi = 0x7fffffffu - (unsigned)(C::M - out_hi);
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
+      for (int s = 0; s < C::R3; ++s) {
+        constexpr int H = C::R3 / 2;
         if (!((umask >> (2 * s)) & 3u)) continue;  // wave-uniform: no lane has these two bins in band
-        const unsigned b0 = (s < 8 ? klo : khi) - (unsigned)(C::NS3 * s);
-        unsigned b1 = (s < 8 ? nlo : nhi) + (unsigned)(C::NS3 * s);
-        if (s == 8) b1 = (t == 0) ? 0x7fffffffu - (unsigned)(C::M / 2) : b1;
+        const unsigned b0 = (s < H ? klo : khi) - (unsigned)(C::NS3 * s);
+        unsigned b1 = (s < H ? nlo : nhi) + (unsigned)(C::NS3 * s);
+        if (s == H) b1 = (t == 0) ? 0x7fffffffu - (unsigned)(C::M / 2) : b1;
         const unsigned v0 = (unsigned)((int)(bmask << (31 - 2 * s)) >> 31);      // all-ones iff bit 2s
         const unsigned v1 = (unsigned)((int)(bmask << (31 - (2 * s + 1))) >> 31);  // all-ones iff bit 2s+1
         const unsigned long long k0 = ((unsigned long long)(__float_as_uint(mg[2 * s]) & v0) << 32) | (b0 & v0);
@@ -167,25 +176,54 @@ void stft_kernel(const StftArgs a0) {
         best = k0 > best ? k0 : best;
         best = k1 > best ? k1 : best;
       }
-    }
-    if (a.pitch) {
       best = wave_max_u64(best);
       if constexpr (NW > 1) {
-        unsigned long long *red = reinterpret_cast<unsigned long long *>(lds + C::M);
-        if ((t & 63) == 0) red[t >> 6] = best;
-        __syncthreads();
-        if (t == 0) {
+        if ((t & 63) == 0) red[t >> 6] = best;  // published by the barrier below
+      }
+    }
+
+    // ---- magnitudes ----
+    if (a.mags) {
+      // Transpose through LDS: each lane scatters its E bins as dwords (consecutive lanes ->
+      // consecutive bins, conflict-free), then every lane owns 4 consecutive bins and the row
+      // leaves as global_store_dwordx4, 1 KiB contiguous per wavefront instruction, instead of E
+      // dword stores with one stray element each (thread 0's self-paired bins).
+      float *plo = lout + out_lo, *phi = lout + out_hi;
+      float *mlo = lout + (C::M - out_lo), *mhi = lout + (C::M - out_hi);
 #pragma unroll
-          for (int i = 1; i < NW; ++i) best = red[i] > best ? red[i] : best;
-        }
-        // red[] is rewritten only after the next frame's barriers
+      for (int s = 0; s < C::R3; ++s) {
+        constexpr int H = C::R3 / 2;
+        (s < H ? plo : phi)[C::NS3 * s] = mg[2 * s];
+        if (s == H) (t == 0 ? lout + C::M / 2 : mhi - C::NS3 * H)[0] = mg[2 * s + 1];
+        else (s < H ? mlo : mhi)[-C::NS3 * s] = mg[2 * s + 1];
       }
-      if (t == 0) {
-        mx_pitch p;
-        p.bin = 0x7fffffff - (int)(unsigned)(best & 0xffffffffull);
-        p.mag = __uint_as_float((unsigned)(best >> 32));
-        a.pitch[f] = p;
+      __syncthreads();  // (also: every wave is past load_t2, so the image may be refilled)
+      using f32x4 = float __attribute__((ext_vector_type(4)));
+      const f32x4 *l4 = reinterpret_cast<const f32x4 *>(lout) + t;
+#ifdef MX_ABL_SAMEROW
+      f32x4 *row4 = reinterpret_cast<f32x4 *>(a.mags + (size_t)(blockIdx.x & 1023) * (size_t)(N / 2)) + t;
+#else
+      f32x4 *row4 = reinterpret_cast<f32x4 *>(a.mags + (size_t)f * (size_t)(N / 2)) + t;
+#endif
+      f32x4 q[C::M / 4 / C::T];
+#pragma unroll
+      for (int i = 0; i < C::M / 4 / C::T; ++i) q[i] = l4[C::T * i];
+#pragma unroll
+      for (int i = 0; i < C::M / 4 / C::T; ++i) __builtin_nontemporal_store(q[i], &row4[C::T * i]);
+      if constexpr (!OUTSEP) __syncthreads();  // image free again
+    } else {
+      if constexpr (NW > 1 || !OUTSEP) __syncthreads();
+    }
+    if (a.pitch && t == 0) {
+      if constexpr (NW > 1) {
+#pragma unroll
+        for (int i = 1; i < NW; ++i) best = red[i] > best ? red[i] : best;
+        // red[] is rewritten only after the next frame's T1/T2 barriers
       }
+      mx_pitch p;
+      p.bin = 0x7fffffff - (int)(unsigned)(best & 0xffffffffull);
+      p.mag = __uint_as_float((unsigned)(best >> 32));
+      a.pitch[f] = p;
     }
   }
 }

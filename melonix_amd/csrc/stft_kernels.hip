@@ -17,35 +17,40 @@ namespace mx {
 
 namespace {
 
-// Register/occupancy policy per FFT size (measured on MI355X, profiles/):
-// LDS admits 160 KiB / (M*8 B) workgroups per CU, i.e. 2.5 / 2 / 2 waves per SIMD.
-template <int N>
+// Register/occupancy policy per plan (measured on MI355X, profiles/).
+// One-wave plan (E = 32): LDS admits 160 KiB / (M*8 B) workgroups per CU = 2.5 / 2 / 2 waves per SIMD.
+// Two-wave plan for N = 4096 (E = 16): half the registers per thread, twice the resident waves.
+template <class P>
 struct Tune {
-  static constexpr int WPE = 2;
+  static constexpr bool TWO_WAVE = (P::E == 16);
+  static constexpr int WPE = TWO_WAVE ? 3 : 2;
   static constexpr bool NOHOIST = true;
+  static constexpr bool TWREG = TWO_WAVE;   // 22 twiddles in registers for the whole workgroup
+  static constexpr bool OUTSEP = false;     // a separate LDS region for the magnitude transposition measured no gain
 };
 
-template <int N>
-hipError_t launch_n(int mode, const StftArgs &a, hipStream_t s) {
-  using C = Cfg<N>;
+template <class P>
+hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
+  constexpr int N = P::N;
   if (a.count <= 0) return hipSuccess;
   const int g = a.frames_per_block > 0 ? a.frames_per_block : 1;
   const int64_t blocks = (a.count + g - 1) / g;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   StftArgs b = a;
   b.frames_per_block = g;
-  const dim3 grid((unsigned)blocks), block(C::T);
-  constexpr int W = Tune<N>::WPE;
-  constexpr bool NH = Tune<N>::NOHOIST;
+  const dim3 grid((unsigned)blocks), block(P::T);
+  constexpr int W = Tune<P>::WPE;
+  constexpr bool NH = Tune<P>::NOHOIST;
+  constexpr bool TR = Tune<P>::TWREG, OS = Tune<P>::OUTSEP;
   switch (mode) {
     case kBulkAligned:
       // the headline hops slide the windowed frame through registers (one HBM read per sample)
-      if (N == 4096 && a.hop == 256) hipLaunchKernelGGL((stft_kernel<N, kBulkAligned, (N == 4096 ? 256 : 0), W, NH>), grid, block, 0, s, b);
-      else if (N == 16384 && a.hop == 512) hipLaunchKernelGGL((stft_kernel<N, kBulkAligned, (N == 16384 ? 512 : 0), W, NH>), grid, block, 0, s, b);
-      else hipLaunchKernelGGL((stft_kernel<N, kBulkAligned, 0, W, NH>), grid, block, 0, s, b);
+      if (N == 4096 && a.hop == 256) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 4096 ? 256 : 0), W, NH, true, TR, OS>), grid, block, 0, s, b);
+      else if (N == 16384 && a.hop == 512) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 16384 ? 512 : 0), W, NH, true, TR, OS>), grid, block, 0, s, b);
+      else hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TR, OS>), grid, block, 0, s, b);
       break;
-    case kBulkAny: hipLaunchKernelGGL((stft_kernel<N, kBulkAny, 0, W, NH>), grid, block, 0, s, b); break;
-    case kRanges: hipLaunchKernelGGL((stft_kernel<N, kRanges, 0, W, NH>), grid, block, 0, s, b); break;
+    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TR, OS>), grid, block, 0, s, b); break;
+    case kRanges: hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TR, OS>), grid, block, 0, s, b); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -53,11 +58,13 @@ hipError_t launch_n(int mode, const StftArgs &a, hipStream_t s) {
 
 }  // namespace
 
+int stft_points_per_thread(int N) { return N == 4096 ? kPlan4096E : 32; }
+
 hipError_t launch_stft(int N, int mode, const StftArgs &a, hipStream_t s) {
   switch (N) {
-    case 4096: return launch_n<4096>(mode, a, s);
-    case 16384: return launch_n<16384>(mode, a, s);
-    case 32768: return launch_n<32768>(mode, a, s);
+    case 4096: return launch_plan<Plan<4096, kPlan4096E>>(mode, a, s);
+    case 16384: return launch_plan<Plan<16384, 32>>(mode, a, s);
+    case 32768: return launch_plan<Plan<32768, 32>>(mode, a, s);
   }
   return hipErrorInvalidValue;
 }

@@ -30,31 +30,28 @@ inline cpx_h unit_root(long long num, long long den) {  // exp(-2*pi*i*num/den)
   return r;
 }
 
-template <int N>
+template <class C>
 std::vector<cpx_h> make_tw2() {
-  using C = Cfg<N>;
   std::vector<cpx_h> t((size_t)C::TW2);
   for (int r = 1; r < C::R2; ++r)
     for (int k = 0; k < C::R1; ++k) t[(size_t)(r - 1) * C::R1 + k] = unit_root((long long)r * k, C::R1 * C::R2);
   return t;
 }
 
-template <int N>
+template <class C>
 std::vector<cpx_h> make_tw3() {
-  using C = Cfg<N>;
   std::vector<cpx_h> t((size_t)C::TW3);
-  for (int r = 1; r < 16; ++r)
+  for (int r = 1; r < C::R3; ++r)
     for (int k = 0; k < C::NS3; ++k) t[(size_t)(r - 1) * C::NS3 + k] = unit_root((long long)r * k, C::M);
   return t;
 }
 
 // ubase[t] = i * exp(-2*pi*i*t/N), t = 0..T-1
-template <int N>
+template <class C>
 std::vector<cpx_h> make_ubase() {
-  using C = Cfg<N>;
   std::vector<cpx_h> t((size_t)C::T);
   for (int k = 0; k < C::T; ++k) {
-    const cpx_h w = unit_root(k, N);
+    const cpx_h w = unit_root(k, C::N);
     t[(size_t)k].x = -w.y;  // i*(a+ib) = -b + ia
     t[(size_t)k].y = w.x;
   }

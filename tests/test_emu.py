@@ -22,8 +22,8 @@ def emu():
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", src, "-o", so])
     L = C.CDLL(so)
     fp = C.POINTER(C.c_float)
-    L.emu_stft_frame.argtypes = [C.c_int, fp, C.c_long, C.c_int, C.c_int, C.c_int, fp]
-    L.emu_stft_slide.argtypes = [C.c_int, C.c_int, fp, C.c_long, C.c_long, C.c_long, fp]
+    L.emu_stft_frame.argtypes = [C.c_int, C.c_int, fp, C.c_long, C.c_int, C.c_int, C.c_int, fp]
+    L.emu_stft_slide.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.c_long, C.c_long, C.c_long, fp]
     return L
 
 
@@ -31,8 +31,8 @@ RANGES = [(48000, 48375), (0, 256), (-500, -100), (239744, 240000), (479900, 480
           (5000, 4000), (1000, 60000)]
 
 
-@pytest.mark.parametrize("N", [4096, 16384, 32768])
-def test_single_frames(emu, oracle, N):
+@pytest.mark.parametrize("N,E", [(4096, 32), (4096, 16), (16384, 32), (32768, 32)])
+def test_single_frames(emu, oracle, N, E):
     w = noisy(accum_sweep(10 * SR))
     fp = C.POINTER(C.c_float)
     for (s, e) in RANGES:
@@ -41,20 +41,21 @@ def test_single_frames(emu, oracle, N):
             if hop_mode and e <= s:
                 continue
             out = np.empty(N // 2, np.float32)
-            rc = emu.emu_stft_frame(N, w.ctypes.data_as(fp), len(w), s, e, hop_mode, out.ctypes.data_as(fp))
+            rc = emu.emu_stft_frame(N, E, w.ctypes.data_as(fp), len(w), s, e, hop_mode, out.ctypes.data_as(fp))
             assert rc == 0, "LDS closed-form address differs from the swizzle, or is not a bijection"
             assert (np.abs(out - ref) <= mag_tol(ref[None])[0]).all()
             assert np.abs(out - ref).max() <= 1e-6 * max(ref.max(), 1e-30) + 1e-12  # in fact ~1e-7 of the peak
 
 
-@pytest.mark.parametrize("N,hop,first,count", [(4096, 256, 0, 40), (4096, 256, 520, 43), (16384, 512, 0, 40), (16384, 512, 250, 32)])
-def test_sliding_window(emu, oracle, N, hop, first, count):
+@pytest.mark.parametrize("N,E,hop,first,count", [(4096, 32, 256, 0, 40), (4096, 32, 256, 520, 43), (4096, 16, 256, 0, 40),
+                                                  (4096, 16, 256, 520, 43), (16384, 32, 512, 0, 40), (16384, 32, 512, 250, 32)])
+def test_sliding_window(emu, oracle, N, E, hop, first, count):
     """The register image slid frame to frame stays within 1e-6 of the frame peak of the oracle
     (tolerance 2e-5): at most N/hop - 2 decays per point."""
     w = noisy(accum_sweep(3 * SR))
     fp = C.POINTER(C.c_float)
     out = np.empty((count, N // 2), np.float32)
-    rc = emu.emu_stft_slide(N, hop, w.ctypes.data_as(fp), len(w), first, count, out.ctypes.data_as(fp))
+    rc = emu.emu_stft_slide(N, E, hop, w.ctypes.data_as(fp), len(w), first, count, out.ctypes.data_as(fp))
     assert rc == 0
     ref = np.stack([oracle.spec_frame(w, N, (first + f) * hop, (first + f + 1) * hop) for f in range(count)])
     err = np.abs(out - ref)

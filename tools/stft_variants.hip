@@ -22,17 +22,17 @@ using namespace mx;
     }                                                                          \
   } while (0)
 
-template <int N, int MODE, int HOP, int WPE, bool NH, bool XM = true>
+template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, bool TR = false, bool OS = false>
 float time_variant(const StftArgs &a, int reps, const char *name) {
-  using C = Cfg<N>;
+  constexpr int N = C::N;
   const int64_t blocks = (a.count + a.frames_per_block - 1) / a.frames_per_block;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<N, MODE, HOP, WPE, NH, XM>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<N, MODE, HOP, WPE, NH, XM>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -40,7 +40,7 @@ float time_variant(const StftArgs &a, int reps, const char *name) {
   ms /= reps;
   const double fps = a.count / (ms * 1e-3);
   const double balg = 4.0 * a.hop + (a.mags ? 4.0 * (N / 2) : 0.0) + 8.0;
-  printf("%-34s N=%5d G=%3d %8.3f ms  %8.2f Mframes/s  %7.1f GB/s alg (%.1f%% of 8 TB/s)\n", name, N,
+  printf("%-30s E=%2d N=%5d G=%3d %8.3f ms  %8.2f Mframes/s  %7.1f GB/s alg (%.1f%% of 8 TB/s)\n", name, C::E, N,
          a.frames_per_block, ms, fps / 1e6, fps * balg / 1e9, fps * balg / 8e12 * 100);
   fflush(stdout);
   return ms;
@@ -174,17 +174,14 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&d_out, 256 * 8 * 256 * 4));
   auto wext = make_wext(fold_scale(N));
   auto wtab = make_wtab(N, hop, wext);
-  auto tw2 = make_tw2<N>();
-  auto tw3 = make_tw3<N>();
-  auto ub = make_ubase<N>();
+  using P32 = Plan<N, 32>;
+  using P16 = Plan<N, 16>;
+  auto up = [&](const std::vector<cpx_h> &v) { float2 *d; CK(hipMalloc(&d, v.size() * 8)); CK(hipMemcpy(d, v.data(), v.size() * 8, hipMemcpyHostToDevice)); return d; };
   CK(hipMalloc(&d_wtab, wtab.size() * 4));
   CK(hipMemcpy(d_wtab, wtab.data(), wtab.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMalloc(&d_tw2, tw2.size() * 8));
-  CK(hipMemcpy(d_tw2, tw2.data(), tw2.size() * 8, hipMemcpyHostToDevice));
-  CK(hipMalloc(&d_tw3, tw3.size() * 8));
-  CK(hipMemcpy(d_tw3, tw3.data(), tw3.size() * 8, hipMemcpyHostToDevice));
-  CK(hipMalloc(&d_ub, ub.size() * 8));
-  CK(hipMemcpy(d_ub, ub.data(), ub.size() * 8, hipMemcpyHostToDevice));
+  float2 *tw2_32 = up(make_tw2<P32>()), *tw3_32 = up(make_tw3<P32>()), *ub_32 = up(make_ubase<P32>());
+  float2 *tw2_16 = up(make_tw2<P16>()), *tw3_16 = up(make_tw3<P16>()), *ub_16 = up(make_ubase<P16>());
+  (void)d_tw2; (void)d_tw3; (void)d_ub;
 
   run_valu<0>("v_add_f32", d_out);
   run_valu<1>("v_pk_add_f32", d_out);
@@ -195,20 +192,26 @@ int main(int argc, char **argv) {
   run_lds<2>("lds write+read b64", d_out);
 
   StftArgs a{};
-  a.audio = d_audio; a.n = n; a.wtab = d_wtab; a.tw2 = d_tw2; a.tw3 = d_tw3; a.ubase = d_ub;
+  a.audio = d_audio; a.n = n; a.wtab = d_wtab;
   a.decay = hop_decay(hop);
   a.hop = hop; a.first_frame = 0; a.count = F; a.kmin = 5; a.kmax = 150; a.mags = d_mags; a.pitch = d_pitch;
+  StftArgs a32 = a, a16 = a;
+  a32.tw2 = tw2_32; a32.tw3 = tw3_32; a32.ubase = ub_32;
+  a16.tw2 = tw2_16; a16.tw3 = tw3_16; a16.ubase = ub_16;
   const int reps = 5;
-  for (int g : {4, 8, 16, 32, 64, 128}) {
-    a.frames_per_block = g;
-    time_variant<N, kBulkAligned, 0, 2, true, true>(a, reps, "direct  wpe2");
-    time_variant<N, kBulkAligned, 256, 2, true, true>(a, reps, "sliding wpe2");
+  for (int g : {4, 8, 16, 32, 64}) {
+    a32.frames_per_block = a16.frames_per_block = g;
+    time_variant<P32, kBulkAligned, 256, 2, true, true>(a32, reps, "1 wave/frame  sliding wpe2");
+    time_variant<P16, kBulkAligned, 256, 4, true, true>(a16, reps, "2 waves/frame sliding wpe4");
+    time_variant<P16, kBulkAligned, 256, 3, true, true, true>(a16, reps, "2 waves/frame twreg wpe3");
+    time_variant<P16, kBulkAligned, 256, 3, true, true, true, true>(a16, reps, "2 waves/frame twreg outsep wpe3");
   }
-  a.frames_per_block = 32;
-  a.mags = nullptr;
-  time_variant<N, kBulkAligned, 256, 2, true, true>(a, reps, "sliding wpe2 pitch-only");
-  a.mags = d_mags;
-  a.pitch = nullptr;
-  time_variant<N, kBulkAligned, 256, 2, true, true>(a, reps, "sliding wpe2 mags-only");
+  a16.frames_per_block = 16;
+  time_variant<P16, kBulkAligned, 0, 3, true, true, true, true>(a16, reps, "2 waves/frame direct  twreg outsep");
+  a16.mags = nullptr;
+  time_variant<P16, kBulkAligned, 256, 3, true, true, true, true>(a16, reps, "2w twreg outsep pitch-only");
+  a16.mags = d_mags;
+  a16.pitch = nullptr;
+  time_variant<P16, kBulkAligned, 256, 3, true, true, true, true>(a16, reps, "2w twreg outsep mags-only");
   return 0;
 }

@@ -56,5 +56,12 @@ if "FETCH_SIZE" in p:
 if "WRITE_SIZE" in p:
     res["write_bytes"] = p["WRITE_SIZE"]["per_launch_avg"] * 1024
     print("WRITE bytes:", res["write_bytes"])
+# bench.py reads profiles/pmc_latest.json for roofline.traffic (HBM bytes per launch from PMC)
+stft = [k for k in res["kernels"] if "stft_kernel" in k.get("Name", "")]
+if stft and "WRITE_SIZE" in p and "FETCH_SIZE" in p:
+    res["stft_kernel_avg_ns"] = float(stft[0]["AverageNs"])
+    res["hbm_bytes_per_launch"] = res["fetch_bytes_corrected"] + res["write_bytes"]
+    res["hbm_bytes_note"] = ("FETCH_SIZE*1024*2 (gfx950 counts 64 B per 128-B request on wide coalesced reads, "
+                             "MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024; separate --pmc passes")
 with open(os.path.join(OUT, f"prof_{tag}.json"), "w") as fh:
     json.dump(res, fh, indent=1)
