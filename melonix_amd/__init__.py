@@ -116,6 +116,14 @@ class Context:
                                                _ptr(mags), _ptr(pitch)))
         return mags, pitch
 
+    def stft_ranges_rgb(self, audio: Audio, N: int, ranges, k: float):
+        """Texture rows (count x N/2 x 3 uint8): STFT + the spec-cache.cpp:77-96 colormap on the GPU."""
+        ranges = np.ascontiguousarray(ranges, dtype=np.int32).reshape(-1, 2)
+        rgb = np.empty((len(ranges), N // 2, 3), dtype=np.uint8)
+        _capi.check(_capi.lib().mx_stft_ranges_rgb(self.handle, audio.handle, N, _ptr(ranges), len(ranges), float(k),
+                                                   _ptr(rgb)))
+        return rgb
+
     # ---- STFT, device-resident outputs (raw device pointers, async on the ctx stream) ----
     def stft_hop_dev(self, audio: Audio, N: int, hop: int, first: int, count: int, d_mags: int | None,
                      d_pitch: int | None, band=(-1, -1)):

@@ -29,6 +29,7 @@ UNITS = [
     ("stft_kernels.hip", "hip", ["-fno-slp-vectorize"]),
     # bit-exact PCM: no FMA contraction in the resampler
     ("resynth_kernels.hip", "hip", ["-ffp-contract=off"]),
+    ("colormap_kernel.hip", "hip", ["-ffp-contract=off"]),
     ("capi.cpp", "hip", []),
     # pure host logic: plain g++, no contraction, no -march (SURVEY §7 "Bit-exact schedule")
     ("host_logic.cpp", "cxx", ["-ffp-contract=off"]),

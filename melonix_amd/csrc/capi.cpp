@@ -395,8 +395,41 @@ int mx_stft_ranges(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges,
   return stft_host_common(ctx, a, N, true, 0, 0, ranges, count, kmin, kmax, mags_out, pitch_out);
 }
 
-int mx_stft_ranges_rgb(mx_ctx *, const mx_audio *, int, const int32_t *, int64_t, float, uint8_t *) {
-  return fail(MX_ERR_INVALID, "mx_stft_ranges_rgb: fused colormap not built yet (SURVEY §8f row 1)");
+int mx_stft_ranges_rgb(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges, int64_t count, float k,
+                       uint8_t *rgb_out) {
+  int kmin = -1, kmax = -1;
+  int rc = check_common(ctx, a, N, count, kmin, kmax);
+  if (rc) return rc;
+  if (count == 0) return MX_OK;
+  if (!ranges || !rgb_out) return fail(MX_ERR_INVALID, "ranges / rgb_out is null");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t row = (size_t)(N / 2);
+  const int64_t chunk = std::min<int64_t>(count, chunk_frames(N));
+  float *d_mags = nullptr;
+  uint8_t *d_rgb = nullptr;
+  int32_t *d_ranges = nullptr;
+  hipError_t e = hipMalloc(&d_mags, (size_t)chunk * row * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&d_rgb, (size_t)chunk * row * 3);
+  if (e == hipSuccess) e = hipMalloc(&d_ranges, (size_t)chunk * 2 * sizeof(int32_t));
+  if (e != hipSuccess) {
+    hipFree(d_mags); hipFree(d_rgb); hipFree(d_ranges);
+    return fail(MX_ERR_NOMEM, "device staging buffers: %s", hipGetErrorString(e));
+  }
+  for (int64_t done = 0; done < count && rc == MX_OK; done += chunk) {
+    const int64_t c = std::min(chunk, count - done);
+    e = hipMemcpyAsync(d_ranges, ranges + 2 * done, (size_t)c * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { rc = fail(MX_ERR_DEVICE, "ranges upload: %s", hipGetErrorString(e)); break; }
+    rc = mx_stft_ranges_dev(ctx, a, N, d_ranges, c, kmin, kmax, d_mags, nullptr);
+    if (rc) break;
+    // second launch on the same stream: the magnitudes never leave the device
+    e = launch_colormap(d_mags, d_rgb, c * (int64_t)row, k, ctx->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(rgb_out + (size_t)done * row * 3, d_rgb, (size_t)c * row * 3, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "colormap / download: %s", hipGetErrorString(e));
+  }
+  hipFree(d_mags); hipFree(d_rgb); hipFree(d_ranges);
+  return rc;
 }
 
 // ---- time maps -----------------------------------------------------------------

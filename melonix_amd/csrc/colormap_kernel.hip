@@ -1,0 +1,63 @@
+// colormap_kernel.hip — SpecCache::populateTex's colormap (reference spec-cache.cpp:77-96) on the
+// GPU: magnitude rows (HBM/L2-resident, straight out of the STFT kernel) -> RGB8 texture rows, so a
+// batch of columns leaves the device as 3 bytes per bin instead of 4 and the UI thread's per-column
+// loop disappears.  Arithmetic follows the reference operation by operation:
+//   v = clamp(mag*k, 0, 255)                      binary32
+//   v < 85 (=255/3):   (uchar)v, 0, 0
+//   v < 170 (=2*255/3): a = (v-85)/85 [binary32] * 3.141592 / 2 [binary64];
+//                       (uchar)(v*cos(a)), (uchar)(v*sin(a)), 0   [binary64 products, truncation]
+//   else:               l = (uchar)((v-170)*3); l, (uchar)v, l
+// Built with -ffp-contract=off.  Four texels per thread -> three dword stores (coalesced).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace mx {
+namespace {
+
+__device__ __forceinline__ void texel(float mag, float k, unsigned &r, unsigned &g, unsigned &b) {
+  float v = mag * k;
+  v = v < 0.f ? 0.f : (255.f < v ? 255.f : v);  // std::clamp(v, 0.f, 255.f)
+  if (v < 85.f) {
+    r = (unsigned)(unsigned char)v; g = 0; b = 0;
+  } else if (v < 170.f) {
+    const double a = (double)((v - 85.f) / 85.f) * 3.141592 / 2;
+    r = (unsigned)(unsigned char)((double)v * cos(a));
+    g = (unsigned)(unsigned char)((double)v * sin(a));
+    b = 0;
+  } else {
+    const unsigned l = (unsigned)(unsigned char)((v - 170.f) * 3.f);
+    r = l; g = (unsigned)(unsigned char)v; b = l;
+  }
+}
+
+__global__ __launch_bounds__(256) void colormap_kernel(const float4 *__restrict__ mags, uint32_t *__restrict__ rgb,
+                                                       int64_t n4, float k) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 m = mags[i];
+  unsigned r0, g0, b0, r1, g1, b1, r2, g2, b2, r3, g3, b3;
+  texel(m.x, k, r0, g0, b0);
+  texel(m.y, k, r1, g1, b1);
+  texel(m.z, k, r2, g2, b2);
+  texel(m.w, k, r3, g3, b3);
+  uint32_t *o = rgb + 3 * i;  // 12 bytes: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+  o[0] = r0 | (g0 << 8) | (b0 << 16) | (r1 << 24);
+  o[1] = g1 | (b1 << 8) | (r2 << 16) | (g2 << 24);
+  o[2] = b2 | (r3 << 8) | (g3 << 16) | (b3 << 24);
+}
+
+}  // namespace
+
+hipError_t launch_colormap(const float *mags, uint8_t *rgb, int64_t nbins_total, float k, hipStream_t s) {
+  if (nbins_total <= 0) return hipSuccess;
+  if (nbins_total % 4) return hipErrorInvalidValue;  // rows are N/2 bins, N/2 % 4 == 0
+  const int64_t n4 = nbins_total / 4;
+  const int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(colormap_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4 *>(mags),
+                     reinterpret_cast<uint32_t *>(rgb), n4, k);
+  return hipGetLastError();
+}
+
+}  // namespace mx

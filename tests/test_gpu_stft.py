@@ -145,3 +145,23 @@ def test_errors(gpu_ctx, mxlib):
     with pytest.raises(mxlib.MxError):
         gpu_ctx.stft_hop(a, 4096, 256, band=(100, 50))
     a.free()
+
+
+@pytest.mark.parametrize("N", [4096, 32768])
+def test_fused_colormap(gpu_ctx, oracle, N):
+    """mx_stft_ranges_rgb = oracle colormap (spec-cache.cpp:77-96) of the GPU's own magnitude rows, byte for
+    byte, for brightness settings that exercise all three segments; vs the oracle's own magnitudes the
+    bytes may differ by one level where a bin sits on a truncation edge."""
+    w = noisy(accum_sweep(10 * SR))
+    ranges = [(48000, 48375), (0, 256), (-500, -100), (239744, 240000), (100000, 100001), (1000, 60000)]
+    a = gpu_ctx.upload(w)
+    mags, _ = gpu_ctx.stft_ranges(a, N, ranges)
+    for k in (0.01, 512.0, 2.0 ** 15, 2.0 ** 19):  # k = 2^(brightness/10 + 9), app.cpp:75
+        rgb = gpu_ctx.stft_ranges_rgb(a, N, ranges, k)
+        want = np.stack([oracle.colormap(m, k) for m in mags])
+        assert np.array_equal(rgb, want)
+        ref = np.stack([oracle.colormap(oracle.spec_frame(w, N, s, e), k) for s, e in ranges])
+        assert (np.abs(rgb.astype(int) - ref.astype(int)) <= 1).mean() > 0.999
+    seg = np.stack([oracle.colormap(m, 2.0 ** 15) for m in mags])
+    assert (seg[..., 1] > 0).any() and (seg[..., 2] > 0).any()  # the test really reaches segments 2 and 3
+    a.free()
