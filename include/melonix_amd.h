@@ -177,6 +177,18 @@ int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate,
                   const mx_marker *markers, int nmarkers, const char *path,
                   int strict_reference_header);
 
+/* ---- waveform min/max pyramid ---------------------------------------------------
+ * Replaces App::calcPicks (app.cpp:347-378): level l = floor(n / 2^(l+1)) {min,max} pairs over blocks
+ * of 2^(l+1) samples, for every l with n > 2^(l+1).  picks_out (host, caller-allocated, 2*n floats
+ * always suffice) receives the levels one after the other as interleaved {min,max}; counts_out
+ * (>= 64 entries) the pairs per level; *nlevels the number of levels. */
+int mx_minmax_pyramid(mx_ctx *ctx, const mx_audio *a, float *picks_out, int64_t *counts_out, int *nlevels);
+/* Same, the pairs stay in HBM (d_picks: 2*n floats of capacity); counts_out / nlevels are host. */
+int mx_minmax_pyramid_dev(mx_ctx *ctx, const mx_audio *a, float *d_picks, int64_t *counts_out, int *nlevels);
+/* Replaces App::getMinMaxFromRange (app.cpp:380-426) over such a pyramid (host), quirks included. */
+void mx_minmax_range(const float *host_wav, int64_t n, const float *picks, const int64_t *counts, int nlevels,
+                     int start, int end, float *mn, float *mx);
+
 /* ---- WAV writer -------------------------------------------------------------
  * Replaces saveWav (save-wav.cpp:17-48).  strict_reference_header != 0
  * reproduces the size-field quirk of save-wav.cpp:43 byte for byte (data size

@@ -155,6 +155,18 @@ class Context:
         _capi.check(_capi.lib().mx_resynth_dev(self.handle, audio.handle, C.c_void_p(d_steps), nsteps, nsamples,
                                                C.c_void_p(d_f32 or 0), C.c_void_p(d_i16 or 0)))
 
+    def minmax_pyramid(self, audio: Audio):
+        """App::calcPicks on the GPU -> list of (count_l, 2) float32 arrays {min,max}, one per level."""
+        picks = np.empty(2 * max(audio.n, 1), dtype=np.float32)
+        counts = np.zeros(64, dtype=np.int64)
+        nl = C.c_int()
+        _capi.check(_capi.lib().mx_minmax_pyramid(self.handle, audio.handle, _ptr(picks), _ptr(counts), C.byref(nl)))
+        out, off = [], 0
+        for l in range(nl.value):
+            out.append(picks[off:off + 2 * counts[l]].reshape(-1, 2).copy())
+            off += 2 * int(counts[l])
+        return out
+
     def export_wav(self, wav, sr: int, markers, path: str, strict: bool = True):
         wav = np.ascontiguousarray(wav, dtype=np.float32)
         m = _capi.markers_array(markers)
@@ -194,6 +206,18 @@ def schedule_build(wav, sr: int, starts, lens, markers):
 def save_wav(path, pcm16, sr: int, strict: bool = True):
     pcm16 = np.ascontiguousarray(pcm16, dtype=np.int16)
     _capi.check(_capi.lib().mx_save_wav(str(path).encode(), _ptr(pcm16), len(pcm16), sr, 1 if strict else 0))
+
+
+def minmax_range(wav, levels, start, end):
+    """App::getMinMaxFromRange over a pyramid from Context.minmax_pyramid (host)."""
+    wav = np.ascontiguousarray(wav, dtype=np.float32)
+    flat = np.ascontiguousarray(np.concatenate([l.reshape(-1) for l in levels]) if levels else np.zeros(2, np.float32))
+    counts = np.zeros(64, dtype=np.int64)
+    counts[:len(levels)] = [len(l) for l in levels]
+    a, b = C.c_float(), C.c_float()
+    _capi.lib().mx_minmax_range(_ptr(wav), len(wav), _ptr(flat), _ptr(counts), len(levels), int(start), int(end),
+                                C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def sample2time(markers, sr, val):

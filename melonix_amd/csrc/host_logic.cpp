@@ -226,6 +226,52 @@ int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *g
 }
 
 // ---------------------------------------------------------------------------
+// Waveform pyramid query
+// ---------------------------------------------------------------------------
+namespace {
+struct Pyramid {
+  const float *wav;
+  int64_t n;
+  const float *level[64];
+  const int64_t *counts;
+  int nlevels;
+
+  std::pair<float, float> query(int start, int end) const {
+    const int size = static_cast<int>(n);
+    if (start >= end) return (start >= 0 && start < size) ? std::pair{wav[start], wav[start]} : std::pair{0.f, 0.f};
+    if (start < 0 || end < 0 || start >= size || end >= size) return {0.f, 0.f};
+    if (end - start == 1) return {wav[start], wav[start]};
+    const auto lvl = static_cast<size_t>(std::log2(end - start));  // app.cpp:399
+    const int block = 1 << lvl;
+    const int idx = start / block;
+    std::pair<float, float> r{0.f, 0.f};
+    if (lvl - 1 < static_cast<size_t>(nlevels) && idx < static_cast<int>(counts[lvl - 1]))
+      r = {level[lvl - 1][2 * idx], level[lvl - 1][2 * idx + 1]};
+    auto widen = [&r](std::pair<float, float> o) {
+      r.first = std::min(r.first, o.first);
+      r.second = std::max(r.second, o.second);
+    };
+    if (idx * block >= start) widen(query(start, idx * block));       // app.cpp:410-416
+    if ((idx + 1) * block < end) widen(query((idx + 1) * block, end));  // app.cpp:418-424
+    return r;
+  }
+};
+}  // namespace
+
+void minmax_from_range(const float *wav, int64_t n, const float *picks, const int64_t *counts, int nlevels,
+                       int start, int end, float &mn, float &mx) {
+  Pyramid p{wav, n, {}, counts, std::min(nlevels, 64)};
+  const float *q = picks;
+  for (int l = 0; l < p.nlevels; ++l) {
+    p.level[l] = q;
+    q += 2 * counts[l];
+  }
+  const auto r = p.query(start, end);
+  mn = r.first;
+  mx = r.second;
+}
+
+// ---------------------------------------------------------------------------
 // RIFF writer
 // ---------------------------------------------------------------------------
 namespace {

@@ -66,6 +66,12 @@ int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *g
 // count does not fit (rate so small that the reference's int loop would overflow).
 int64_t step_size(float rate, int32_t L);
 
+// App::getMinMaxFromRange (app.cpp:380-426) over a pyramid laid out level after level (counts[l] pairs in
+// level l, interleaved {min,max}); reproduces the reference's lookups exactly, including its habit of taking
+// the whole 2^lvl block that contains `start`.
+void minmax_from_range(const float *wav, int64_t n, const float *picks, const int64_t *counts, int nlevels,
+                       int start, int end, float &mn, float &mx);
+
 int write_wav(const char *path, const int16_t *pcm, int64_t m, int sampleRate, bool strict);
 
 }  // namespace mx

@@ -56,6 +56,10 @@ hipError_t launch_resynth(const ResynthArgs &a, hipStream_t s);
 // spec-cache.cpp:77-96 colormap: nbins_total magnitudes -> 3*nbins_total bytes (both device).
 hipError_t launch_colormap(const float *mags, uint8_t *rgb, int64_t nbins_total, float k, hipStream_t s);
 
+// App::calcPicks (app.cpp:347-378): all levels, level after level, into d_out ({min,max} pairs; n pairs
+// of capacity always suffice); counts[l] = pairs in level l (host array of >= 64), *nlevels = levels.
+hipError_t launch_picks(const float *audio_padded, int64_t n, float *d_out, int64_t *counts, int *nlevels, hipStream_t s);
+
 // Zero-crossing predicate bitmaps for grain segmentation (app.cpp:167-181, 202-216).
 hipError_t launch_zc_bitmaps(const float *audio_padded, int64_t n, uint64_t *zc7, uint64_t *zc3,
                              hipStream_t s);

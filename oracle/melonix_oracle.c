@@ -666,6 +666,81 @@ int mxo_save_wav(const char *path, const int16_t *pcm, long m, int sampleRate) {
 }
 
 /* ======================================================================
+ * Waveform min/max pyramid — App::calcPicks / getMinMaxFromRange, app.cpp:347-426
+ * ====================================================================== */
+int mxo_calc_picks(const float *wav, long n, float *out, long *counts, int max_levels) {
+  int lvl = 0;
+  size_t size = (size_t)n;
+  if (size <= ((size_t)1 << (lvl + 1))) return 0; /* app.cpp:352 */
+  long cnt = (long)(size / ((size_t)1 << (lvl + 1)));
+  for (long i = 0; i < cnt; ++i) { /* app.cpp:356-361 */
+    const float a = wav[i * 2], b = wav[i * 2 + 1];
+    out[2 * i] = b < a ? b : a;     /* std::min(a, b) */
+    out[2 * i + 1] = a < b ? b : a; /* std::max(a, b) */
+  }
+  counts[0] = cnt;
+  const float *prev = out;
+  float *cur = out + 2 * cnt;
+  for (;;) { /* app.cpp:363-376 */
+    ++lvl;
+    if (size <= ((size_t)1 << (lvl + 1)) || lvl >= max_levels) break;
+    cnt = (long)(size / ((size_t)1 << (lvl + 1)));
+    for (long i = 0; i < cnt; ++i) {
+      const float m0 = prev[2 * (2 * i)], m1 = prev[2 * (2 * i + 1)];
+      const float x0 = prev[2 * (2 * i) + 1], x1 = prev[2 * (2 * i + 1) + 1];
+      cur[2 * i] = m1 < m0 ? m1 : m0;
+      cur[2 * i + 1] = x0 < x1 ? x1 : x0;
+    }
+    counts[lvl] = cnt;
+    prev = cur;
+    cur += 2 * cnt;
+  }
+  return lvl;
+}
+
+static void minmax_rec(const float *wav, long n, const float *const *lv, const long *counts, int nlevels,
+                       int start, int end, float *mn, float *mx) {
+  if (start >= end) { /* app.cpp:382-387 */
+    if (start >= 0 && start < (int)n) { *mn = wav[start]; *mx = wav[start]; } else { *mn = 0.f; *mx = 0.f; }
+    return;
+  }
+  if (start < 0 || end < 0) { *mn = 0.f; *mx = 0.f; return; }
+  if (start >= (int)n || end >= (int)n) { *mn = 0.f; *mx = 0.f; return; }
+  if (end - start == 1) { *mn = wav[start]; *mx = wav[start]; return; }
+  const size_t lvl = (size_t)log2((double)(end - start)); /* app.cpp:399 */
+  const int lvlStart = start / (1 << lvl);
+  float a = 0.f, b = 0.f; /* app.cpp:402-408 */
+  if (!(lvl - 1 >= (size_t)nlevels) && !(lvlStart >= (int)counts[lvl - 1])) {
+    a = lv[lvl - 1][2 * lvlStart];
+    b = lv[lvl - 1][2 * lvlStart + 1];
+  }
+  const int leftEnd = lvlStart * (1 << lvl);
+  if (leftEnd >= start) { /* app.cpp:411-416 */
+    float l0, l1;
+    minmax_rec(wav, n, lv, counts, nlevels, start, leftEnd, &l0, &l1);
+    a = l0 < a ? l0 : a;
+    b = b < l1 ? l1 : b;
+  }
+  const int rightStart = (lvlStart + 1) * (1 << lvl);
+  if (rightStart < end) { /* app.cpp:419-424 */
+    float r0, r1;
+    minmax_rec(wav, n, lv, counts, nlevels, rightStart, end, &r0, &r1);
+    a = r0 < a ? r0 : a;
+    b = b < r1 ? r1 : b;
+  }
+  *mn = a;
+  *mx = b;
+}
+
+void mxo_minmax_range(const float *wav, long n, const float *picks, const long *counts, int nlevels,
+                      int start, int end, float *mn, float *mx) {
+  const float *lv[64];
+  const float *p = picks;
+  for (int l = 0; l < nlevels && l < 64; ++l) { lv[l] = p; p += 2 * counts[l]; }
+  minmax_rec(wav, n, lv, counts, nlevels, start, end, mn, mx);
+}
+
+/* ======================================================================
  * Synthetic input — SURVEY.md §8(d): closed-form linear sine sweep.
  * ====================================================================== */
 void mxo_sweep(float *out, long n, int sampleRate, double f0, double f1, double amp) {

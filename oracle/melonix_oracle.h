@@ -131,6 +131,15 @@ int mxo_save_wav(const char *path, const int16_t *pcm, long m, int sampleRate);
 /* Same bytes into memory; buf must hold 44+2*m (and at least 48) bytes; returns length. */
 long mxo_wav_bytes(const int16_t *pcm, long m, int sampleRate, unsigned char *buf);
 
+/* ---- waveform min/max pyramid (app.cpp:347-426) ------------------------- */
+/* calcPicks: level l holds floor(n / 2^(l+1)) (min,max) pairs over blocks of 2^(l+1) samples, while
+ * n > 2^(l+1).  Returns the number of levels; pairs are written level after level, interleaved
+ * {min,max}, into out (capacity: n pairs is always enough); counts[l] = pairs in level l. */
+int mxo_calc_picks(const float *wav, long n, float *out, long *counts, int max_levels);
+/* getMinMaxFromRange(start, end) over a pyramid built by mxo_calc_picks (incl. its quirks). */
+void mxo_minmax_range(const float *wav, long n, const float *picks, const long *counts, int nlevels,
+                      int start, int end, float *mn, float *mx);
+
 /* ---- synthetic input ----------------------------------- */
 void mxo_sweep(float *out, long n, int sampleRate, double f0, double f1, double amp);
 

@@ -90,6 +90,9 @@ def lib():
         L.mxo_save_wav.argtypes = [C.c_char_p, C.POINTER(C.c_int16), C.c_long, C.c_int]
         L.mxo_wav_bytes.restype = C.c_long
         L.mxo_wav_bytes.argtypes = [C.POINTER(C.c_int16), C.c_long, C.c_int, C.POINTER(C.c_ubyte)]
+        L.mxo_calc_picks.restype = C.c_int
+        L.mxo_calc_picks.argtypes = [fp, C.c_long, fp, C.POINTER(C.c_long), C.c_int]
+        L.mxo_minmax_range.argtypes = [fp, C.c_long, fp, C.POINTER(C.c_long), C.c_int, C.c_int, C.c_int, fp, fp]
         L.mxo_sweep.argtypes = [fp, C.c_long, C.c_int, C.c_double, C.c_double, C.c_double]
         _LIB = L
     return _LIB
@@ -227,6 +230,30 @@ def export_run(wav, sr, markers, memo=True):
     pcm = np.ctypeslib.as_array(e.pcm, shape=(max(e.nsamples, 1),))[: e.nsamples].copy()
     lib().mxo_export_free(C.byref(e))
     return steps, pcm
+
+
+def calc_picks(wav):
+    """-> list of (count_l, 2) float32 arrays, one per level (app.cpp:347-378)."""
+    wav, p = _f32(wav)
+    n = len(wav)
+    out = np.empty(2 * max(n, 1), dtype=np.float32)
+    counts = (C.c_long * 64)()
+    nl = lib().mxo_calc_picks(p, n, out.ctypes.data_as(C.POINTER(C.c_float)), counts, 64)
+    levels, off = [], 0
+    for l in range(nl):
+        levels.append(out[off:off + 2 * counts[l]].reshape(-1, 2).copy())
+        off += 2 * counts[l]
+    return levels
+
+
+def minmax_range(wav, levels, start, end):
+    wav, p = _f32(wav)
+    flat = np.concatenate([l.reshape(-1) for l in levels]) if levels else np.zeros(2, np.float32)
+    counts = (C.c_long * 64)(*[len(l) for l in levels])
+    a, b = C.c_float(), C.c_float()
+    lib().mxo_minmax_range(p, len(wav), flat.ctypes.data_as(C.POINTER(C.c_float)), counts, len(levels), int(start), int(end),
+                           C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def pcm_to_i16(pcm):

@@ -126,3 +126,15 @@ def test_save_wav_correct_header(mxlib, tmp_path):
     assert int.from_bytes(b[40:44], "little") == 20 and int.from_bytes(b[4:8], "little") == len(b) - 8
     assert np.array_equal(np.frombuffer(b[44:], dtype="<i2"), pcm)
     assert int.from_bytes(b[24:28], "little") == 44100 and int.from_bytes(b[28:32], "little") == 88200
+
+
+@settings(max_examples=50, deadline=None)
+@given(st.integers(3, 5000), st.integers(0, 2**31 - 1))
+def test_minmax_range_matches_oracle(mxlib, oracle, n, seed):
+    """Host query App::getMinMaxFromRange (product) == oracle on the oracle's pyramid."""
+    rng = np.random.default_rng(seed)
+    w = rng.uniform(-1, 1, n).astype(np.float32)
+    lv = oracle.calc_picks(w)
+    for _ in range(20):
+        s_, e_ = (int(x) for x in rng.integers(-5, n + 5, 2))
+        assert mxlib.minmax_range(w, lv, s_, e_) == oracle.minmax_range(w, lv, s_, e_)
