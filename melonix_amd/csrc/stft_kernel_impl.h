@@ -10,34 +10,42 @@
 
 namespace mx {
 
-// Wavefront max of a 64-bit key through the DPP crossbar (no LDS round trips, unlike __shfl_xor
-// which lowers to ds_bpermute): xor-1, xor-2 (quad_perm), row_half_mirror, row_mirror leave every
-// 16-lane row with its maximum; row_bcast:15 / row_bcast:31 fold the rows; lane 63 holds the result.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long k) {
-  const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
-  // lanes the control does not reach keep their own value (old = src): identity for max
-  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
-  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
-  const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-  return o > k ? o : k;
+// Wavefront reductions through the DPP crossbar (no LDS round trips, unlike __shfl_xor which lowers
+// to ds_bpermute): xor-1, xor-2 (quad_perm), row_half_mirror, row_mirror leave every 16-lane row
+// with its result; row_bcast:15 / row_bcast:31 fold the rows; lane 63 holds the wavefront's.
+// `old` is the operation's identity, so lanes a control does not reach are unaffected and the
+// compiler's DPP-combine pass can fold each move into the v_max/v_min that consumes it.
+template <bool MAXOP>
+__device__ __forceinline__ unsigned wave_reduce_u32(unsigned k) {
+  constexpr unsigned ident = MAXOP ? 0u : 0xffffffffu;
+#define MX_DPP_STEP(CTRL, ROWS)                                                                      \
+  {                                                                                                  \
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)k, CTRL, ROWS, 0xf, false); \
+    k = MAXOP ? (o > k ? o : k) : (o < k ? o : k);                                                   \
+  }
+  MX_DPP_STEP(0xB1, 0xf)   // quad_perm [1,0,3,2]
+  MX_DPP_STEP(0x4E, 0xf)   // quad_perm [2,3,0,1]
+  MX_DPP_STEP(0x141, 0xf)  // row_half_mirror
+  MX_DPP_STEP(0x140, 0xf)  // row_mirror
+  MX_DPP_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+  MX_DPP_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef MX_DPP_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
 }
+// max over the wavefront of (magnitude bits, then lowest bin): two 32-bit reductions.
+// key = (mag bits << 32) | (0x7fffffff - bin); returns the wavefront's best key.
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
-  k = dpp_max_step<0xB1, 0xf>(k);   // quad_perm [1,0,3,2]
-  k = dpp_max_step<0x4E, 0xf>(k);   // quad_perm [2,3,0,1]
-  k = dpp_max_step<0x141, 0xf>(k);  // row_half_mirror
-  k = dpp_max_step<0x140, 0xf>(k);  // row_mirror
-  k = dpp_max_step<0x142, 0xa>(k);  // row_bcast:15 into rows 1 and 3
-  k = dpp_max_step<0x143, 0xc>(k);  // row_bcast:31 into rows 2 and 3
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
-  return ((unsigned long long)hi << 32) | lo;
+  const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+  const unsigned mhi = wave_reduce_u32<true>(hi);
+  const unsigned mlo = wave_reduce_u32<true>(hi == mhi ? lo : 0u);
+  return ((unsigned long long)mhi << 32) | mlo;
 }
 
 // WPE: waves per SIMD the register allocator must leave room for (amdgpu_waves_per_eu);
 // NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
 // and window loads are not hoisted out of the frame loop into hundreds of registers.
-template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, bool TWREG = false, bool OUTSEP = false>
+template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, bool TWREG = false, bool OUTSEP = false,
+          bool DEFER = false>
 __global__ __launch_bounds__(P::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void stft_kernel(const StftArgs a0) {
   const StftArgs &a = a0;
@@ -53,6 +61,7 @@ void stft_kernel(const StftArgs a0) {
   float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + C::M + kRed : lds);
 
   const int t_ = threadIdx.x;
+  const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;  // wave-uniform
   cpx u[P::R3];  // post-split twiddles: E registers that replace R3 complex multiplies per frame
   post_twiddles<P>(t_, a.ubase, u);
   const uint32_t bmask_ = band_mask<P>(t_, a.kmin, a.kmax);
@@ -91,6 +100,47 @@ void stft_kernel(const StftArgs a0) {
     slide_edge<P, HOP>(t_, a.wtab, 2.0f * (float)N, edge);
   }
 
+  // DEFER (needs OUTSEP): the magnitude row and the pitch record of frame f leave the workgroup
+  // during frame f+1 — scatter at the end of f, LDS read + global stores after f+1's T1 barrier —
+  // so no barrier and no LDS round trip sits in the output path.
+  static_assert(!DEFER || OUTSEP, "deferred output needs its own LDS region");
+  unsigned long long *const red = reinterpret_cast<unsigned long long *>(lds + C::M);
+  auto flush_pitch = [&](int64_t fr, int tt) {  // after a barrier that follows red[] of frame fr
+    if (a.pitch && tt == 0) {
+      unsigned long long b = red[0];
+#pragma unroll
+      for (int i = 1; i < NW; ++i) b = red[i] > b ? red[i] : b;
+      mx_pitch p;
+      p.bin = 0x7fffffff - (int)(unsigned)(b & 0xffffffffull);
+      p.mag = __uint_as_float((unsigned)(b >> 32));
+      a.pitch[fr] = p;
+    }
+  };
+  auto flush_row = [&](int64_t fr, int tt) {  // after a barrier that follows the scatter of frame fr
+    if (a.mags) {
+      using f32x4 = float __attribute__((ext_vector_type(4)));
+      const f32x4 *l4 = reinterpret_cast<const f32x4 *>(lout) + tt;
+      f32x4 *row4 = reinterpret_cast<f32x4 *>(a.mags + (size_t)fr * (size_t)(N / 2)) + tt;
+      f32x4 q[C::M / 4 / C::T];
+#pragma unroll
+      for (int i = 0; i < C::M / 4 / C::T; ++i) q[i] = l4[C::T * i];
+#pragma unroll
+      for (int i = 0; i < C::M / 4 / C::T; ++i) {
+#if defined(MX_ABL_NOGSTORE)
+        asm volatile("" ::"v"(q[i]), "v"(row4));
+#elif defined(MX_STORE_PLAIN)
+        row4[C::T * i] = q[i];
+#elif defined(MX_STORE_SC)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, q[i]),
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.mags + (size_t)fr * (size_t)(N / 2)), 0, N / 2 * 4, 0x00020000),
+            (tt + C::T * i) * 16, 0, MX_STORE_SC);
+#else
+        __builtin_nontemporal_store(q[i], &row4[C::T * i]);
+#endif
+      }
+    }
+  };
+
   for (int64_t f = f0; f < f1; ++f) {
     // Everything below that depends only on the thread index is frame-invariant; left alone,
     // LICM hoists ~150 addresses, masks and table values out of the frame loop and the kernel
@@ -107,7 +157,9 @@ void stft_kernel(const StftArgs a0) {
     out_bases<P>(t, out_lo, out_hi);
 
     if constexpr (kSlide) {
+      // in-place shift+decay into this frame (Y[e] <- Y[e+D]*g reads ahead of what it writes), then
       // prefetch the next frame's newest hop (1 KiB per wavefront) under this frame's math
+      if (f > f0) slide_step<P, HOP>(Y, nx, edge, a.decay, kSc);
       if (f + 1 < f1) slide_fetch<P, HOP>(t, a.audio + MX_AUDIO_PAD + (a.first_frame + f + 2) * (int64_t)HOP, nx);
     } else {
       const float *x;
@@ -131,13 +183,17 @@ void stft_kernel(const StftArgs a0) {
 
     cpx v[P::E];
     pass1<P>(Y, v);
-    if constexpr (kSlide) {
-      if (f + 1 < f1) slide_step<P, HOP>(Y, nx, edge, a.decay, kSc);
-    }
 #ifndef MX_ABL_NOLDS
+    if constexpr (DEFER) {
+      __syncthreads();  // every wave is past load_t2 / scatter / red[] of the previous frame
+      if (f > f0) flush_pitch(f - 1, t);
+    }
     store_t1<P>(t, v, lds);
     __syncthreads();
     load_t1<P>(t, v, lds);
+    if constexpr (DEFER) {
+      if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
+    }
     __syncthreads();
 #endif
     if constexpr (TWREG) pass2_reg<P>(v, w2r);
@@ -148,17 +204,22 @@ void stft_kernel(const StftArgs a0) {
     load_t2<P>(t, v, lds);
     if constexpr (!OUTSEP) __syncthreads();  // image free: the magnitude scatter below reuses it
 #endif
-    if constexpr (TWREG) pass3_reg<P>(t, v, w3r);
-    else pass3<P>(t, v, tw3);
     float mg[P::E];
-    post<P>(t, v, u, mg);
+    if (NW == 1 || wave0) {  // wave-uniform: only the first wavefront contains thread 0
+      if constexpr (TWREG) pass3_reg<P, true>(t, v, w3r);
+      else pass3<P, true>(t, v, tw3);
+      post<P, true>(t, v, u, mg);
+    } else {
+      if constexpr (TWREG) pass3_reg<P, false>(t, v, w3r);
+      else pass3<P, false>(t, v, tw3);
+      post<P, false>(t, v, u, mg);
+    }
 
     // ---- pitch pick: per-thread best, then wavefront max (registers only) ----
     // key = (magnitude bits << 32) | (0x7fffffff - bin): non-negative floats order like their
     // bit patterns, so max(key) = largest magnitude, lowest bin on ties; out-of-band -> 0.
     // bins: even o -> (s < R3/2 ? lo : hi) + NS3*s, odd o -> M - that (thread 0, s = R3/2: M/2)
     unsigned long long best = 0ull;
-    unsigned long long *red = reinterpret_cast<unsigned long long *>(lds + C::M);
     if (a.pitch) {
       const unsigned klo = 0x7fffffffu - (unsigned)out_lo, khi = 0x7fffffffu - (unsigned)out_hi;
       const unsigned nlo = 0x7fffffffu - (unsigned)(C::M - out_lo), nhi = 0x7fffffffu - (unsigned)(C::M - out_hi);
@@ -177,17 +238,17 @@ void stft_kernel(const StftArgs a0) {
         best = k1 > best ? k1 : best;
       }
       best = wave_max_u64(best);
-      if constexpr (NW > 1) {
-        if ((t & 63) == 0) red[t >> 6] = best;  // published by the barrier below
+      if constexpr (NW > 1 || DEFER) {
+        if ((t & 63) == 0) red[t >> 6] = best;  // published by the next barrier
       }
     }
 
     // ---- magnitudes ----
+    // Transpose through LDS: each lane scatters its E bins as dwords (consecutive lanes ->
+    // consecutive bins, conflict-free), then every lane owns 4 consecutive bins and the row
+    // leaves as global_store_dwordx4, 1 KiB contiguous per wavefront instruction, instead of E
+    // dword stores with one stray element each (thread 0's self-paired bins).
     if (a.mags) {
-      // Transpose through LDS: each lane scatters its E bins as dwords (consecutive lanes ->
-      // consecutive bins, conflict-free), then every lane owns 4 consecutive bins and the row
-      // leaves as global_store_dwordx4, 1 KiB contiguous per wavefront instruction, instead of E
-      // dword stores with one stray element each (thread 0's self-paired bins).
       float *plo = lout + out_lo, *phi = lout + out_hi;
       float *mlo = lout + (C::M - out_lo), *mhi = lout + (C::M - out_hi);
 #pragma unroll
@@ -197,33 +258,30 @@ void stft_kernel(const StftArgs a0) {
         if (s == H) (t == 0 ? lout + C::M / 2 : mhi - C::NS3 * H)[0] = mg[2 * s + 1];
         else (s < H ? mlo : mhi)[-C::NS3 * s] = mg[2 * s + 1];
       }
-      __syncthreads();  // (also: every wave is past load_t2, so the image may be refilled)
-      using f32x4 = float __attribute__((ext_vector_type(4)));
-      const f32x4 *l4 = reinterpret_cast<const f32x4 *>(lout) + t;
-#ifdef MX_ABL_SAMEROW
-      f32x4 *row4 = reinterpret_cast<f32x4 *>(a.mags + (size_t)(blockIdx.x & 1023) * (size_t)(N / 2)) + t;
-#else
-      f32x4 *row4 = reinterpret_cast<f32x4 *>(a.mags + (size_t)f * (size_t)(N / 2)) + t;
-#endif
-      f32x4 q[C::M / 4 / C::T];
-#pragma unroll
-      for (int i = 0; i < C::M / 4 / C::T; ++i) q[i] = l4[C::T * i];
-#pragma unroll
-      for (int i = 0; i < C::M / 4 / C::T; ++i) __builtin_nontemporal_store(q[i], &row4[C::T * i]);
-      if constexpr (!OUTSEP) __syncthreads();  // image free again
-    } else {
-      if constexpr (NW > 1 || !OUTSEP) __syncthreads();
     }
-    if (a.pitch && t == 0) {
-      if constexpr (NW > 1) {
-#pragma unroll
-        for (int i = 1; i < NW; ++i) best = red[i] > best ? red[i] : best;
-        // red[] is rewritten only after the next frame's T1/T2 barriers
+    if constexpr (!DEFER) {
+      if (a.mags) {
+        __syncthreads();  // (also: every wave is past load_t2, so the image may be refilled)
+        flush_row(f, t);
+        if constexpr (!OUTSEP) __syncthreads();  // image free again
+      } else {
+        if constexpr (NW > 1 || !OUTSEP) __syncthreads();
       }
-      mx_pitch p;
-      p.bin = 0x7fffffff - (int)(unsigned)(best & 0xffffffffull);
-      p.mag = __uint_as_float((unsigned)(best >> 32));
-      a.pitch[f] = p;
+      if constexpr (NW > 1) {
+        flush_pitch(f, t);  // red[] is rewritten only after the next frame's T1/T2 barriers
+      } else if (a.pitch && t == 0) {
+        mx_pitch p;
+        p.bin = 0x7fffffff - (int)(unsigned)(best & 0xffffffffull);
+        p.mag = __uint_as_float((unsigned)(best >> 32));
+        a.pitch[f] = p;
+      }
+    }
+  }
+  if constexpr (DEFER) {
+    if (f0 < f1) {  // the last frame of this workgroup
+      __syncthreads();
+      flush_pitch(f1 - 1, t_);
+      flush_row(f1 - 1, t_);
     }
   }
 }

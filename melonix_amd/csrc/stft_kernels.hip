@@ -26,7 +26,8 @@ struct Tune {
   static constexpr int WPE = TWO_WAVE ? 3 : 2;
   static constexpr bool NOHOIST = true;
   static constexpr bool TWREG = TWO_WAVE;   // 22 twiddles in registers for the whole workgroup
-  static constexpr bool OUTSEP = false;     // a separate LDS region for the magnitude transposition measured no gain
+  static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
+  static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
 };
 
 template <class P>
@@ -41,16 +42,16 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
   const dim3 grid((unsigned)blocks), block(P::T);
   constexpr int W = Tune<P>::WPE;
   constexpr bool NH = Tune<P>::NOHOIST;
-  constexpr bool TR = Tune<P>::TWREG, OS = Tune<P>::OUTSEP;
+  constexpr bool TR = Tune<P>::TWREG, OS = Tune<P>::OUTSEP, DF = Tune<P>::DEFER;
   switch (mode) {
     case kBulkAligned:
       // the headline hops slide the windowed frame through registers (one HBM read per sample)
-      if (N == 4096 && a.hop == 256) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 4096 ? 256 : 0), W, NH, true, TR, OS>), grid, block, 0, s, b);
-      else if (N == 16384 && a.hop == 512) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 16384 ? 512 : 0), W, NH, true, TR, OS>), grid, block, 0, s, b);
-      else hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TR, OS>), grid, block, 0, s, b);
+      if (N == 4096 && a.hop == 256) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 4096 ? 256 : 0), W, NH, true, TR, OS, DF>), grid, block, 0, s, b);
+      else if (N == 16384 && a.hop == 512) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 16384 ? 512 : 0), W, NH, true, TR, OS, DF>), grid, block, 0, s, b);
+      else hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TR, OS, DF>), grid, block, 0, s, b);
       break;
-    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TR, OS>), grid, block, 0, s, b); break;
-    case kRanges: hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TR, OS>), grid, block, 0, s, b); break;
+    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TR, OS, DF>), grid, block, 0, s, b); break;
+    case kRanges: hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TR, OS, DF>), grid, block, 0, s, b); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

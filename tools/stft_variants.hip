@@ -22,17 +22,17 @@ using namespace mx;
     }                                                                          \
   } while (0)
 
-template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, bool TR = false, bool OS = false>
+template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, bool TR = false, bool OS = false, bool DF = false>
 float time_variant(const StftArgs &a, int reps, const char *name) {
   constexpr int N = C::N;
   const int64_t blocks = (a.count + a.frames_per_block - 1) / a.frames_per_block;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -205,13 +205,14 @@ int main(int argc, char **argv) {
     time_variant<P16, kBulkAligned, 256, 4, true, true>(a16, reps, "2 waves/frame sliding wpe4");
     time_variant<P16, kBulkAligned, 256, 3, true, true, true>(a16, reps, "2 waves/frame twreg wpe3");
     time_variant<P16, kBulkAligned, 256, 3, true, true, true, true>(a16, reps, "2 waves/frame twreg outsep wpe3");
+    time_variant<P16, kBulkAligned, 256, 3, true, true, true, true, true>(a16, reps, "2 waves/frame twreg defer wpe3");
   }
   a16.frames_per_block = 16;
   time_variant<P16, kBulkAligned, 0, 3, true, true, true, true>(a16, reps, "2 waves/frame direct  twreg outsep");
   a16.mags = nullptr;
-  time_variant<P16, kBulkAligned, 256, 3, true, true, true, true>(a16, reps, "2w twreg outsep pitch-only");
+  time_variant<P16, kBulkAligned, 256, 3, true, true, true, true, true>(a16, reps, "2w twreg defer pitch-only");
   a16.mags = d_mags;
   a16.pitch = nullptr;
-  time_variant<P16, kBulkAligned, 256, 3, true, true, true, true>(a16, reps, "2w twreg outsep mags-only");
+  time_variant<P16, kBulkAligned, 256, 3, true, true, true, true, true>(a16, reps, "2w twreg defer mags-only");
   return 0;
 }
