@@ -88,8 +88,8 @@ def cpu_baseline(N: int, hop: int, seconds_budget: float = 12.0):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--fft", type=int, default=4096)
     ap.add_argument("--hop", type=int, default=256)
     ap.add_argument("--minutes", type=float, default=60.0, help="audio per GPU")
