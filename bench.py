@@ -96,6 +96,7 @@ def main() -> None:
     ap.add_argument("--pitch-only", action="store_true", help="do not materialise magnitudes")
     ap.add_argument("--frames-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-resynth", action="store_true", help="skip the supplementary resynthesis measurement")
     args = ap.parse_args()
 
     import torch
@@ -114,7 +115,9 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL path is exercised even with one rank
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -138,22 +141,22 @@ def main() -> None:
 
     mags_t = None if args.pitch_only else torch.empty((F, N // 2), dtype=torch.float32, device=dev)
     pitch_t = [torch.empty((F, 2), dtype=torch.int32, device=dev) for _ in range(2)]  # {bin, mag bits}
-    gathered = [torch.empty((world * F, 2), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world * F, 2), dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def run(k: int, works: list):
-        if world > 1 and k >= 2 and works[k - 2] is not None:
+        if use_dist and k >= 2 and works[k - 2] is not None:
             works[k - 2].wait()
         ctx.stft_hop_dev(audio, N, hop, 0, F, mags_t.data_ptr() if mags_t is not None else None,
                          pitch_t[k & 1].data_ptr(), band=band)
         # the one exchange: stitch the per-rank pitch tracks (8 B/frame) into the whole-signal track,
         # on RCCL's stream so it overlaps the next step's kernel
         works.append(dist.all_gather_into_tensor(gathered[k & 1], pitch_t[k & 1], async_op=True)
-                     if world > 1 else None)
+                     if use_dist else None)
 
     works = []
     for k in range(args.warmup):
@@ -167,13 +170,13 @@ def main() -> None:
     works = []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        if world > 1 and k >= 2 and works[k - 2] is not None:
+        if use_dist and k >= 2 and works[k - 2] is not None:
             works[k - 2].wait()  # the all-gather that read pitch buffer k&1 two steps ago is done
         ev[k][0].record()
         ctx.stft_hop_dev(audio, N, hop, 0, F, mags_t.data_ptr() if mags_t is not None else None,
                          pitch_t[k & 1].data_ptr(), band=band)
         ev[k][1].record()
-        if world > 1:
+        if use_dist:
             works.append(dist.all_gather_into_tensor(gathered[k & 1], pitch_t[k & 1], async_op=True))
         else:
             works.append(None)
@@ -186,7 +189,7 @@ def main() -> None:
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     k_max = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
@@ -195,6 +198,41 @@ def main() -> None:
     # sanity: the last step produced a plausible pitch track (guards against a silently skipped kernel)
     bins = pitch_t[(args.steps - 1) & 1][:, 0]
     ok = bool(((bins >= band[0]) & (bins <= band[1])).all().item())
+    if use_dist:  # the gathered whole-signal track must contain this rank's shard, bit for bit
+        g = gathered[(args.steps - 1) & 1]
+        ok = ok and bool(torch.equal(g[rank * F:(rank + 1) * F], pitch_t[(args.steps - 1) & 1]))
+        okt = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+
+    # supplementary (outside the timed region, rank 0, N=1): resynthesis +3 st of the same audio
+    # (BASELINE configs[2]) — grains on the GPU, schedule on the host, gather-lerp + int16 kernel
+    resynth = None
+    if rank == 0 and world == 1 and not args.no_resynth:
+        host = audio_t[pad:pad + n].cpu().numpy()
+        t0 = time.perf_counter()
+        gs, gl = ctx.grains_dev(audio)
+        t_gr = time.perf_counter() - t0
+        mk = [(1, 0, 0, 3.0), (n - 1, 0, 0, 3.0)]
+        t0 = time.perf_counter()
+        steps_arr, total = mx.schedule_build(host, SR, gs, gl, mk)
+        t_sc = time.perf_counter() - t0
+        d_steps = torch.from_numpy(steps_arr.view(np.uint8).copy()).to(dev)
+        pcm_i = torch.empty(total, dtype=torch.int16, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            ctx.resynth_dev(audio, d_steps.data_ptr(), len(steps_arr), total, None, pcm_i.data_ptr())
+        e0.record()
+        for _ in range(10):
+            ctx.resynth_dev(audio, d_steps.data_ptr(), len(steps_arr), total, None, pcm_i.data_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        r_ms = e0.elapsed_time(e1) / 10
+        rb = (4 * 2.0 ** (3 / 12) + 2) * total  # ~6.76 B per output sample at +3 st
+        resynth = {"pitch_bend_semitones": 3, "pcm_samples": int(total), "steps": int(len(steps_arr)), "kernel_ms": r_ms,
+                   "hop256_frames_per_s": total / 256 / (r_ms * 1e-3), "achieved_GBps": rb / (r_ms * 1e-3) / 1e9,
+                   "frac_of_hbm_peak": rb / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "grain_scan_s": t_gr,
+                   "schedule_host_s": t_sc, "outputs": "int16 PCM, HBM-resident"}
 
     if rank == 0:
         balg = b_alg(N, hop, mags=not args.pitch_only)
@@ -243,6 +281,8 @@ def main() -> None:
             },
             "pitch_track_ok": ok,
         }
+        if resynth is not None:
+            line["resynth_supplementary"] = resynth
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, hop)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
@@ -250,7 +290,7 @@ def main() -> None:
 
     audio.free()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
