@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 // WPE: waves per SIMD the register allocator must leave room for (amdgpu_waves_per_eu);
 // NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
 // and window loads are not hoisted out of the frame loop into hundreds of registers.
-template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, bool TWREG = false, bool OUTSEP = false,
+template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, int TWREG = 0, bool OUTSEP = false,
           bool DEFER = false>
 __global__ __launch_bounds__(P::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void stft_kernel(const StftArgs a0) {
@@ -57,8 +57,11 @@ void stft_kernel(const StftArgs a0) {
   // separate M-float region for the magnitude transposition, so that the image can be refilled by
   // the next frame without an extra barrier
   constexpr int kRed = (NW > 1) ? ((NW + 1) / 2) * 2 : 0;
-  __shared__ __attribute__((aligned(16))) float2 lds[C::M + kRed + (OUTSEP ? C::M / 2 : 0)];
+  // TWREG == 2: the (small) pass-2 twiddle table lives in LDS, shared by the workgroup's waves
+  constexpr int kTw2 = (TWREG == 2) ? ((C::TW2 + 1) / 2) * 2 : 0;
+  __shared__ __attribute__((aligned(16))) float2 lds[C::M + kRed + (OUTSEP ? C::M / 2 : 0) + kTw2];
   float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + C::M + kRed : lds);
+  float2 *const ltw2 = lds + C::M + kRed + (OUTSEP ? C::M / 2 : 0);
 
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;  // wave-uniform
@@ -74,10 +77,12 @@ void stft_kernel(const StftArgs a0) {
   constexpr int SD = Slide<P, (HOP > 0 ? HOP : 2)>::D;
   constexpr float kSc = 0.5f / (float)N;
   // TWREG: this thread's pass-2/pass-3 twiddles live in registers for the whole workgroup
-  cpx w2r[TWREG ? P::NB2 : 1][P::R2 - 1], w3r[P::R3 - 1];
-  if constexpr (TWREG) {
-    fetch_tw2<P>(t_, a.tw2, w2r);
-    fetch_tw3<P>(t_, a.tw3, w3r);
+  cpx w2r[TWREG == 1 ? P::NB2 : 1][P::R2 - 1], w3r[P::R3 - 1];
+  if constexpr (TWREG == 1) fetch_tw2<P>(t_, a.tw2, w2r);
+  if constexpr (TWREG != 0) fetch_tw3<P>(t_, a.tw3, w3r);
+  if constexpr (TWREG == 2) {
+    for (int i = t_; i < C::TW2; i += C::T) ltw2[i] = a.tw2[i];
+    __syncthreads();
   }
 
   // XCD-aware block -> frame-range map: the dispatcher places block b on XCD b % 8 and each
@@ -196,7 +201,8 @@ void stft_kernel(const StftArgs a0) {
     }
     __syncthreads();
 #endif
-    if constexpr (TWREG) pass2_reg<P>(v, w2r);
+    if constexpr (TWREG == 1) pass2_reg<P>(v, w2r);
+    else if constexpr (TWREG == 2) pass2<P>(t, v, ltw2);
     else pass2<P>(t, v, tw2);
 #ifndef MX_ABL_NOLDS
     store_t2<P>(t, v, lds);
@@ -206,11 +212,11 @@ void stft_kernel(const StftArgs a0) {
 #endif
     float mg[P::E];
     if (NW == 1 || wave0) {  // wave-uniform: only the first wavefront contains thread 0
-      if constexpr (TWREG) pass3_reg<P, true>(t, v, w3r);
+      if constexpr (TWREG != 0) pass3_reg<P, true>(t, v, w3r);
       else pass3<P, true>(t, v, tw3);
       post<P, true>(t, v, u, mg);
     } else {
-      if constexpr (TWREG) pass3_reg<P, false>(t, v, w3r);
+      if constexpr (TWREG != 0) pass3_reg<P, false>(t, v, w3r);
       else pass3<P, false>(t, v, tw3);
       post<P, false>(t, v, u, mg);
     }

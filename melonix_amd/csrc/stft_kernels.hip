@@ -25,7 +25,10 @@ struct Tune {
   static constexpr bool TWO_WAVE = (P::E == 16);
   static constexpr int WPE = TWO_WAVE ? 3 : 2;
   static constexpr bool NOHOIST = true;
-  static constexpr bool TWREG = TWO_WAVE;   // 22 twiddles in registers for the whole workgroup
+  // twiddles: 2 = the 7 pass-3 twiddles of this thread in registers for the whole workgroup and the
+  // 1.9 KiB pass-2 table in LDS (145 VGPRs, no global twiddle loads); 1 = all 22 in registers (spills
+  // at 168); 0 = both tables read from L2 every frame
+  static constexpr int TWREG = TWO_WAVE ? 2 : 0;
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
   static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
 };
@@ -42,7 +45,8 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
   const dim3 grid((unsigned)blocks), block(P::T);
   constexpr int W = Tune<P>::WPE;
   constexpr bool NH = Tune<P>::NOHOIST;
-  constexpr bool TR = Tune<P>::TWREG, OS = Tune<P>::OUTSEP, DF = Tune<P>::DEFER;
+  constexpr int TR = Tune<P>::TWREG;
+  constexpr bool OS = Tune<P>::OUTSEP, DF = Tune<P>::DEFER;
   switch (mode) {
     case kBulkAligned:
       // the headline hops slide the windowed frame through registers (one HBM read per sample)

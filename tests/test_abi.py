@@ -72,3 +72,18 @@ def test_resampler_isa_has_no_fma():
     body = body[:body.index("s_endpgm")]
     assert not re.search(r"\bv_(fma|fmac|mad|pk_fma)_f32", body)
     assert "v_mul_f64" in body and "v_cvt_i32_f64" in body  # app.cpp:1212: double multiply, truncation
+
+
+def test_stft_kernels_do_not_spill():
+    """Every shipped STFT kernel instantiation must be scratch-free (a silent spill cost ~7 % once)."""
+    src = os.path.join(ROOT, "melonix_amd", "csrc", "stft_kernels.hip")
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-c", "-x", "hip", src,
+                          "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    vgprs = [int(x) for x in re.findall(r"\bVGPRs: (\d+)", out.stderr)]
+    assert len(names) == len(scratch) == len(vgprs) and len(names) >= 9
+    bad = [(n, s) for n, s in zip(names, scratch) if "stft_kernel" in n and s != 0]
+    assert not bad, bad
+    assert max(vgprs) <= 256

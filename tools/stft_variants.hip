@@ -22,7 +22,7 @@ using namespace mx;
     }                                                                          \
   } while (0)
 
-template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, bool TR = false, bool OS = false, bool DF = false>
+template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, int TR = 0, bool OS = false, bool DF = false>
 float time_variant(const StftArgs &a, int reps, const char *name) {
   constexpr int N = C::N;
   const int64_t blocks = (a.count + a.frames_per_block - 1) / a.frames_per_block;
@@ -203,16 +203,18 @@ int main(int argc, char **argv) {
     a32.frames_per_block = a16.frames_per_block = g;
     time_variant<P32, kBulkAligned, 256, 2, true, true>(a32, reps, "1 wave/frame  sliding wpe2");
     time_variant<P16, kBulkAligned, 256, 4, true, true>(a16, reps, "2 waves/frame sliding wpe4");
-    time_variant<P16, kBulkAligned, 256, 3, true, true, true>(a16, reps, "2 waves/frame twreg wpe3");
-    time_variant<P16, kBulkAligned, 256, 3, true, true, true, true>(a16, reps, "2 waves/frame twreg outsep wpe3");
-    time_variant<P16, kBulkAligned, 256, 3, true, true, true, true, true>(a16, reps, "2 waves/frame twreg defer wpe3");
+    time_variant<P16, kBulkAligned, 256, 3, true, true, 1>(a16, reps, "2 waves/frame twreg wpe3");
+    time_variant<P16, kBulkAligned, 256, 4, true, true, 2>(a16, reps, "2w tw3reg+tw2lds wpe4");
+    time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true>(a16, reps, "2w tw3reg+tw2lds defer wpe3");
+    time_variant<P16, kBulkAligned, 256, 3, true, true, 1, true>(a16, reps, "2 waves/frame twreg outsep wpe3");
+    time_variant<P16, kBulkAligned, 256, 3, true, true, true, 1, true>(a16, reps, "2 waves/frame twreg defer wpe3");
   }
   a16.frames_per_block = 16;
-  time_variant<P16, kBulkAligned, 0, 3, true, true, true, true>(a16, reps, "2 waves/frame direct  twreg outsep");
+  time_variant<P16, kBulkAligned, 0, 3, true, true, 1, true>(a16, reps, "2 waves/frame direct  twreg outsep");
   a16.mags = nullptr;
-  time_variant<P16, kBulkAligned, 256, 3, true, true, true, true, true>(a16, reps, "2w twreg defer pitch-only");
+  time_variant<P16, kBulkAligned, 256, 3, true, true, true, 1, true>(a16, reps, "2w twreg defer pitch-only");
   a16.mags = d_mags;
   a16.pitch = nullptr;
-  time_variant<P16, kBulkAligned, 256, 3, true, true, true, true, true>(a16, reps, "2w twreg defer mags-only");
+  time_variant<P16, kBulkAligned, 256, 3, true, true, true, 1, true>(a16, reps, "2w twreg defer mags-only");
   return 0;
 }
