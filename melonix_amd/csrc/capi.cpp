@@ -75,7 +75,7 @@ int default_frames_per_block(int N, int64_t count) {
     const int v = atoi(e);
     if (v > 0) return v;
   }
-  const int cap = N == 4096 ? 16 : (N == 16384 ? 8 : 4);
+  const int cap = N == 32768 ? 8 : 16;
   const int64_t want_blocks = 2048;
   const int64_t g = count / want_blocks;
   return (int)std::max<int64_t>(1, std::min<int64_t>(cap, g));

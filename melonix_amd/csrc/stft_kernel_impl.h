@@ -58,7 +58,7 @@ void stft_kernel(const StftArgs a0) {
   // the next frame without an extra barrier
   constexpr int kRed = (NW > 1) ? ((NW + 1) / 2) * 2 : 0;
   // TWREG == 2: the (small) pass-2 twiddle table lives in LDS, shared by the workgroup's waves
-  constexpr int kTw2 = (TWREG == 2) ? ((C::TW2 + 1) / 2) * 2 : 0;
+  constexpr int kTw2 = (TWREG >= 2) ? ((C::TW2 + 1) / 2) * 2 : 0;  // TWREG == 3: tw2 in LDS, tw3 from L2
   __shared__ __attribute__((aligned(16))) float2 lds[C::M + kRed + (OUTSEP ? C::M / 2 : 0) + kTw2];
   float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + C::M + kRed : lds);
   float2 *const ltw2 = lds + C::M + kRed + (OUTSEP ? C::M / 2 : 0);
@@ -79,8 +79,8 @@ void stft_kernel(const StftArgs a0) {
   // TWREG: this thread's pass-2/pass-3 twiddles live in registers for the whole workgroup
   cpx w2r[TWREG == 1 ? P::NB2 : 1][P::R2 - 1], w3r[P::R3 - 1];
   if constexpr (TWREG == 1) fetch_tw2<P>(t_, a.tw2, w2r);
-  if constexpr (TWREG != 0) fetch_tw3<P>(t_, a.tw3, w3r);
-  if constexpr (TWREG == 2) {
+  if constexpr (TWREG == 1 || TWREG == 2) fetch_tw3<P>(t_, a.tw3, w3r);
+  if constexpr (TWREG >= 2) {
     for (int i = t_; i < C::TW2; i += C::T) ltw2[i] = a.tw2[i];
     __syncthreads();
   }
@@ -202,7 +202,7 @@ void stft_kernel(const StftArgs a0) {
     __syncthreads();
 #endif
     if constexpr (TWREG == 1) pass2_reg<P>(v, w2r);
-    else if constexpr (TWREG == 2) pass2<P>(t, v, ltw2);
+    else if constexpr (TWREG >= 2) pass2<P>(t, v, ltw2);
     else pass2<P>(t, v, tw2);
 #ifndef MX_ABL_NOLDS
     store_t2<P>(t, v, lds);
@@ -212,11 +212,11 @@ void stft_kernel(const StftArgs a0) {
 #endif
     float mg[P::E];
     if (NW == 1 || wave0) {  // wave-uniform: only the first wavefront contains thread 0
-      if constexpr (TWREG != 0) pass3_reg<P, true>(t, v, w3r);
+      if constexpr (TWREG == 1 || TWREG == 2) pass3_reg<P, true>(t, v, w3r);
       else pass3<P, true>(t, v, tw3);
       post<P, true>(t, v, u, mg);
     } else {
-      if constexpr (TWREG != 0) pass3_reg<P, false>(t, v, w3r);
+      if constexpr (TWREG == 1 || TWREG == 2) pass3_reg<P, false>(t, v, w3r);
       else pass3<P, false>(t, v, tw3);
       post<P, false>(t, v, u, mg);
     }

@@ -28,7 +28,8 @@ struct Tune {
   // twiddles: 2 = the 7 pass-3 twiddles of this thread in registers for the whole workgroup and the
   // 1.9 KiB pass-2 table in LDS (145 VGPRs, no global twiddle loads); 1 = all 22 in registers (spills
   // at 168); 0 = both tables read from L2 every frame
-  static constexpr int TWREG = TWO_WAVE ? 2 : 0;
+  // 3 = only the pass-2 table in LDS (3.8 / 7.9 KiB at N = 16384 / 32768: still 2 / 1 workgroups per CU)
+  static constexpr int TWREG = TWO_WAVE ? 2 : 3;
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
   static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
 };
