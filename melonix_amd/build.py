@@ -26,7 +26,8 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-u
 UNITS = [
     # packed f32 VALU has no rate advantage on gfx950 (measured: 69 vs 57 T lane-ops/s) and the SLP
     # vectoriser's v_pk_* forms cost ~200 register-pairing moves per frame: keep the butterflies scalar
-    ("stft_kernels.hip", "hip", ["-fno-slp-vectorize"]),
+    # -ffp-contract=off: the core spells out every FMA, so all kernel instantiations round alike
+    ("stft_kernels.hip", "hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
     # bit-exact PCM: no FMA contraction in the resampler
     ("resynth_kernels.hip", "hip", ["-ffp-contract=off"]),
     ("colormap_kernel.hip", "hip", ["-ffp-contract=off"]),

@@ -50,9 +50,13 @@ MX_HD cpx mk(float x, float y) {
   r.y = y;
   return r;
 }
+// All fused multiply-adds are written out (fma_) and the kernels are built with -ffp-contract=off, so
+// every instantiation of these templates — and the host emulation — performs the same roundings.
+MX_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 MX_HD cpx cadd(cpx a, cpx b) { return mk(a.x + b.x, a.y + b.y); }
 MX_HD cpx csub(cpx a, cpx b) { return mk(a.x - b.x, a.y - b.y); }
-MX_HD cpx cmul(cpx a, cpx b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+MX_HD cpx cmul(cpx a, cpx b) { return mk(fma_(a.x, b.x, -(a.y * b.y)), fma_(a.x, b.y, a.y * b.x)); }
+MX_HD float cnorm2(cpx a) { return fma_(a.x, a.x, a.y * a.y); }
 MX_HD cpx cconj(cpx a) { return mk(a.x, -a.y); }
 // by-value select (a conditional on two array lvalues would select addresses and
 // push the register array into scratch)
@@ -84,7 +88,7 @@ MX_HD cpx mulw64(cpx a) {
   else if constexpr (k == 56) return mk(h * (a.x - a.y), h * (a.x + a.y));
   else {
     constexpr float c = kCos64[k], s = kSin64[k];
-    return mk(a.x * c + a.y * s, a.y * c - a.x * s);
+    return mk(fma_(a.x, c, a.y * s), fma_(a.y, c, -(a.x * s)));
   }
 }
 
@@ -94,8 +98,6 @@ MX_HD cpx mulw64(cpx a) {
 // out1 = 2*E - out0  (one FMA per component): 6 instructions for a general W instead of the 8 of
 // "t = W*O; E + t; E - t", and 6 instead of 8 for the (1 -+ i)/sqrt(2) twiddles.  Trivial twiddles
 // (1, -i, -1, i) stay plain add/sub.
-MX_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
 template <int K>
 MX_HD void bfly_w64(cpx E, cpx O, cpx &out0, cpx &out1) {  // W = exp(-2*pi*i*K/64)
   constexpr int k = ((K % 64) + 64) % 64;
@@ -263,6 +265,43 @@ MX_HD void load_frame(int t, cpx (&Y)[P::E], const float *x, const float *w) {
     x0 = (float)p; x1 = 1.0f;
 #endif
     Y[e] = mk(x0 * w0, x1 * w1);  // float product, as spec.cpp:58 (times the folded 2^-k)
+  }
+}
+
+// Direct modes, split in two so that the raw samples of the NEXT frame can be in flight while the
+// current one is transformed: load_raw issues the 64-bit sample loads, apply_window multiplies by
+// the weights (same rounded binary32 product as load_frame) once the frame is needed.
+template <class P, bool ALIGNED8>
+MX_HD void load_raw(int t, cpx (&xr)[P::E], const float *x) {
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const int p = 2 * (t + P::T * e);
+    if constexpr (ALIGNED8) {
+      xr[e] = *reinterpret_cast<const cpx *>(x + p);
+    } else {
+      const f2u xs = *reinterpret_cast<const f2u *>(x + p);
+      xr[e] = mk(xs.x, xs.y);
+    }
+  }
+}
+template <class P, int WSTEP, bool ALIGNED8>
+MX_HD void apply_window(int t, cpx (&Y)[P::E], const cpx (&xr)[P::E], const float *w) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const int p = 2 * (t + P::T * e);
+    float w0, w1;
+    if constexpr (ALIGNED8 && WSTEP == 1) {
+      const cpx ws = *reinterpret_cast<const cpx *>(w + p);
+      w0 = ws.x; w1 = ws.y;
+    } else if constexpr (WSTEP == 1) {
+      const f2u ws = *reinterpret_cast<const f2u *>(w + p);
+      w0 = ws.x; w1 = ws.y;
+    } else {
+      const f2u ws = *reinterpret_cast<const f2u *>(w - p - 1);
+      w0 = ws.y; w1 = ws.x;
+    }
+    Y[e] = mk(xr[e].x * w0, xr[e].y * w1);
   }
 }
 
@@ -568,11 +607,11 @@ struct PostSlot {
     const cpx Dm = csub(A, B);
     const cpx D = cmul(u[S], Dm);
     const cpx lo = csub(Sm, D), hi = cadd(Sm, D);
-    mg[2 * S] = fast_sqrt(lo.x * lo.x + lo.y * lo.y);
-    mg[2 * S + 1] = fast_sqrt(hi.x * hi.x + hi.y * hi.y);
+    mg[2 * S] = fast_sqrt(cnorm2(lo));
+    mg[2 * S + 1] = fast_sqrt(cnorm2(hi));
     if constexpr (S == H) {  // thread 0: bin M/2 instead of the Nyquist bin; |X[M/2]| = |Z[M/2]|
       const cpx z = v[H];
-      const float m = fast_sqrt(z.x * z.x + z.y * z.y) * 2.0f;
+      const float m = fast_sqrt(cnorm2(z)) * 2.0f;
       mg[2 * S + 1] = t0 ? m : mg[2 * S + 1];
     }
     if constexpr (S + 1 < R) PostSlot<P, S + 1>::run(t0, v, u, mg);

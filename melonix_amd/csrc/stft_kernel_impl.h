@@ -45,7 +45,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 // NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
 // and window loads are not hoisted out of the frame loop into hundreds of registers.
 template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, int TWREG = 0, bool OUTSEP = false,
-          bool DEFER = false>
+          bool DEFER = false, bool PREFETCH = false>
 __global__ __launch_bounds__(P::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void stft_kernel(const StftArgs a0) {
   const StftArgs &a = a0;
@@ -133,18 +133,39 @@ void stft_kernel(const StftArgs a0) {
       for (int i = 0; i < C::M / 4 / C::T; ++i) {
 #if defined(MX_ABL_NOGSTORE)
         asm volatile("" ::"v"(q[i]), "v"(row4));
-#elif defined(MX_STORE_PLAIN)
-        row4[C::T * i] = q[i];
-#elif defined(MX_STORE_SC)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, q[i]),
-            __builtin_amdgcn_make_buffer_rsrc((void *)(a.mags + (size_t)fr * (size_t)(N / 2)), 0, N / 2 * 4, 0x00020000),
-            (tt + C::T * i) * 16, 0, MX_STORE_SC);
 #else
         __builtin_nontemporal_store(q[i], &row4[C::T * i]);
 #endif
       }
     }
   };
+
+  // sample / weight pointers of frame f in the direct modes
+  auto frame_ptrs = [&](int64_t fr, int zo, const float *&x, const float *&w) {
+    if constexpr (MODE == kRanges) {
+      const int s = a.ranges[2 * fr], e = a.ranges[2 * fr + 1];
+      const bool outside = (e <= 0) || ((int64_t)e - N >= a.n);  // spec.cpp:50-54: all zeros
+      // the leading pad holds MX_AUDIO_PAD >= N zeros: an all-zero frame
+      x = outside ? a.audio : a.audio + MX_AUDIO_PAD + ((int64_t)e - N);
+      int64_t d0 = (int64_t)N - ((int64_t)e - (int64_t)s);
+      d0 = d0 < (int64_t)(N - 1 - kWOff) ? (int64_t)(N - 1 - kWOff) : d0;
+      d0 = d0 > (int64_t)(kWDmax + kWTail) ? (int64_t)(kWDmax + kWTail) : d0;
+      w = a.wext + kWOff + d0;
+    } else {
+      const int64_t e = (a.first_frame + fr + 1) * (int64_t)a.hop;  // end of frame h: (h+1)*hop
+      x = a.audio + MX_AUDIO_PAD + (e - N);
+      w = a.wtab + zo;
+    }
+  };
+  cpx xr[(PREFETCH && !kSlide) ? P::E : 1];  // raw samples of the next frame, in flight
+  if constexpr (PREFETCH && !kSlide) {
+    if (f0 < f1) {
+      const float *x0;
+      const float *w0;
+      frame_ptrs(f0, 0, x0, w0);
+      load_raw<P, (MODE == kBulkAligned)>(t_, xr, x0);
+    }
+  }
 
   for (int64_t f = f0; f < f1; ++f) {
     // Everything below that depends only on the thread index is frame-invariant; left alone,
@@ -169,21 +190,19 @@ void stft_kernel(const StftArgs a0) {
     } else {
       const float *x;
       const float *w;
-      if constexpr (MODE == kRanges) {
-        const int s = a.ranges[2 * f], e = a.ranges[2 * f + 1];
-        const bool outside = (e <= 0) || ((int64_t)e - N >= a.n);  // spec.cpp:50-54: all zeros
-        // the leading pad holds MX_AUDIO_PAD >= N zeros: an all-zero frame
-        x = outside ? a.audio : a.audio + MX_AUDIO_PAD + ((int64_t)e - N);
-        int64_t d0 = (int64_t)N - ((int64_t)e - (int64_t)s);
-        d0 = d0 < (int64_t)(N - 1 - kWOff) ? (int64_t)(N - 1 - kWOff) : d0;
-        d0 = d0 > (int64_t)(kWDmax + kWTail) ? (int64_t)(kWDmax + kWTail) : d0;
-        w = a.wext + kWOff + d0;
+      frame_ptrs(f, zoff, x, w);
+      if constexpr (PREFETCH) {
+        // this frame's samples were requested one frame ago; window them, then request the next frame's
+        apply_window<P, (MODE == kRanges ? -1 : 1), (MODE == kBulkAligned)>(t, Y, xr, w);
+        if (f + 1 < f1) {
+          const float *xn;
+          const float *wn;
+          frame_ptrs(f + 1, zoff, xn, wn);
+          load_raw<P, (MODE == kBulkAligned)>(t, xr, xn);
+        }
       } else {
-        const int64_t e = (a.first_frame + f + 1) * (int64_t)a.hop;  // end of frame h: (h+1)*hop
-        x = a.audio + MX_AUDIO_PAD + (e - N);
-        w = a.wtab + zoff;
+        load_frame<P, (MODE == kRanges ? -1 : 1), (MODE == kBulkAligned)>(t, Y, x, w);
       }
-      load_frame<P, (MODE == kRanges ? -1 : 1), (MODE == kBulkAligned)>(t, Y, x, w);
     }
 
     cpx v[P::E];

@@ -25,11 +25,14 @@ struct Tune {
   static constexpr bool TWO_WAVE = (P::E == 16);
   static constexpr int WPE = TWO_WAVE ? 3 : 2;
   static constexpr bool NOHOIST = true;
-  // twiddles: 2 = the 7 pass-3 twiddles of this thread in registers for the whole workgroup and the
-  // 1.9 KiB pass-2 table in LDS (145 VGPRs, no global twiddle loads); 1 = all 22 in registers (spills
-  // at 168); 0 = both tables read from L2 every frame
-  // 3 = only the pass-2 table in LDS (3.8 / 7.9 KiB at N = 16384 / 32768: still 2 / 1 workgroups per CU)
-  static constexpr int TWREG = TWO_WAVE ? 2 : 3;
+  // Twiddle placement (measured, profiles/variants_*):
+  //   2 = this thread's pass-3 twiddles in registers for the whole workgroup + the pass-2 table in LDS
+  //       (no global twiddle loads at all);
+  //   3 = only the pass-2 table in LDS (1.9 / 3.8 / 7.9 KiB), pass-3 twiddles from L2 — for the sliding
+  //       N = 16384 kernel, whose register image of the frame leaves no room for 30 more VGPRs;
+  //   (1 = all in registers: spills; 0 = both from L2 every frame.)
+  template <bool SLIDING>
+  static constexpr int twreg() { return (P::N == 16384 && SLIDING) ? 3 : 2; }
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
   static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
 };
@@ -46,17 +49,17 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
   const dim3 grid((unsigned)blocks), block(P::T);
   constexpr int W = Tune<P>::WPE;
   constexpr bool NH = Tune<P>::NOHOIST;
-  constexpr int TR = Tune<P>::TWREG;
+  constexpr int TRS = Tune<P>::template twreg<true>(), TRD = Tune<P>::template twreg<false>();
   constexpr bool OS = Tune<P>::OUTSEP, DF = Tune<P>::DEFER;
   switch (mode) {
     case kBulkAligned:
       // the headline hops slide the windowed frame through registers (one HBM read per sample)
-      if (N == 4096 && a.hop == 256) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 4096 ? 256 : 0), W, NH, true, TR, OS, DF>), grid, block, 0, s, b);
-      else if (N == 16384 && a.hop == 512) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 16384 ? 512 : 0), W, NH, true, TR, OS, DF>), grid, block, 0, s, b);
-      else hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TR, OS, DF>), grid, block, 0, s, b);
+      if (N == 4096 && a.hop == 256) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 4096 ? 256 : 0), W, NH, true, (N == 4096 ? TRS : TRD), OS, DF>), grid, block, 0, s, b);
+      else if (N == 16384 && a.hop == 512) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 16384 ? 512 : 0), W, NH, true, (N == 16384 ? TRS : TRD), OS, DF>), grid, block, 0, s, b);
+      else hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF>), grid, block, 0, s, b);
       break;
-    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TR, OS, DF>), grid, block, 0, s, b); break;
-    case kRanges: hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TR, OS, DF>), grid, block, 0, s, b); break;
+    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF>), grid, block, 0, s, b); break;
+    case kRanges: hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TRD, OS, DF>), grid, block, 0, s, b); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

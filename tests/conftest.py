@@ -59,3 +59,21 @@ def gpu_ctx(mxlib):
 def mag_tol(ref_rows):
     """max_k |g-r| <= 2e-5 * max_k r + 1e-9 per frame (fp32 LDS FFT vs the f64 path)."""
     return 2e-5 * ref_rows.max(axis=-1, keepdims=True) + 1e-9
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """tests/emu/stft_emu.cpp: the kernel's per-thread templates run thread by thread on the CPU."""
+    import ctypes as C
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "emu", "stft_emu.cpp")
+    so = os.path.join(here, "emu", "libstft_emu.so")
+    deps = [src] + [os.path.join(ROOT, "melonix_amd", "csrc", f) for f in ("stft_core.h", "stft_tables.h", "stft_consts.inc")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", src, "-o", so])
+    L = C.CDLL(so)
+    fp = C.POINTER(C.c_float)
+    L.emu_stft_frame.argtypes = [C.c_int, C.c_int, fp, C.c_long, C.c_int, C.c_int, C.c_int, fp]
+    L.emu_stft_slide.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.c_long, C.c_long, C.c_long, fp]
+    return L

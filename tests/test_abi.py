@@ -77,7 +77,7 @@ def test_resampler_isa_has_no_fma():
 def test_stft_kernels_do_not_spill():
     """Every shipped STFT kernel instantiation must be scratch-free (a silent spill cost ~7 % once)."""
     src = os.path.join(ROOT, "melonix_amd", "csrc", "stft_kernels.hip")
-    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-c", "-x", "hip", src,
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-ffp-contract=off", "-c", "-x", "hip", src,
                           "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     names = re.findall(r"Function Name: (\S+)", out.stderr)

@@ -13,20 +13,6 @@ from conftest import SR, accum_sweep, mag_tol, noisy
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def emu():
-    src = os.path.join(HERE, "emu", "stft_emu.cpp")
-    so = os.path.join(HERE, "emu", "libstft_emu.so")
-    deps = [src] + [os.path.join(HERE, "..", "melonix_amd", "csrc", f) for f in ("stft_core.h", "stft_tables.h", "stft_consts.inc")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", src, "-o", so])
-    L = C.CDLL(so)
-    fp = C.POINTER(C.c_float)
-    L.emu_stft_frame.argtypes = [C.c_int, C.c_int, fp, C.c_long, C.c_int, C.c_int, C.c_int, fp]
-    L.emu_stft_slide.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.c_long, C.c_long, C.c_long, fp]
-    return L
-
-
 RANGES = [(48000, 48375), (0, 256), (-500, -100), (239744, 240000), (479900, 480300), (100000, 100001),
           (5000, 4000), (1000, 60000)]
 

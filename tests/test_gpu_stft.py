@@ -167,3 +167,21 @@ def test_fused_colormap(gpu_ctx, oracle, N):
     seg = np.stack([oracle.colormap(m, 2.0 ** 15) for m in mags])
     assert (seg[..., 1] > 0).any() and (seg[..., 2] > 0).any()  # the test really reaches segments 2 and 3
     a.free()
+
+
+@pytest.mark.parametrize("N,E", [(4096, 16), (16384, 32), (32768, 32)])
+def test_device_equals_cpu_emulation(gpu_ctx, emu, N, E):
+    """The kernels spell out every FMA and are built with -ffp-contract=off, so the CPU emulation of the
+    same templates (tests/emu) reproduces the device arithmetic; only v_sqrt_f32 (1 ulp) vs sqrtf differs."""
+    import ctypes as C
+    w = noisy(accum_sweep(3 * SR))
+    fp = C.POINTER(C.c_float)
+    ranges = [(48000, 48375), (0, 256), (100000, 100001), (5000, 4000), (1000, 60000)]
+    a = gpu_ctx.upload(w)
+    mags, _ = gpu_ctx.stft_ranges(a, N, ranges)
+    for i, (s_, e_) in enumerate(ranges):
+        out = np.empty(N // 2, np.float32)
+        assert emu.emu_stft_frame(N, E, w.ctypes.data_as(fp), len(w), s_, e_, 0, out.ctypes.data_as(fp)) == 0
+        ulp = np.spacing(np.maximum(np.abs(out), np.float32(1e-30)))
+        assert (np.abs(mags[i] - out) <= 2 * ulp).all(), float((np.abs(mags[i] - out) / ulp).max())
+    a.free()

@@ -22,17 +22,17 @@ using namespace mx;
     }                                                                          \
   } while (0)
 
-template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, int TR = 0, bool OS = false, bool DF = false>
+template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, int TR = 0, bool OS = false, bool DF = false, bool PF = false>
 float time_variant(const StftArgs &a, int reps, const char *name) {
   constexpr int N = C::N;
   const int64_t blocks = (a.count + a.frames_per_block - 1) / a.frames_per_block;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF, PF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF, PF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -210,7 +210,8 @@ int main(int argc, char **argv) {
     time_variant<P16, kBulkAligned, 256, 3, true, true, true, 1, true>(a16, reps, "2 waves/frame twreg defer wpe3");
   }
   a16.frames_per_block = 16;
-  time_variant<P16, kBulkAligned, 0, 3, true, true, 1, true>(a16, reps, "2 waves/frame direct  twreg outsep");
+  time_variant<P16, kBulkAligned, 0, 3, true, true, 2, true, true>(a16, reps, "2w direct tw2lds defer");
+  time_variant<P16, kBulkAligned, 0, 3, true, true, 2, true, true, true>(a16, reps, "2w direct tw2lds defer prefetch");
   a16.mags = nullptr;
   time_variant<P16, kBulkAligned, 256, 3, true, true, true, 1, true>(a16, reps, "2w twreg defer pitch-only");
   a16.mags = d_mags;

@@ -22,17 +22,17 @@ using namespace mx;
     }                                                                          \
   } while (0)
 
-template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, int TR = 0, bool OS = false, bool DF = false>
+template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, int TR = 0, bool OS = false, bool DF = false, bool PF = false>
 float time_variant(const StftArgs &a, int reps, const char *name) {
   constexpr int N = C::N;
   const int64_t blocks = (a.count + a.frames_per_block - 1) / a.frames_per_block;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF, PF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF, PF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -186,6 +186,8 @@ int main(int argc, char **argv) {
     a.frames_per_block = g;
     time_variant<PB, kBulkAligned, SH, 2, true, true, 0>(a, reps, "tw global");
     time_variant<PB, kBulkAligned, SH, 2, true, true, 3>(a, reps, "tw2 in LDS");
+    time_variant<PB, kBulkAligned, SH, 2, true, true, 2>(a, reps, "tw2 LDS + tw3 regs");
+    time_variant<PB, kBulkAligned, SH, 2, true, true, 3, false, false, true>(a, reps, "tw2 LDS + prefetch");
   }
   return 0;
 }
