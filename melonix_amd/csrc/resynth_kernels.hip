@@ -11,9 +11,12 @@
 //
 // Parallelisation: the export loop is serial only in its scalar cursor
 // (host_logic.cpp: build_schedule).  Given the schedule, every output sample
-// is independent: one workgroup per step stages nothing but reads the step's
-// grain (contiguous source samples, L2/HBM-coalesced) and writes a contiguous
-// run of the PCM stream at out_offset.
+// is independent: one workgroup per step.  resynth_kernel_v stages the step's
+// grain in LDS with coalesced 16-byte loads (each source sample leaves HBM/L2
+// once), gathers the two interpolation taps from LDS (one ds_read2_b32), and
+// writes the PCM run as aligned 16-byte vectors (8 outputs per thread), with
+// scalar head/tail elements up to the first/after the last 8-aligned output.
+// resynth_kernel (scalar) remains for output pointers that are not 16-byte aligned.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -44,6 +47,89 @@ __global__ __launch_bounds__(kResynthThreads) void resynth_kernel(const ResynthA
     const float v = (1.f - f) * a0 + f * a1;  // app.cpp:340-341, no contraction
     if (of) of[i] = v;
     if (oi) oi[i] = (int16_t)((double)v * 32767.);  // app.cpp:1212: double multiply, truncation
+  }
+}
+
+constexpr int kMaxGrain = 2304;  // good grains are 751..2249 samples (app.cpp:164-166); longer ones take the scalar kernel
+
+__device__ __forceinline__ float lerp_tap(const float *lg, int i, float rate) {
+  const float x = (float)i * rate;       // app.cpp:336
+  const float ip = __builtin_truncf(x);  // std::modf
+  const float f = x - ip;
+  const int idx = (int)ip;
+  return (1.f - f) * lg[idx] + f * lg[idx + 1];  // lg[L] holds nextGrainFirstSample (app.cpp:340-341)
+}
+
+__global__ __launch_bounds__(kResynthThreads) void resynth_kernel_v(const ResynthArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kMaxGrain + 8];
+  const mx_step st = a.steps[blockIdx.x];
+  const int L = st.grain_len, sz = st.sz, tid = threadIdx.x;
+  if (L > kMaxGrain) return;  // handled by the scalar launch (wave-uniform: whole block exits)
+  const float *g = a.audio + MX_AUDIO_PAD + st.grain_start;
+  // stage [g - shift, g + L] with aligned float4 loads (the padded image makes g - 3 readable)
+  const int shift = (int)((reinterpret_cast<uintptr_t>(g) >> 2) & 3);
+  const float4 *ga = reinterpret_cast<const float4 *>(g - shift);
+  float4 *l4 = reinterpret_cast<float4 *>(lds);
+  for (int j = tid; j < (L + shift + 4) / 4; j += kResynthThreads) l4[j] = ga[j];
+  __syncthreads();
+  float *lg = lds + shift;
+  if (tid == 0) lg[L] = st.next_first;  // may differ from wav[grain_start + L] when grains repeat or skip
+  __syncthreads();
+
+  float *of = a.pcm_f32 ? a.pcm_f32 + st.out_offset : nullptr;
+  int16_t *oi = a.pcm_i16 ? a.pcm_i16 + st.out_offset : nullptr;
+  const float rate = st.rate;
+  // outputs [head, head + 8*nv) are 8-aligned in the PCM stream
+  const int head = (int)((8 - (st.out_offset & 7)) & 7) < sz ? (int)((8 - (st.out_offset & 7)) & 7) : sz;
+  const int nv = (sz - head) / 8;
+  for (int q = tid; q < nv; q += kResynthThreads) {
+    const int i0 = head + 8 * q;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = lerp_tap(lg, i0 + k, rate);
+    if (of) {
+      float4 *o4 = reinterpret_cast<float4 *>(of + i0);
+      o4[0] = make_float4(v[0], v[1], v[2], v[3]);
+      o4[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (oi) {
+      unsigned w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned lo = (unsigned)(unsigned short)(int16_t)((double)v[2 * k] * 32767.);  // app.cpp:1212
+        const unsigned hi = (unsigned)(unsigned short)(int16_t)((double)v[2 * k + 1] * 32767.);
+        w[k] = lo | (hi << 16);
+      }
+      *reinterpret_cast<uint4 *>(oi + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  // scalar head and tail
+  const int tail0 = head + 8 * nv;
+  for (int i = tid; i < head + (sz - tail0); i += kResynthThreads) {
+    const int ii = i < head ? i : tail0 + (i - head);
+    const float v = lerp_tap(lg, ii, rate);
+    if (of) of[ii] = v;
+    if (oi) oi[ii] = (int16_t)((double)v * 32767.);
+  }
+}
+
+// scalar kernel restricted to the steps the vector kernel skips (grains longer than kMaxGrain)
+__global__ __launch_bounds__(kResynthThreads) void resynth_kernel_long(const ResynthArgs a) {
+  const mx_step st = a.steps[blockIdx.x];
+  if (st.grain_len <= kMaxGrain) return;
+  const float *g = a.audio + MX_AUDIO_PAD + st.grain_start;
+  const int L = st.grain_len;
+  float *of = a.pcm_f32 ? a.pcm_f32 + st.out_offset : nullptr;
+  int16_t *oi = a.pcm_i16 ? a.pcm_i16 + st.out_offset : nullptr;
+  for (int i = threadIdx.x; i < st.sz; i += kResynthThreads) {
+    const float x = (float)i * st.rate;
+    const float ip = __builtin_truncf(x);
+    const float f = x - ip;
+    const int idx = (int)ip;
+    const float a1 = (idx + 1 < L) ? g[idx + 1] : st.next_first;
+    const float v = (1.f - f) * g[idx] + f * a1;
+    if (of) of[i] = v;
+    if (oi) oi[i] = (int16_t)((double)v * 32767.);
   }
 }
 
@@ -82,7 +168,14 @@ hipError_t launch_resynth(const ResynthArgs &a, hipStream_t s) {
   // The terminating process() call's 1500 zeros (app.cpp:303-309) are not a step:
   // capi.cpp clears the tail [sum(sz), nsamples) with hipMemsetAsync before this launch.
   if (a.nsteps > 0) {
-    hipLaunchKernelGGL(resynth_kernel, dim3((unsigned)a.nsteps), dim3(kResynthThreads), 0, s, a);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.pcm_f32) | reinterpret_cast<uintptr_t>(a.pcm_i16) |
+                           reinterpret_cast<uintptr_t>(a.audio)) & 15) == 0;
+    if (aligned) {
+      hipLaunchKernelGGL(resynth_kernel_v, dim3((unsigned)a.nsteps), dim3(kResynthThreads), 0, s, a);
+      if (a.has_long_grains) hipLaunchKernelGGL(resynth_kernel_long, dim3((unsigned)a.nsteps), dim3(kResynthThreads), 0, s, a);
+    } else {
+      hipLaunchKernelGGL(resynth_kernel, dim3((unsigned)a.nsteps), dim3(kResynthThreads), 0, s, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

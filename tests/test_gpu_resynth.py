@@ -90,3 +90,31 @@ def test_minmax_pyramid_bit_exact(gpu_ctx, oracle, mxlib):
         for s_, e_ in qs:
             assert mxlib.minmax_range(w, lv, s_, e_) == oracle.minmax_range(w, ref, s_, e_)
         a.free()
+
+
+def test_resynth_long_and_fallback_grains_bit_exact(gpu_ctx, oracle, mxlib):
+    """Grains longer than the LDS-staged kernel's capacity (the look-around-3 fallback of app.cpp:198-228
+    after long stretches without a clean zero crossing) take the scalar pass; repeated/skipped grains make
+    nextGrainFirstSample differ from the sample after the grain.  All bit-exact vs the oracle."""
+    rng = np.random.default_rng(11)
+    n = 6 * SR
+    t = np.arange(n) / SR
+    w = (0.3 * np.sin(2 * np.pi * 220 * t)).astype(np.float32)
+    w[SR:2 * SR] = np.abs(w[SR:2 * SR]) + 0.01          # one second without any negative sample
+    w[3 * SR:3 * SR + 9000] = 0.2                         # a flat positive stretch
+    w[4 * SR:5 * SR] += (0.3 * rng.standard_normal(SR)).astype(np.float32)  # noisy: short sign runs
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    rs, rl = oracle.grains(w)
+    assert np.array_equal(s, rs) and np.array_equal(l, rl)
+    assert l.max() > 2304 and l.min() < 2304
+    for mk in ([], [(1, 0, 0, 5.0), (n - 1, 0, 0, 5.0)], [(1, 0, 0, -7.0), (n // 2, 0, 0.4, 9.0), (n - 1, 0, -0.1, 0.0)]):
+        st, total = mxlib.schedule_build(w, SR, s, l, mk)
+        f32, i16 = gpu_ctx.resynth(a, st, total)
+        _, opcm = oracle.export_run(w, SR, mk)
+        assert total == len(opcm)
+        assert np.array_equal(f32.view(np.uint32), opcm.view(np.uint32))
+        assert np.array_equal(i16, oracle.pcm_to_i16(opcm))
+        only16 = gpu_ctx.resynth(a, st, total, want_f32=False)[1]
+        assert np.array_equal(only16, i16)
+    a.free()
