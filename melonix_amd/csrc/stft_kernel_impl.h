@@ -214,13 +214,26 @@ void stft_kernel(const StftArgs a0) {
     }
     store_t1<P>(t, v, lds);
     __syncthreads();
-    load_t1<P>(t, v, lds);
+#ifdef MX_LDS_ASM
+    constexpr bool kTw2Batch = (TWREG >= 2) && (P::NB2 == 1);
+#else
+    constexpr bool kTw2Batch = false;
+#endif
+    cpx w2b[1][P::R2 - 1];
+    if constexpr (kTw2Batch) {
+#ifdef MX_LDS_ASM
+      load_t1_tw2<P>(t, v, lds, ltw2, w2b);
+#endif
+    } else {
+      load_t1<P>(t, v, lds);
+    }
     if constexpr (DEFER) {
       if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
     }
     __syncthreads();
 #endif
     if constexpr (TWREG == 1) pass2_reg<P>(v, w2r);
+    else if constexpr (kTw2Batch) pass2_reg<P>(v, w2b);
     else if constexpr (TWREG >= 2) pass2<P>(t, v, ltw2);
     else pass2<P>(t, v, tw2);
 #ifndef MX_ABL_NOLDS
