@@ -68,14 +68,14 @@ struct mx_audio {
 namespace {
 
 // Consecutive frames one workgroup walks.  Long runs amortise the per-workgroup setup (full window
-// load, twiddle fetch) over 16 frames; short batches (a screen of 1280 columns) use fewer frames per
+// load, twiddle fetch) over 16-32 frames; short batches (a screen of 1280 columns) use fewer frames per
 // workgroup so that every CU still gets work (>= ~8 workgroups per CU when there are enough frames).
 int default_frames_per_block(int N, int64_t count) {
   if (const char *e = getenv("MELONIX_FRAMES_PER_BLOCK")) {
     const int v = atoi(e);
     if (v > 0) return v;
   }
-  const int cap = N == 32768 ? 8 : 16;
+  const int cap = N == 32768 ? 8 : (N == 4096 ? 32 : 16);  // (4096: 32 measured 1% over 16; 48 no better)
   const int64_t want_blocks = 2048;
   const int64_t g = count / want_blocks;
   return (int)std::max<int64_t>(1, std::min<int64_t>(cap, g));

@@ -269,6 +269,48 @@ MX_HD void load_frame(int t, cpx (&Y)[P::E], const float *x, const float *w) {
   }
 }
 
+// Bulk direct modes: the weights of a thread's points form a geometric sequence
+// (w(p + 2T) = w(p) * exp(2.5e-4 * 2T) until the flat top d <= 0, where w = sc), so only the
+// samples are loaded: wb[p], p < 2T, is the UNCLAMPED weight sc*exp(-2.5e-4f*(N-hop-p)) of the
+// thread's first pair (stft_tables.h make_wtab, second section) and the rest are one multiply and
+// one min each.  This halves the L1 traffic of a frame (the weight table was as large as the
+// frame).  The weights then differ from expf(-2.5e-4f*d) by <= 2 ulp — like the sliding kernel's
+// decay chain, far inside the magnitude tolerance; the ranges mode (the reference's per-column
+// calls) keeps the exact table.
+template <int T>
+MX_HD constexpr float win_grow(int e) {
+  return T == 64 ? kWinGrow64[e] : T == 128 ? kWinGrow128[e] : T == 256 ? kWinGrow256[e] : kWinGrow512[e];
+}
+template <class P, bool ALIGNED8>
+MX_HD void load_frame_geo(int t, cpx (&Y)[P::E], const float *x, const float *wb) {
+#pragma clang fp contract(off)
+  static_assert(P::T == 64 || P::T == 128 || P::T == 256 || P::T == 512, "growth table per T");
+  static_assert(P::E <= 32, "growth table length");
+  constexpr float sc = 0.5f / (float)P::N;
+  const cpx a0 = *reinterpret_cast<const cpx *>(wb + 2 * t);
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const int p = 2 * (t + P::T * e);
+    float x0, x1;
+    if constexpr (ALIGNED8) {
+      const cpx xs = *reinterpret_cast<const cpx *>(x + p);
+      x0 = xs.x; x1 = xs.y;
+    } else {
+      const f2u xs = *reinterpret_cast<const f2u *>(x + p);
+      x0 = xs.x; x1 = xs.y;
+    }
+    constexpr float one = 1.0f;
+    const float g = e == 0 ? one : win_grow<P::T>(e);
+    float w0 = a0.x * g, w1 = a0.y * g;
+    w0 = w0 < sc ? w0 : sc;
+    w1 = w1 < sc ? w1 : sc;
+#ifdef MX_ABL_NOX
+    x0 = (float)p; x1 = 1.0f;
+#endif
+    Y[e] = mk(x0 * w0, x1 * w1);
+  }
+}
+
 // Direct modes, split in two so that the raw samples of the NEXT frame can be in flight while the
 // current one is transformed: load_raw issues the 64-bit sample loads, apply_window multiplies by
 // the weights (same rounded binary32 product as load_frame) once the frame is needed.

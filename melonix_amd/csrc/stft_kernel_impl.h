@@ -8,6 +8,13 @@
 #include "stft_core.h"
 #include "stft_tables.h"
 
+// (tuning ablation: MX_ABL_NOBAR drops the workgroup barriers — results are then garbage)
+#ifdef MX_ABL_NOBAR
+#define MX_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define MX_BARRIER() __syncthreads()
+#endif
+
 namespace mx {
 
 // Wavefront reductions through the DPP crossbar (no LDS round trips, unlike __shfl_xor which lowers
@@ -45,7 +52,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 // NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
 // and window loads are not hoisted out of the frame loop into hundreds of registers.
 template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, int TWREG = 0, bool OUTSEP = false,
-          bool DEFER = false, bool PREFETCH = false>
+          bool DEFER = false, bool PREFETCH = false, bool EARLYBAR = false>
 __global__ __launch_bounds__(P::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void stft_kernel(const StftArgs a0) {
   const StftArgs &a = a0;
@@ -59,6 +66,10 @@ void stft_kernel(const StftArgs a0) {
   constexpr int kRed = (NW > 1) ? ((NW + 1) / 2) * 2 : 0;
   // TWREG == 2: the (small) pass-2 twiddle table lives in LDS, shared by the workgroup's waves
   constexpr int kTw2 = (TWREG >= 2) ? ((C::TW2 + 1) / 2) * 2 : 0;  // TWREG == 3: tw2 in LDS, tw3 from L2
+  // EARLYBAR (needs DEFER): the barrier that frees the image for the next frame sits right after
+  // the T2 read instead of in front of the next T1 scatter, so that scatter can be issued while
+  // pass 1 is still computing (same number of barriers per frame).
+  static_assert(!EARLYBAR || DEFER, "the early barrier is written for the deferred-output schedule");
   __shared__ __attribute__((aligned(16))) float2 lds[C::M + kRed + (OUTSEP ? C::M / 2 : 0) + kTw2];
   float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + C::M + kRed : lds);
   float2 *const ltw2 = lds + C::M + kRed + (OUTSEP ? C::M / 2 : 0);
@@ -82,7 +93,7 @@ void stft_kernel(const StftArgs a0) {
   if constexpr (TWREG == 1 || TWREG == 2) fetch_tw3<P>(t_, a.tw3, w3r);
   if constexpr (TWREG >= 2) {
     for (int i = t_; i < C::TW2; i += C::T) ltw2[i] = a.tw2[i];
-    __syncthreads();
+    MX_BARRIER();
   }
 
   // XCD-aware block -> frame-range map: the dispatcher places block b on XCD b % 8 and each
@@ -122,7 +133,11 @@ void stft_kernel(const StftArgs a0) {
     }
   };
   auto flush_row = [&](int64_t fr, int tt) {  // after a barrier that follows the scatter of frame fr
+#ifdef MX_EXP_DIRECTOUT
+    if (false) {
+#else
     if (a.mags) {
+#endif
       using f32x4 = float __attribute__((ext_vector_type(4)));
       const f32x4 *l4 = reinterpret_cast<const f32x4 *>(lout) + tt;
       f32x4 *row4 = reinterpret_cast<f32x4 *>(a.mags + (size_t)fr * (size_t)(N / 2)) + tt;
@@ -200,26 +215,31 @@ void stft_kernel(const StftArgs a0) {
           frame_ptrs(f + 1, zoff, xn, wn);
           load_raw<P, (MODE == kBulkAligned)>(t, xr, xn);
         }
+      } else if constexpr (MODE == kRanges) {
+        load_frame<P, -1, false>(t, Y, x, w);  // exact d-indexed weights (per-column calls)
       } else {
-        load_frame<P, (MODE == kRanges ? -1 : 1), (MODE == kBulkAligned)>(t, Y, x, w);
+        load_frame_geo<P, (MODE == kBulkAligned)>(t, Y, x, a.wtab + N + zoff);  // samples only
       }
     }
 
     cpx v[P::E];
     pass1<P>(Y, v);
-#ifndef MX_ABL_NOLDS
-    if constexpr (DEFER) {
-      __syncthreads();  // every wave is past load_t2 / scatter / red[] of the previous frame
-      if (f > f0) flush_pitch(f - 1, t);
-    }
-    store_t1<P>(t, v, lds);
-    __syncthreads();
-#ifdef MX_LDS_ASM
-    constexpr bool kTw2Batch = (TWREG >= 2) && (P::NB2 == 1);
+#if defined(MX_LDS_ASM) && !defined(MX_ABL_NOLDS)
+    constexpr bool kTw2Batch = (TWREG >= 2) && (P::NB2 == 1);  // twiddles ride with the T1 read
 #else
     constexpr bool kTw2Batch = false;
 #endif
     cpx w2b[1][P::R2 - 1];
+#ifndef MX_ABL_NOLDS
+    if constexpr (DEFER && !EARLYBAR) {
+      MX_BARRIER();  // every wave is past load_t2 / scatter / red[] of the previous frame
+      if (f > f0) flush_pitch(f - 1, t);
+    }
+    store_t1<P>(t, v, lds);
+    MX_BARRIER();
+    if constexpr (EARLYBAR) {
+      if (f > f0) flush_pitch(f - 1, t);
+    }
     if constexpr (kTw2Batch) {
 #ifdef MX_LDS_ASM
       load_t1_tw2<P>(t, v, lds, ltw2, w2b);
@@ -230,7 +250,7 @@ void stft_kernel(const StftArgs a0) {
     if constexpr (DEFER) {
       if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
     }
-    __syncthreads();
+    MX_BARRIER();
 #endif
     if constexpr (TWREG == 1) pass2_reg<P>(v, w2r);
     else if constexpr (kTw2Batch) pass2_reg<P>(v, w2b);
@@ -238,9 +258,9 @@ void stft_kernel(const StftArgs a0) {
     else pass2<P>(t, v, tw2);
 #ifndef MX_ABL_NOLDS
     store_t2<P>(t, v, lds);
-    __syncthreads();
+    MX_BARRIER();
     load_t2<P>(t, v, lds);
-    if constexpr (!OUTSEP) __syncthreads();  // image free: the magnitude scatter below reuses it
+    if constexpr (!OUTSEP || EARLYBAR) MX_BARRIER();  // image free (for the magnitude scatter / the next T1 scatter)
 #endif
     float mg[P::E];
     if (NW == 1 || wave0) {  // wave-uniform: only the first wavefront contains thread 0
@@ -286,8 +306,25 @@ void stft_kernel(const StftArgs a0) {
     // consecutive bins, conflict-free), then every lane owns 4 consecutive bins and the row
     // leaves as global_store_dwordx4, 1 KiB contiguous per wavefront instruction, instead of E
     // dword stores with one stray element each (thread 0's self-paired bins).
+#ifdef MX_EXP_DIRECTOUT
+    if (a.mags) {  // experiment: E dword stores per lane straight to the row, no LDS transposition
+      float *row = a.mags + (size_t)f * (size_t)(N / 2);
+      float *plo = row + out_lo, *phi = row + out_hi;
+      float *mlo = row + (C::M - out_lo), *mhi = row + (C::M - out_hi);
+#pragma unroll
+      for (int s = 0; s < C::R3; ++s) {
+        constexpr int H = C::R3 / 2;
+        __builtin_nontemporal_store(mg[2 * s], &(s < H ? plo : phi)[C::NS3 * s]);
+        if (s == H) __builtin_nontemporal_store(mg[2 * s + 1], (t == 0 ? row + C::M / 2 : mhi - C::NS3 * H));
+        else __builtin_nontemporal_store(mg[2 * s + 1], &(s < H ? mlo : mhi)[-C::NS3 * s]);
+      }
+    }
+    if (false) {
+      float *plo = lout + out_lo, *phi = lout + out_hi;
+#else
     if (a.mags) {
       float *plo = lout + out_lo, *phi = lout + out_hi;
+#endif
       float *mlo = lout + (C::M - out_lo), *mhi = lout + (C::M - out_hi);
 #pragma unroll
       for (int s = 0; s < C::R3; ++s) {
@@ -299,11 +336,11 @@ void stft_kernel(const StftArgs a0) {
     }
     if constexpr (!DEFER) {
       if (a.mags) {
-        __syncthreads();  // (also: every wave is past load_t2, so the image may be refilled)
+        MX_BARRIER();  // (also: every wave is past load_t2, so the image may be refilled)
         flush_row(f, t);
-        if constexpr (!OUTSEP) __syncthreads();  // image free again
+        if constexpr (!OUTSEP) MX_BARRIER();  // image free again
       } else {
-        if constexpr (NW > 1 || !OUTSEP) __syncthreads();
+        if constexpr (NW > 1 || !OUTSEP) MX_BARRIER();
       }
       if constexpr (NW > 1) {
         flush_pitch(f, t);  // red[] is rewritten only after the next frame's T1/T2 barriers
@@ -317,7 +354,7 @@ void stft_kernel(const StftArgs a0) {
   }
   if constexpr (DEFER) {
     if (f0 < f1) {  // the last frame of this workgroup
-      __syncthreads();
+      MX_BARRIER();
       flush_pitch(f1 - 1, t_);
       flush_row(f1 - 1, t_);
     }

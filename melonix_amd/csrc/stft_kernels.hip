@@ -35,6 +35,8 @@ struct Tune {
   static constexpr int twreg() { return (P::N == 16384 && SLIDING) ? 3 : 2; }
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
   static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
+  // with DEFER: free the image right after the T2 read, so the next T1 scatter can start under pass 1 (+1%)
+  static constexpr bool EARLYBAR = DEFER;
 };
 
 template <class P>
@@ -50,16 +52,16 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
   constexpr int W = Tune<P>::WPE;
   constexpr bool NH = Tune<P>::NOHOIST;
   constexpr int TRS = Tune<P>::template twreg<true>(), TRD = Tune<P>::template twreg<false>();
-  constexpr bool OS = Tune<P>::OUTSEP, DF = Tune<P>::DEFER;
+  constexpr bool OS = Tune<P>::OUTSEP, DF = Tune<P>::DEFER, EB = Tune<P>::EARLYBAR;
   switch (mode) {
     case kBulkAligned:
       // the headline hops slide the windowed frame through registers (one HBM read per sample)
-      if (N == 4096 && a.hop == 256) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 4096 ? 256 : 0), W, NH, true, (N == 4096 ? TRS : TRD), OS, DF>), grid, block, 0, s, b);
-      else if (N == 16384 && a.hop == 512) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 16384 ? 512 : 0), W, NH, true, (N == 16384 ? TRS : TRD), OS, DF>), grid, block, 0, s, b);
-      else hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF>), grid, block, 0, s, b);
+      if (N == 4096 && a.hop == 256) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 4096 ? 256 : 0), W, NH, true, (N == 4096 ? TRS : TRD), OS, DF, false, EB>), grid, block, 0, s, b);
+      else if (N == 16384 && a.hop == 512) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 16384 ? 512 : 0), W, NH, true, (N == 16384 ? TRS : TRD), OS, DF, false, EB>), grid, block, 0, s, b);
+      else hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b);
       break;
-    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF>), grid, block, 0, s, b); break;
-    case kRanges: hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TRD, OS, DF>), grid, block, 0, s, b); break;
+    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b); break;
+    case kRanges: hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -84,13 +84,22 @@ inline float fold_scale(int N) { return 0.5f / (float)N; }
 inline float hop_decay(int hop) { return (float)exp(-2.5e-4 * (double)hop); }
 
 // Bulk mode (uniform hop): weight of frame position p is that of d = N-hop-p.
+// Section 1, w[0..N): the exact weights (sliding kernels' first frame, slide_edge).
+// Section 2, w[N..N+kWBase): the UNCLAMPED weights sc*exp(-2.5e-4f*d) of positions p < kWBase
+// (no flat top: for d <= 0 they exceed sc) — the per-thread seed of load_frame_geo.
+constexpr int kWBase = 1024;  // 2 * the largest T
 inline std::vector<float> make_wtab(int N, int hop, const std::vector<float> &wext) {
-  std::vector<float> w((size_t)N);
+  std::vector<float> w((size_t)N + kWBase);
   for (int p = 0; p < N; ++p) {
     long long d = (long long)N - hop - p;
     if (d < -kWOff) d = -kWOff;
     if (d > kWDmax) d = kWDmax;
     w[(size_t)p] = wext[(size_t)(d + kWOff)];
+  }
+  const double sc = (double)wext[0];  // the folded output scale (weight of d <= 0)
+  for (int p = 0; p < kWBase; ++p) {
+    const double d = (double)N - (double)hop - (double)p;
+    w[(size_t)N + p] = (float)(sc * exp(-(double)2.5e-4f * d));  // 0 once it underflows (huge d)
   }
   return w;
 }

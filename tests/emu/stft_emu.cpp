@@ -54,12 +54,17 @@ void emu_from_state(std::vector<cpx> &Yall, float *mags, std::vector<int> *colli
   }
 }
 
+// WSTEP = -1: ranges mode (exact d-indexed weights); WSTEP = +1: bulk mode, whose weights the
+// kernel derives from a per-thread seed (load_frame_geo; w then points at the table's 2nd section)
 template <class C, int WSTEP>
 void emu_frame(const float *x, const float *w, float *mags, std::vector<int> *collisions) {
   constexpr int E = C::E;
   std::vector<cpx> Yall((size_t)C::T * E);
-  for (int t = 0; t < C::T; ++t)
-    load_frame<C, WSTEP, false>(t, *reinterpret_cast<cpx(*)[E]>(&Yall[(size_t)t * E]), x, w);
+  for (int t = 0; t < C::T; ++t) {
+    auto &Y = *reinterpret_cast<cpx(*)[E]>(&Yall[(size_t)t * E]);
+    if constexpr (WSTEP == 1) load_frame_geo<C, false>(t, Y, x, w);
+    else load_frame<C, WSTEP, false>(t, Y, x, w);
+  }
   emu_from_state<C>(Yall, mags, collisions);
 }
 
@@ -113,7 +118,7 @@ int run(const float *wav, long n, int start, int end, int hop_mode, float *mags)
   std::vector<int> coll;
   if (hop_mode) {
     const std::vector<float> wtab = make_wtab(N, end - start, wext);
-    emu_frame<C, 1>(x, wtab.data(), mags, &coll);
+    emu_frame<C, 1>(x, wtab.data() + N, mags, &coll);
   } else {
     long D0 = (long)N - ((long)end - (long)start);
     D0 = std::max<long>(D0, (long)N - 1 - kWOff);

@@ -22,17 +22,17 @@ using namespace mx;
     }                                                                          \
   } while (0)
 
-template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, int TR = 0, bool OS = false, bool DF = false, bool PF = false>
+template <class C, int MODE, int HOP, int WPE, bool NH, bool XM = true, int TR = 0, bool OS = false, bool DF = false, bool PF = false, bool DU = false>
 float time_variant(const StftArgs &a, int reps, const char *name) {
   constexpr int N = C::N;
   const int64_t blocks = (a.count + a.frames_per_block - 1) / a.frames_per_block;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF, PF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF, PF, DU>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF, PF>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stft_kernel<C, MODE, HOP, WPE, NH, XM, TR, OS, DF, PF, DU>), dim3((unsigned)blocks), dim3(C::T), 0, 0, a);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -40,8 +40,25 @@ float time_variant(const StftArgs &a, int reps, const char *name) {
   ms /= reps;
   const double fps = a.count / (ms * 1e-3);
   const double balg = 4.0 * a.hop + (a.mags ? 4.0 * (N / 2) : 0.0) + 8.0;
-  printf("%-30s E=%2d N=%5d G=%3d %8.3f ms  %8.2f Mframes/s  %7.1f GB/s alg (%.1f%% of 8 TB/s)\n", name, C::E, N,
-         a.frames_per_block, ms, fps / 1e6, fps * balg / 1e9, fps * balg / 8e12 * 100);
+  // fingerprint of the outputs (sampled rows + the whole pitch track) so variants can be compared
+  uint64_t fp = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t nb) { const unsigned char *c = (const unsigned char *)p; for (size_t i = 0; i < nb; ++i) { fp ^= c[i]; fp *= 1099511628211ull; } };
+  if (a.mags) {
+    std::vector<float> row(N / 2);
+    for (int64_t f : {(int64_t)0, (int64_t)1, (int64_t)17, a.count / 3, a.count / 2 + 5, a.count - 2, a.count - 1}) {
+      CK(hipMemcpy(row.data(), a.mags + (size_t)f * (N / 2), (N / 2) * 4, hipMemcpyDeviceToHost));
+      mix(row.data(), (N / 2) * 4);
+    }
+  }
+  if (a.pitch) {
+    std::vector<mx_pitch> pt((size_t)a.count);
+    CK(hipMemcpy(pt.data(), a.pitch, pt.size() * sizeof(mx_pitch), hipMemcpyDeviceToHost));
+    for (auto &q : pt) { mix(&q.bin, 4); mix(&q.mag, 4); }
+  }
+  printf("%-30s E=%2d N=%5d G=%3d %8.3f ms  %8.2f Mframes/s  %7.1f GB/s alg (%.1f%% of 8 TB/s) fp=%016llx\n", name, C::E, N,
+         a.frames_per_block, ms, fps / 1e6, fps * balg / 1e9, fps * balg / 8e12 * 100, (unsigned long long)fp);
+  if (a.mags) CK(hipMemset(a.mags, 0xff, (size_t)a.count * (N / 2) * 4));
+  if (a.pitch) CK(hipMemset(a.pitch, 0xff, (size_t)a.count * sizeof(mx_pitch)));
   fflush(stdout);
   return ms;
 }
@@ -183,6 +200,7 @@ int main(int argc, char **argv) {
   float2 *tw2_16 = up(make_tw2<P16>()), *tw3_16 = up(make_tw3<P16>()), *ub_16 = up(make_ubase<P16>());
   (void)d_tw2; (void)d_tw3; (void)d_ub;
 
+  if (argc > 2 && atoi(argv[2])) {
   run_valu<0>("v_add_f32", d_out);
   run_valu<1>("v_pk_add_f32", d_out);
   run_valu<2>("v_fma_f32", d_out);
@@ -190,6 +208,7 @@ int main(int argc, char **argv) {
   run_lds<0>("lds write b64", d_out);
   run_lds<1>("lds read b64", d_out);
   run_lds<2>("lds write+read b64", d_out);
+  }
 
   StftArgs a{};
   a.audio = d_audio; a.n = n; a.wtab = d_wtab;
@@ -198,24 +217,27 @@ int main(int argc, char **argv) {
   StftArgs a32 = a, a16 = a;
   a32.tw2 = tw2_32; a32.tw3 = tw3_32; a32.ubase = ub_32;
   a16.tw2 = tw2_16; a16.tw3 = tw3_16; a16.ubase = ub_16;
-  const int reps = 5;
-  for (int g : {4, 8, 16, 32, 64}) {
+  const int reps = 10;
+  const bool ubench = argc > 2 && atoi(argv[2]);
+  (void)ubench;
+#ifdef ABLNAME
+  a16.frames_per_block = 32;
+  time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true>(a16, reps, ABLNAME);
+  time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true, false, true>(a16, reps, ABLNAME " earlybar");
+  a16.mags = nullptr;
+  time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true>(a16, reps, ABLNAME " pitch-only");
+  return 0;
+#endif
+  for (int g : {8, 16, 32}) {
     a32.frames_per_block = a16.frames_per_block = g;
-    time_variant<P32, kBulkAligned, 256, 2, true, true>(a32, reps, "1 wave/frame  sliding wpe2");
-    time_variant<P16, kBulkAligned, 256, 4, true, true>(a16, reps, "2 waves/frame sliding wpe4");
-    time_variant<P16, kBulkAligned, 256, 3, true, true, 1>(a16, reps, "2 waves/frame twreg wpe3");
-    time_variant<P16, kBulkAligned, 256, 4, true, true, 2>(a16, reps, "2w tw3reg+tw2lds wpe4");
-    time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true>(a16, reps, "2w tw3reg+tw2lds defer wpe3");
-    time_variant<P16, kBulkAligned, 256, 3, true, true, 1, true>(a16, reps, "2 waves/frame twreg outsep wpe3");
-    time_variant<P16, kBulkAligned, 256, 3, true, true, true, 1, true>(a16, reps, "2 waves/frame twreg defer wpe3");
+    time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true>(a16, reps, "shipped: tw2lds defer wpe3");
+    time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true, false, true>(a16, reps, "early barrier wpe3");
   }
   a16.frames_per_block = 16;
-  time_variant<P16, kBulkAligned, 0, 3, true, true, 2, true, true>(a16, reps, "2w direct tw2lds defer");
-  time_variant<P16, kBulkAligned, 0, 3, true, true, 2, true, true, true>(a16, reps, "2w direct tw2lds defer prefetch");
+  time_variant<P16, kBulkAligned, 0, 3, true, true, 2, true, true>(a16, reps, "direct: tw2lds defer");
+  time_variant<P16, kBulkAligned, 0, 3, true, true, 2, true, true, false, true>(a16, reps, "direct: early barrier");
   a16.mags = nullptr;
-  time_variant<P16, kBulkAligned, 256, 3, true, true, true, 1, true>(a16, reps, "2w twreg defer pitch-only");
-  a16.mags = d_mags;
-  a16.pitch = nullptr;
-  time_variant<P16, kBulkAligned, 256, 3, true, true, true, 1, true>(a16, reps, "2w twreg defer mags-only");
+  time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true>(a16, reps, "pitch-only shipped");
+  time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true, false, true>(a16, reps, "pitch-only early barrier");
   return 0;
 }

@@ -182,12 +182,21 @@ int main(int argc, char **argv) {
   a.hop = hop; a.first_frame = 0; a.count = F; a.kmin = 20; a.kmax = 600; a.mags = d_mags; a.pitch = d_pitch;
   const int reps = 5;
   constexpr int SH = (BIGN == 16384 && BIGHOP == 512) ? 512 : 0;
+#ifndef BIGTR
+#define BIGTR 2
+#endif
+#ifdef BIGSWEEP
   for (int g : {2, 4, 8, 16}) {
     a.frames_per_block = g;
     time_variant<PB, kBulkAligned, SH, 2, true, true, 0>(a, reps, "tw global");
     time_variant<PB, kBulkAligned, SH, 2, true, true, 3>(a, reps, "tw2 in LDS");
     time_variant<PB, kBulkAligned, SH, 2, true, true, 2>(a, reps, "tw2 LDS + tw3 regs");
-    time_variant<PB, kBulkAligned, SH, 2, true, true, 3, false, false, true>(a, reps, "tw2 LDS + prefetch");
   }
+#else
+  a.frames_per_block = 8;
+  time_variant<PB, kBulkAligned, SH, 2, true, true, BIGTR>(a, reps, BIGNAME);
+  a.mags = nullptr;
+  time_variant<PB, kBulkAligned, SH, 2, true, true, BIGTR>(a, reps, BIGNAME " pitch-only");
+#endif
   return 0;
 }
