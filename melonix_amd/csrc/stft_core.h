@@ -311,6 +311,23 @@ MX_HD void load_frame_geo(int t, cpx (&Y)[P::E], const float *x, const float *wb
   }
 }
 
+// The same weights applied to samples fetched earlier (load_raw, the prefetching schedule).
+template <class P>
+MX_HD void apply_window_geo(int t, cpx (&Y)[P::E], const cpx (&xr)[P::E], const float *wb) {
+#pragma clang fp contract(off)
+  constexpr float sc = 0.5f / (float)P::N;
+  const cpx a0 = *reinterpret_cast<const cpx *>(wb + 2 * t);
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    constexpr float one = 1.0f;
+    const float g = e == 0 ? one : win_grow<P::T>(e);
+    float w0 = a0.x * g, w1 = a0.y * g;
+    w0 = w0 < sc ? w0 : sc;
+    w1 = w1 < sc ? w1 : sc;
+    Y[e] = mk(xr[e].x * w0, xr[e].y * w1);
+  }
+}
+
 // Direct modes, split in two so that the raw samples of the NEXT frame can be in flight while the
 // current one is transformed: load_raw issues the 64-bit sample loads, apply_window multiplies by
 // the weights (same rounded binary32 product as load_frame) once the frame is needed.

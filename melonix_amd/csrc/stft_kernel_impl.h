@@ -207,14 +207,9 @@ void stft_kernel(const StftArgs a0) {
       const float *w;
       frame_ptrs(f, zoff, x, w);
       if constexpr (PREFETCH) {
-        // this frame's samples were requested one frame ago; window them, then request the next frame's
-        apply_window<P, (MODE == kRanges ? -1 : 1), (MODE == kBulkAligned)>(t, Y, xr, w);
-        if (f + 1 < f1) {
-          const float *xn;
-          const float *wn;
-          frame_ptrs(f + 1, zoff, xn, wn);
-          load_raw<P, (MODE == kBulkAligned)>(t, xr, xn);
-        }
+        // this frame's samples were requested while the previous frame was being finished (below)
+        if constexpr (MODE == kRanges) apply_window<P, -1, false>(t, Y, xr, w);
+        else apply_window_geo<P>(t, Y, xr, a.wtab + N + zoff);
       } else if constexpr (MODE == kRanges) {
         load_frame<P, -1, false>(t, Y, x, w);  // exact d-indexed weights (per-column calls)
       } else {
@@ -271,6 +266,17 @@ void stft_kernel(const StftArgs a0) {
       if constexpr (TWREG == 1 || TWREG == 2) pass3_reg<P, false>(t, v, w3r);
       else pass3<P, false>(t, v, tw3);
       post<P, false>(t, v, u, mg);
+    }
+
+    if constexpr (PREFETCH && !kSlide) {
+      // the transform's registers are free again: request the next frame's samples now, so that they
+      // arrive under the pitch pick, the magnitude transposition and the row's stores
+      if (f + 1 < f1) {
+        const float *xn;
+        const float *wn;
+        frame_ptrs(f + 1, zoff, xn, wn);
+        load_raw<P, (MODE == kBulkAligned)>(t, xr, xn);
+      }
     }
 
     // ---- pitch pick: per-thread best, then wavefront max (registers only) ----

@@ -195,6 +195,9 @@ int main(int argc, char **argv) {
 #else
   a.frames_per_block = 8;
   time_variant<PB, kBulkAligned, SH, 2, true, true, BIGTR>(a, reps, BIGNAME);
+  time_variant<PB, kBulkAligned, SH, 2, true, true, BIGTR, false, false, true>(a, reps, BIGNAME " prefetch");
+  time_variant<PB, kBulkAligned, SH, 2, true, true, 3, false, false, true>(a, reps, BIGNAME " prefetch tw3 L2");
+  time_variant<PB, kBulkAligned, SH, 2, true, true, 3>(a, reps, BIGNAME " tw3 L2");
   a.mags = nullptr;
   time_variant<PB, kBulkAligned, SH, 2, true, true, BIGTR>(a, reps, BIGNAME " pitch-only");
 #endif
