@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <new>
@@ -57,6 +58,10 @@ struct mx_ctx {
   std::map<std::pair<int, int>, float *> wtabs;  // (N, hop) -> forward weights
   int frames_per_block = 0;  // 0 = per-N default
   std::mutex mu;
+  // host landing zone of the zero-crossing bitmaps (mx_grains_dev), kept between calls: a copy into
+  // pages that are already mapped runs at PCIe rate, a fresh 2 x n/8-byte buffer pays ~3 ms of faults
+  std::mutex zc_mu;
+  mx::ZcBitmaps zc_scratch;
 };
 
 struct mx_audio {
@@ -485,25 +490,57 @@ int mx_grains_dev(mx_ctx *ctx, const mx_audio *a, int32_t **starts, int32_t **le
   if (!ctx || !a || !starts || !lens || !count) return fail(MX_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(ctx->device));
   try {
-    ZcBitmaps zc;
+    const bool tr = getenv("MELONIX_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
+    std::lock_guard<std::mutex> zlk(ctx->zc_mu);
+    ZcBitmaps &zc = ctx->zc_scratch;
     zc.n = a->n;
     const size_t words = (size_t)((a->n + 63) >> 6);
-    zc.zc7.assign(words, 0);
-    zc.zc3.assign(words, 0);
-    if (words) {
-      uint64_t *d7 = nullptr, *d3 = nullptr;
-      HIP_TRY(hipMalloc(&d7, words * 8));
-      hipError_t e = hipMalloc(&d3, words * 8);
-      if (e == hipSuccess) e = launch_zc_bitmaps(a->d_padded, a->n, d7, d3, ctx->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(zc.zc7.data(), d7, words * 8, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(zc.zc3.data(), d3, words * 8, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    zc.zc7.resize(words);  // (no-init allocator: the kernel writes every word)
+    zc.zc3.resize(words);
+    const auto t1 = now();
+    auto t2 = t1, t3 = t1, t4 = t1;
+    std::vector<int32_t> s, l;
+    if (!words) return export_vectors(s, l, starts, lens, count);
+    uint64_t *d7 = nullptr, *d3 = nullptr;
+    hipEvent_t ev7 = nullptr;
+    HIP_TRY(hipMalloc(&d7, words * 8));
+    hipError_t e = hipMalloc(&d3, words * 8);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev7, hipEventDisableTiming);
+    t2 = now();
+    if (e == hipSuccess) e = launch_zc_bitmaps(a->d_padded, a->n, d7, d3, ctx->stream);
+    if (tr && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    t3 = now();
+    // the look-around-3 bitmap is a fallback the walk rarely needs: it keeps copying while the
+    // walk already runs over the look-around-7 bitmap
+    if (e == hipSuccess) e = hipMemcpyAsync(zc.zc7.data(), d7, words * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev7, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(zc.zc3.data(), d3, words * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ev7);
+    t4 = now();
+    hipError_t e3 = hipSuccess;
+    try {
+      if (e == hipSuccess) grains_from_bitmaps(zc, s, l, [&] { e3 = hipStreamSynchronize(ctx->stream); });
+    } catch (...) {  // the copy into zc's storage may still be running: drain it before unwinding
+      hipStreamSynchronize(ctx->stream);
+      if (ev7) hipEventDestroy(ev7);
       hipFree(d7);
       hipFree(d3);
-      if (e != hipSuccess) return fail(MX_ERR_DEVICE, "zero-crossing bitmaps: %s", hipGetErrorString(e));
+      throw;
     }
-    std::vector<int32_t> s, l;
-    grains_from_bitmaps(zc, s, l);
+    const auto t5 = now();
+    const hipError_t es = hipStreamSynchronize(ctx->stream);  // zc3's copy targets zc's storage: drain before it dies
+    if (e == hipSuccess) e = e3 != hipSuccess ? e3 : es;
+    if (ev7) hipEventDestroy(ev7);
+    hipFree(d7);
+    hipFree(d3);
+    const auto t6 = now();
+    if (e != hipSuccess) return fail(MX_ERR_DEVICE, "zero-crossing bitmaps: %s", hipGetErrorString(e));
+    if (tr)
+      fprintf(stderr, "mx_grains_dev: alloc %.2f ms, kernel %.2f, D2H(zc7) %.2f, chain walk %.2f, drain+free %.2f\n",
+              ms(t0, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, t6));
     return export_vectors(s, l, starts, lens, count);
   } catch (const std::bad_alloc &) {
     return fail(MX_ERR_NOMEM, "out of host memory");
@@ -516,6 +553,8 @@ int mx_schedule_build(const float *host_wav, int64_t n, int sampleRate, const in
   if (!steps || !nsteps || !nsamples || n < 0 || ngrains < 0 || nmarkers < 0 || (n > 0 && !host_wav) ||
       (ngrains > 0 && (!grain_starts || !grain_lens)) || (nmarkers > 0 && !markers))
     return fail(MX_ERR_INVALID, "bad argument");
+  const bool tr = getenv("MELONIX_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   for (int64_t g = 0; g < ngrains; ++g)
     if (grain_starts[g] < 0 || grain_lens[g] <= 0 || (int64_t)grain_starts[g] + grain_lens[g] > n)
       return fail(MX_ERR_INVALID, "grain %lld lies outside the audio", (long long)g);
@@ -523,8 +562,14 @@ int mx_schedule_build(const float *host_wav, int64_t n, int sampleRate, const in
     std::vector<mx_step> v;
     std::string err;
     int64_t total = 0;
+    const auto t1 = std::chrono::steady_clock::now();
     const int rc = build_schedule(host_wav, n, sampleRate, grain_starts, grain_lens, ngrains, markers, nmarkers, v,
                                   total, err);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (tr)
+      fprintf(stderr, "mx_schedule_build: validate %.2f ms, recurrence %.2f ms (%zu steps)\n",
+              std::chrono::duration<double, std::milli>(t1 - t0).count(),
+              std::chrono::duration<double, std::milli>(t2 - t1).count(), v.size());
     if (rc) return fail(rc, "%s", err.c_str());
     mx_step *p = (mx_step *)malloc(sizeof(mx_step) * std::max<size_t>(v.size(), 1));
     if (!p) return fail(MX_ERR_NOMEM, "out of host memory");

@@ -70,10 +70,10 @@ namespace {
 inline bool left_ok(float x) { return !(x >= 0); }
 inline bool right_ok(float x) { return !(x < 0); }
 
-inline bool test_bit(const std::vector<uint64_t> &b, int64_t i) { return (b[(size_t)(i >> 6)] >> (i & 63)) & 1; }
+inline bool test_bit(const BitWords &b, int64_t i) { return (b[(size_t)(i >> 6)] >> (i & 63)) & 1; }
 
 // first set bit in [lo, hi] or -1
-int64_t next_set(const std::vector<uint64_t> &b, int64_t nbits, int64_t lo, int64_t hi) {
+int64_t next_set(const BitWords &b, int64_t nbits, int64_t lo, int64_t hi) {
   if (lo < 0) lo = 0;
   if (hi >= nbits) hi = nbits - 1;
   if (lo > hi) return -1;
@@ -90,7 +90,7 @@ int64_t next_set(const std::vector<uint64_t> &b, int64_t nbits, int64_t lo, int6
   }
 }
 // last set bit in [lo, hi] or -1
-int64_t prev_set(const std::vector<uint64_t> &b, int64_t nbits, int64_t lo, int64_t hi) {
+int64_t prev_set(const BitWords &b, int64_t nbits, int64_t lo, int64_t hi) {
   if (lo < 0) lo = 0;
   if (hi >= nbits) hi = nbits - 1;
   if (lo > hi) return -1;
@@ -131,7 +131,9 @@ void zc_bitmaps_host(const float *wav, int64_t n, ZcBitmaps &out) {
   }
 }
 
-void grains_from_bitmaps(const ZcBitmaps &zc, std::vector<int32_t> &starts, std::vector<int32_t> &lens) {
+void grains_from_bitmaps(const ZcBitmaps &zc, std::vector<int32_t> &starts, std::vector<int32_t> &lens,
+                         const std::function<void()> &need_zc3) {
+  bool have3 = !need_zc3;
   starts.clear();
   lens.clear();
   const int64_t n = zc.n;
@@ -149,6 +151,10 @@ void grains_from_bitmaps(const ZcBitmaps &zc, std::vector<int32_t> &starts, std:
     else if (dn >= 0) pick = dn;
     if (pick < 0) {
       // app.cpp:198-228: first lookAround-3 crossing at i >= start+2250, i < n-1
+      if (!have3) {
+        need_zc3();
+        have3 = true;
+      }
       pick = next_set(zc.zc3, n, start + kPref + kPref / 2, n - 2);
       if (pick < 0) break;
     }
@@ -191,23 +197,45 @@ int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *g
   const int32_t *gend = gstarts + ngrains;
   steps.reserve((size_t)ngrains + 16);
 
+  // std::lower_bound(gstarts, gend, key) with a hint: the cursor moves about one grain per step, so
+  // the answer is almost always within a few entries of the previous one (exact for any key: falls
+  // back to the binary search on the side the short scan ran out on).
+  auto first_ge = [gstarts, gend, ngrains](int key, int64_t hint) -> const int32_t * {
+    int64_t i = hint < 0 ? 0 : (hint > ngrains ? ngrains : hint);
+    for (int k = 0; k < 8; ++k) {
+      if (i < ngrains && gstarts[i] < key) ++i;
+      else if (i > 0 && gstarts[i - 1] >= key) --i;
+      else return gstarts + i;
+    }
+    if (i < ngrains && gstarts[i] < key) return std::lower_bound(gstarts + i, gend, key);
+    if (i > 0 && gstarts[i - 1] >= key) return std::lower_bound(gstarts, gstarts + i, key);
+    return gstarts + i;
+  };
+
   double cursor = 0.;  // app.cpp:1201
+  int64_t hint = 0;
+  float lastBend = 0.f, lastRate = powf(2, 0.f / 12);
   for (;;) {
     const float pitchBend = tm.time2pitchbend(cursor);
-    const float rate = powf(2, pitchBend / 12);  // app.cpp:297
-    const int32_t *it1 = std::lower_bound(gstarts, gend, tm.time2sample(cursor));  // app.cpp:298-301
+    // app.cpp:297; the same libm call on the same argument, made once per distinct bend
+    const float rate = (pitchBend == lastBend) ? lastRate : powf(2, pitchBend / 12);
+    lastBend = pitchBend;
+    lastRate = rate;
+    const int32_t *it1 = first_ge(tm.time2sample(cursor), hint);  // app.cpp:298-301
     if (it1 == gend) {
       nsamples += 1500;  // app.cpp:303-309: preferredGrainSize zeros, then dt = 0 ends the export
       break;
     }
     const int64_t g = it1 - gstarts;
+    hint = g + 1;
+    if (g + 3 < ngrains) __builtin_prefetch(wav + gstarts[g + 3]);  // a later step's next_first
     const int64_t sz = step_size(rate, glens[g]);
     if (sz <= 0) {
       err = "pitch bend drives the resampling rate out of range (rate=" + std::to_string(rate) + ")";
       return MX_ERR_INVALID;
     }
     const double dt = 1. * (int)sz / sampleRate;  // app.cpp:323 / :344
-    const int32_t *it2 = std::lower_bound(gstarts, gend, tm.time2sample(cursor + dt));
+    const int32_t *it2 = first_ge(tm.time2sample(cursor + dt), g + 1);
     mx_step st;
     st.cursor = cursor;
     st.grain_start = gstarts[g];

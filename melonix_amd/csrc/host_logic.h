@@ -8,7 +8,10 @@
 // save-wav.cpp:17-48 (RIFF writer).
 #pragma once
 #include <cstdint>
+#include <functional>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/melonix_amd.h"
@@ -45,16 +48,35 @@ class TimeMap {
 // Zero-crossing predicate bitmaps: bit i of zc[k] set iff the reference's
 // isZeroCrossing lambda with lookAround k accepts index i (app.cpp:167-181 for
 // k = 7, app.cpp:202-216 for k = 3).
+// (vector whose resize() leaves the words uninitialised: the device kernel overwrites all of them,
+// and zero-filling 2 x n/8 bytes first cost more than the kernel and the copy together)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = NoInitAlloc<U>;
+  };
+  template <class U, class... A>
+  void construct(U *p, A &&...a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+    else ::new ((void *)p) U(std::forward<A>(a)...);
+  }
+};
+using BitWords = std::vector<uint64_t, NoInitAlloc<uint64_t>>;
 struct ZcBitmaps {
   int64_t n = 0;
-  std::vector<uint64_t> zc7, zc3;
+  BitWords zc7, zc3;
 };
 void zc_bitmaps_host(const float *wav, int64_t n, ZcBitmaps &out);
 
 // Walks the grain chain over the bitmaps: nearest zc7 to start+1500 within
 // +-749 (ties: the later index first, app.cpp:164-166), else the first zc3 at
 // i >= start+2250 (app.cpp:198-228).
-void grains_from_bitmaps(const ZcBitmaps &zc, std::vector<int32_t> &starts, std::vector<int32_t> &lens);
+// need_zc3 (optional) is called once, before the first look at zc3: the look-around-3 bitmap is only
+// consulted when no look-around-7 crossing lies within +-749 of the preferred cut, so a caller may
+// still have it in flight from the device while the walk runs over zc7.
+void grains_from_bitmaps(const ZcBitmaps &zc, std::vector<int32_t> &starts, std::vector<int32_t> &lens,
+                         const std::function<void()> &need_zc3 = {});
 
 // The export loop's serial recurrence.  Returns MX_OK or MX_ERR_INVALID.
 int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *gstarts,

@@ -133,31 +133,63 @@ __global__ __launch_bounds__(kResynthThreads) void resynth_kernel_long(const Res
   }
 }
 
-// zc bitmaps: one thread per sample, one 64-bit ballot per wavefront.
+// zc bitmaps.  A wavefront owns 64 consecutive bitmap words (4096 samples): every sample is loaded once
+// (64 coalesced 256-byte reads), two ballots turn each row into the sign words
+//   A = { !(x >= 0) }  (app.cpp:175 "wav[idx-j] >= 0 -> reject")   B = { !(x < 0) }  (app.cpp:177)
+// which lane w keeps for row w; the predicates are then bit-parallel on 64 samples per lane:
+//   zc_k[i] = AND_{j<k} A[i-j]  &  AND_{j<k} B[i+1+j],   k = 7 and 3,
+// with the carries from the neighbouring words (previous lane's A, next lane's B; the rows before and
+// after the wavefront's block come from two extra reads).  The reference's index bounds (idx >= k,
+// idx < n-k-1) are masks, so the pads around the audio never decide a bit.
+__device__ __forceinline__ uint64_t bit_range(int64_t base, int64_t lo, int64_t hi) {  // bits i: lo <= base+i < hi
+  const int64_t s = lo - base > 0 ? lo - base : 0;
+  const int64_t e = hi - base < 64 ? hi - base : 64;
+  if (e <= s) return 0ull;
+  const uint64_t upto_e = e >= 64 ? ~0ull : ((1ull << e) - 1ull);
+  return upto_e & ~((1ull << s) - 1ull);
+}
+
 __global__ __launch_bounds__(256) void zc_kernel(const float *__restrict__ wav /* unpadded base */,
                                                  int64_t n, uint64_t *__restrict__ zc7,
                                                  uint64_t *__restrict__ zc3) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  bool z7 = false, z3 = false;
-  if (i + 1 < n) {
-    // padded image: indices -PAD..n+PAD-1 are readable; the reference's bounds
-    // (idx >= k, idx < n-k-1) are applied explicitly so the pads never decide.
-    bool a3 = true, a7 = true;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      // app.cpp:175-178: "wav[idx-j] >= 0 -> reject", "wav[idx+1+j] < 0 -> reject"
-      const bool ok = !(wav[i - j] >= 0.f) && !(wav[i + 1 + j] < 0.f);
-      a7 = a7 && ok;
-      if (j < 3) a3 = a3 && ok;
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;  // first word of this wavefront
+  const int64_t nwords = (n + 63) >> 6;
+  if (w0 >= nwords) return;  // wavefront-uniform
+  // rows -1 .. 64 of the block; MX_AUDIO_PAD readable samples lie on either side of the audio
+  const float *p = wav + w0 * 64 + lane;
+  const float xp = p[-64], xn = p[64 * 64];
+  const uint64_t Aprev = __ballot(!(xp >= 0.f)), Bnext = __ballot(!(xn < 0.f));
+  uint64_t A = 0, B = 0;
+#pragma unroll 16
+  for (int w = 0; w < 64; ++w) {
+    const float x = p[64 * w];
+    const uint64_t a = __ballot(!(x >= 0.f)), b = __ballot(!(x < 0.f));
+    if (lane == w) {
+      A = a;
+      B = b;
     }
-    z7 = a7 && (i >= 7) && (i < n - 7 - 1);
-    z3 = a3 && (i >= 3) && (i < n - 3 - 1);
   }
-  const unsigned long long b7 = __ballot(z7);
-  const unsigned long long b3 = __ballot(z3);
-  if ((threadIdx.x & 63) == 0 && i < n) {
-    zc7[i >> 6] = b7;
-    zc3[i >> 6] = b3;
+  uint64_t Ap = ((uint64_t)(unsigned)__shfl_up((int)(A >> 32), 1) << 32) | (unsigned)__shfl_up((int)A, 1);
+  uint64_t Bn = ((uint64_t)(unsigned)__shfl_down((int)(B >> 32), 1) << 32) | (unsigned)__shfl_down((int)B, 1);
+  if (lane == 0) Ap = Aprev;
+  if (lane == 63) Bn = Bnext;
+  uint64_t ra3 = A, ra7 = A, rb3 = ~0ull, rb7 = ~0ull;
+#pragma unroll
+  for (int j = 1; j <= 7; ++j) {
+    const uint64_t bj = (B >> j) | (Bn << (64 - j));  // B[i + j]
+    rb7 &= bj;
+    if (j <= 3) rb3 &= bj;
+    if (j <= 6) {
+      const uint64_t aj = (A << j) | (Ap >> (64 - j));  // A[i - j]
+      ra7 &= aj;
+      if (j <= 2) ra3 &= aj;
+    }
+  }
+  const int64_t wi = w0 + lane;
+  if (wi < nwords) {
+    zc7[wi] = ra7 & rb7 & bit_range(wi * 64, 7, n - 7 - 1);
+    zc3[wi] = ra3 & rb3 & bit_range(wi * 64, 3, n - 3 - 1);
   }
 }
 
@@ -185,8 +217,9 @@ hipError_t launch_resynth(const ResynthArgs &a, hipStream_t s) {
 hipError_t launch_zc_bitmaps(const float *audio_padded, int64_t n, uint64_t *zc7, uint64_t *zc3,
                              hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  const int64_t blocks = (n + 255) / 256;
+  const int64_t blocks = (((n + 63) >> 6) + 255) / 256;  // 4 wavefronts x 64 words per workgroup
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  static_assert(MX_AUDIO_PAD >= 64 * 65, "zc_kernel reads one block row past either end of the audio");
   hipLaunchKernelGGL(zc_kernel, dim3((unsigned)blocks), dim3(256), 0, s, audio_padded + MX_AUDIO_PAD, n,
                      zc7, zc3);
   return hipGetLastError();

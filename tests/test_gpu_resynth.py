@@ -18,6 +18,32 @@ def test_grains_dev_equals_oracle(gpu_ctx, oracle, mxlib):
         a.free()
 
 
+@pytest.mark.parametrize("n", [1501, 1502, 1600, 4095, 4096, 4097, 4160, 8191, 70001, 262144 + 37])
+def test_grains_dev_ragged_lengths_and_nans(gpu_ctx, oracle, n):
+    """The bitmap kernel works on 64-sample words and 4096-sample blocks: lengths around those sizes,
+    crossings placed on word/block boundaries and right at the ends of the audio (where the reference's
+    idx >= k / idx < n-k-1 bounds decide), NaNs (both predicates accept them, app.cpp:175-178)."""
+    rng = np.random.default_rng(n)
+    t = np.arange(n)
+    w = (0.5 * np.sin(2 * np.pi * t / 151.0 + 0.3)).astype(np.float32)
+    for edge in (64, 128, 4096, 8192, 65536):  # a clean upward crossing exactly on the boundary
+        if edge + 16 < n:
+            w[edge - 12:edge] = -0.25
+            w[edge:edge + 12] = 0.25
+    w[:9] = -0.1  # sign runs touching both ends of the file
+    w[9:20] = 0.1
+    w[-20:-9] = -0.1
+    w[-9:] = 0.1
+    if n > 3000:
+        w[rng.integers(20, n - 20, 6)] = np.nan
+        w[2000:2000 + 1800] = np.abs(w[2000:2000 + 1800]) + 0.01  # forces the look-around-3 fallback
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    rs, rl = oracle.grains(w)
+    assert np.array_equal(s, rs) and np.array_equal(l, rl)
+    a.free()
+
+
 @pytest.mark.parametrize("pb,steps,samples", [(0, 320, 480407), (3, 379, 478903), (-4, 254, 479781), (7.5, 491, 479189)])
 def test_export_known_answers_bit_exact(gpu_ctx, oracle, mxlib, pb, steps, samples, tmp_path):
     """BASELINE.md §2 facts (recorded from the compiled reference) + bit-exact PCM vs the oracle."""

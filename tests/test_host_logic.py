@@ -68,6 +68,21 @@ markers_st = st.lists(
     min_size=0, max_size=5).map(lambda m: sorted(m, key=lambda x: x[0]))
 
 
+@settings(max_examples=25, deadline=None)
+@given(markers_st)
+def test_schedule_random_warp_markers(mxlib, oracle, sweep10, mk):
+    """Arbitrary sorted markers (time stretch either way, so the time maps need not be monotone, and
+    bends that change every step): the hinted grain search and the per-bend rate cache of
+    build_schedule must still give the oracle's schedule field by field."""
+    s, l = mxlib.grains_host(sweep10)
+    try:
+        steps, total = mxlib.schedule_build(sweep10, SR, s, l, mk)
+    except mxlib.MxError:
+        return  # a bend that drives the rate out of range is rejected, not scheduled
+    osteps, opcm = oracle.export_run(sweep10, SR, mk)
+    assert _same_steps(steps, osteps) and total == len(opcm)
+
+
 @settings(max_examples=60, deadline=None)
 @given(markers_st, st.lists(st.floats(-1.0, 12.0), min_size=1, max_size=20))
 def test_time_maps_match_oracle(mxlib, oracle, mk, vals):
