@@ -125,10 +125,21 @@ int mx_stft_hop_dev(mx_ctx *ctx, const mx_audio *a, int N, int hop, int64_t firs
 int mx_stft_ranges_dev(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *d_ranges,
                        int64_t count, int kmin, int kmax, float *d_mags, mx_pitch *d_pitch);
 
-/* Fused colormap (SpecCache::populateTex, spec-cache.cpp:77-96): magnitudes
- * * k -> clamp -> 3-segment RGB8, rgb_out = count x N/2 x 3 bytes (host). */
+/* Fused colormap (SpecCache::populateTex, spec-cache.cpp:77-96): the STFT
+ * kernel's epilogue applies  magnitude * k -> clamp -> 3-segment RGB8  to the
+ * row it has just produced, so texture rows leave the device as 3 bytes per bin
+ * from ONE launch.  rgb = count x N/2 x 3 bytes.  The *_mags variant returns the
+ * magnitude rows of the same launch as well (mags_out / d_mags may be NULL):
+ * that is what a Spec worker feeding both getSpec and a SpecCache wants. */
 int mx_stft_ranges_rgb(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges, int64_t count,
                        float k, uint8_t *rgb_out);
+int mx_stft_ranges_rgb_mags(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges,
+                            int64_t count, float k, float *mags_out, uint8_t *rgb_out);
+int mx_stft_ranges_rgb_dev(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *d_ranges,
+                           int64_t count, float k, float *d_mags, uint8_t *d_rgb);
+/* The colormap alone on device-resident magnitude rows (nbins_total a multiple
+ * of 4), e.g. to re-colour cached rows after the user changed k (app.cpp:75). */
+int mx_colormap_dev(mx_ctx *ctx, const float *d_mags, int64_t nbins_total, float k, uint8_t *d_rgb);
 
 /* Number of frames of the bulk indexing: ceil(n / hop). */
 int64_t mx_frame_count(int64_t n, int hop);

@@ -116,13 +116,19 @@ class Context:
                                                _ptr(mags), _ptr(pitch)))
         return mags, pitch
 
-    def stft_ranges_rgb(self, audio: Audio, N: int, ranges, k: float):
-        """Texture rows (count x N/2 x 3 uint8): STFT + the spec-cache.cpp:77-96 colormap on the GPU."""
+    def stft_ranges_rgb(self, audio: Audio, N: int, ranges, k: float, want_mags: bool = False):
+        """Texture rows (count x N/2 x 3 uint8): the spec-cache.cpp:77-96 colormap applied in the STFT
+        kernel's epilogue (one launch).  want_mags: also return the magnitude rows of that launch."""
         ranges = np.ascontiguousarray(ranges, dtype=np.int32).reshape(-1, 2)
         rgb = np.empty((len(ranges), N // 2, 3), dtype=np.uint8)
-        _capi.check(_capi.lib().mx_stft_ranges_rgb(self.handle, audio.handle, N, _ptr(ranges), len(ranges), float(k),
-                                                   _ptr(rgb)))
-        return rgb
+        if not want_mags:
+            _capi.check(_capi.lib().mx_stft_ranges_rgb(self.handle, audio.handle, N, _ptr(ranges), len(ranges),
+                                                       float(k), _ptr(rgb)))
+            return rgb
+        mags = np.empty((len(ranges), N // 2), dtype=np.float32)
+        _capi.check(_capi.lib().mx_stft_ranges_rgb_mags(self.handle, audio.handle, N, _ptr(ranges), len(ranges),
+                                                        float(k), _ptr(mags), _ptr(rgb)))
+        return rgb, mags
 
     # ---- STFT, device-resident outputs (raw device pointers, async on the ctx stream) ----
     def stft_hop_dev(self, audio: Audio, N: int, hop: int, first: int, count: int, d_mags: int | None,

@@ -65,6 +65,9 @@ SIGNATURES = {
     "mx_stft_hop_dev": (_i, [_vp, _vp, _i, _i, _i64, _i64, _i, _i, _vp, _vp]),
     "mx_stft_ranges_dev": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp]),
     "mx_stft_ranges_rgb": (_i, [_vp, _vp, _i, _vp, _i64, _f, _vp]),
+    "mx_stft_ranges_rgb_mags": (_i, [_vp, _vp, _i, _vp, _i64, _f, _vp, _vp]),
+    "mx_stft_ranges_rgb_dev": (_i, [_vp, _vp, _i, _vp, _i64, _f, _vp, _vp]),
+    "mx_colormap_dev": (_i, [_vp, _vp, _i64, _f, _vp]),
     "mx_frame_count": (_i64, [_i64, _i]),
     "mx_sample2time": (_d, [_vp, _i, _i, _i]),
     "mx_time2sample": (_i, [_vp, _i, _i, _d]),

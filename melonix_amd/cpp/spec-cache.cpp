@@ -47,13 +47,19 @@ struct SpecCache::Impl {
     // column -> sample range: left edge of pixel `key`, one pixel wide (spec-cache.cpp:63-65)
     const double left = key * rangeTime / width;
     const double pixel = rangeTime / width;
-    const std::vector<float> row = spec.getSpec(time2Sample(left), time2Sample(left + pixel));
+    const int start = time2Sample(left), end = time2Sample(left + pixel);
+    const std::vector<float> row = spec.getSpec(start, end);
     if (row.empty()) {
       texels.assign(16 * 3, 0);  // not ready: 16 black texels, retried on the next draw
     } else {
       c.filled = true;
-      texels.resize(row.size() * 3);
-      melonixColormap(row.data(), row.size(), k, texels.data());
+      // the texels normally come out of the same launch as the magnitudes (colormap fused into the STFT
+      // kernel); a row computed before this cache registered its scale is coloured here, as the
+      // reference colours every row (spec-cache.cpp:77-96)
+      if (!spec.getTexRow(start, end, k, texels)) {
+        texels.resize(row.size() * 3);
+        melonixColormap(row.data(), row.size(), k, texels.data());
+      }
     }
     glTexImage1D(GL_TEXTURE_1D, 0, 3, static_cast<GLsizei>(texels.size() / 3), 0, GL_RGB, GL_UNSIGNED_BYTE,
                  texels.data());
@@ -62,7 +68,9 @@ struct SpecCache::Impl {
 };
 
 SpecCache::SpecCache(Spec &spec, float k, int screenWidth, double rangeTime, std::function<int(double)> time2Sample)
-    : impl(std::make_unique<Impl>(spec, k, screenWidth, rangeTime, std::move(time2Sample))) {}
+    : impl(std::make_unique<Impl>(spec, k, screenWidth, rangeTime, std::move(time2Sample))) {
+  spec.setTexScale(k);
+}
 SpecCache::~SpecCache() = default;
 
 auto SpecCache::getTex(double time) -> GLuint {

@@ -30,6 +30,15 @@ public:
 
   auto getSpec(int start, int end) const -> std::vector<float>;
 
+  // Not in the reference — the side door SpecCache uses for the fused colormap.
+  // setTexScale(k): from now on every batch the worker computes also leaves the device as RGB8
+  // texel rows (spec-cache.cpp:77-96 applied in the STFT kernel's epilogue, same launch).
+  // getTexRow: true and N/2*3 bytes when the row of this key was computed with exactly this k;
+  // false otherwise (not computed yet, computed before the scale was set or with another one —
+  // the caller then colours the getSpec row itself, as the reference does).
+  void setTexScale(float k);
+  bool getTexRow(int start, int end, float k, std::vector<unsigned char> &rgb) const;
+
   int fftSize() const;
   bool ok() const;  // false when no MI355X context / upload failed
 

@@ -406,8 +406,19 @@ int mx_stft_ranges(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges,
   return stft_host_common(ctx, a, N, true, 0, 0, ranges, count, kmin, kmax, mags_out, pitch_out);
 }
 
-int mx_stft_ranges_rgb(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges, int64_t count, float k,
-                       uint8_t *rgb_out) {
+int mx_stft_ranges_rgb_dev(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *d_ranges, int64_t count, float k,
+                           float *d_mags, uint8_t *d_rgb) {
+  int kmin = -1, kmax = -1;
+  int rc = check_common(ctx, a, N, count, kmin, kmax);
+  if (rc) return rc;
+  if (count > 0 && (!d_ranges || !d_rgb)) return fail(MX_ERR_INVALID, "ranges / rgb is null");
+  if (count == 0) return MX_OK;
+  // one launch: the STFT kernel's epilogue writes the texels (and, if asked, the magnitudes as well)
+  return stft_launch(ctx, a, N, kRanges, 0, 0, d_ranges, count, kmin, kmax, d_mags, nullptr, d_rgb, k);
+}
+
+int mx_stft_ranges_rgb_mags(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges, int64_t count, float k,
+                            float *mags_out, uint8_t *rgb_out) {
   int kmin = -1, kmax = -1;
   int rc = check_common(ctx, a, N, count, kmin, kmax);
   if (rc) return rc;
@@ -419,8 +430,8 @@ int mx_stft_ranges_rgb(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ran
   float *d_mags = nullptr;
   uint8_t *d_rgb = nullptr;
   int32_t *d_ranges = nullptr;
-  hipError_t e = hipMalloc(&d_mags, (size_t)chunk * row * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&d_rgb, (size_t)chunk * row * 3);
+  hipError_t e = hipMalloc(&d_rgb, (size_t)chunk * row * 3);
+  if (e == hipSuccess && mags_out) e = hipMalloc(&d_mags, (size_t)chunk * row * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&d_ranges, (size_t)chunk * 2 * sizeof(int32_t));
   if (e != hipSuccess) {
     hipFree(d_mags); hipFree(d_rgb); hipFree(d_ranges);
@@ -430,17 +441,30 @@ int mx_stft_ranges_rgb(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ran
     const int64_t c = std::min(chunk, count - done);
     e = hipMemcpyAsync(d_ranges, ranges + 2 * done, (size_t)c * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) { rc = fail(MX_ERR_DEVICE, "ranges upload: %s", hipGetErrorString(e)); break; }
-    rc = mx_stft_ranges_dev(ctx, a, N, d_ranges, c, kmin, kmax, d_mags, nullptr);
+    rc = mx_stft_ranges_rgb_dev(ctx, a, N, d_ranges, c, k, d_mags, d_rgb);
     if (rc) break;
-    // second launch on the same stream: the magnitudes never leave the device
-    e = launch_colormap(d_mags, d_rgb, c * (int64_t)row, k, ctx->stream);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(rgb_out + (size_t)done * row * 3, d_rgb, (size_t)c * row * 3, hipMemcpyDeviceToHost, ctx->stream);
+    e = hipMemcpyAsync(rgb_out + (size_t)done * row * 3, d_rgb, (size_t)c * row * 3, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && mags_out)
+      e = hipMemcpyAsync(mags_out + (size_t)done * row, d_mags, (size_t)c * row * sizeof(float), hipMemcpyDeviceToHost,
+                         ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "colormap / download: %s", hipGetErrorString(e));
+    if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "texel download: %s", hipGetErrorString(e));
   }
   hipFree(d_mags); hipFree(d_rgb); hipFree(d_ranges);
   return rc;
+}
+
+int mx_stft_ranges_rgb(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges, int64_t count, float k,
+                       uint8_t *rgb_out) {
+  return mx_stft_ranges_rgb_mags(ctx, a, N, ranges, count, k, nullptr, rgb_out);
+}
+
+int mx_colormap_dev(mx_ctx *ctx, const float *d_mags, int64_t nbins_total, float k, uint8_t *d_rgb) {
+  if (!ctx || nbins_total < 0 || (nbins_total > 0 && (!d_mags || !d_rgb))) return fail(MX_ERR_INVALID, "bad argument");
+  if (nbins_total % 4) return fail(MX_ERR_INVALID, "bin count must be a multiple of 4 (whole rows)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(launch_colormap(d_mags, d_rgb, nbins_total, k, ctx->stream));
+  return MX_OK;
 }
 
 // ---- time maps -----------------------------------------------------------------

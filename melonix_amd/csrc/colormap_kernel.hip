@@ -11,41 +11,23 @@
 // Built with -ffp-contract=off.  Four texels per thread -> three dword stores (coalesced).
 #include <hip/hip_runtime.h>
 
+#include "colormap_core.h"
 #include "kernels.h"
 
 namespace mx {
 namespace {
-
-__device__ __forceinline__ void texel(float mag, float k, unsigned &r, unsigned &g, unsigned &b) {
-  float v = mag * k;
-  v = v < 0.f ? 0.f : (255.f < v ? 255.f : v);  // std::clamp(v, 0.f, 255.f)
-  if (v < 85.f) {
-    r = (unsigned)(unsigned char)v; g = 0; b = 0;
-  } else if (v < 170.f) {
-    const double a = (double)((v - 85.f) / 85.f) * 3.141592 / 2;
-    r = (unsigned)(unsigned char)((double)v * cos(a));
-    g = (unsigned)(unsigned char)((double)v * sin(a));
-    b = 0;
-  } else {
-    const unsigned l = (unsigned)(unsigned char)((v - 170.f) * 3.f);
-    r = l; g = (unsigned)(unsigned char)v; b = l;
-  }
-}
 
 __global__ __launch_bounds__(256) void colormap_kernel(const float4 *__restrict__ mags, uint32_t *__restrict__ rgb,
                                                        int64_t n4, float k) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const float4 m = mags[i];
-  unsigned r0, g0, b0, r1, g1, b1, r2, g2, b2, r3, g3, b3;
-  texel(m.x, k, r0, g0, b0);
-  texel(m.y, k, r1, g1, b1);
-  texel(m.z, k, r2, g2, b2);
-  texel(m.w, k, r3, g3, b3);
-  uint32_t *o = rgb + 3 * i;  // 12 bytes: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
-  o[0] = r0 | (g0 << 8) | (b0 << 16) | (r1 << 24);
-  o[1] = g1 | (b1 << 8) | (r2 << 16) | (g2 << 24);
-  o[2] = b2 | (r3 << 8) | (g3 << 16) | (b3 << 24);
+  uint32_t w[3];
+  texel4(m.x, m.y, m.z, m.w, k, w);
+  uint32_t *o = rgb + 3 * i;
+  o[0] = w[0];
+  o[1] = w[1];
+  o[2] = w[2];
 }
 
 // ---- waveform min/max pyramid (App::calcPicks, app.cpp:347-378) -------------------------------

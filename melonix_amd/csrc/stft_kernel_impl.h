@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "colormap_core.h"
 #include "kernels.h"
 #include "stft_core.h"
 #include "stft_tables.h"
@@ -52,7 +53,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 // NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
 // and window loads are not hoisted out of the frame loop into hundreds of registers.
 template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, int TWREG = 0, bool OUTSEP = false,
-          bool DEFER = false, bool PREFETCH = false, bool EARLYBAR = false>
+          bool DEFER = false, bool PREFETCH = false, bool EARLYBAR = false, bool CMAP = false>
 __global__ __launch_bounds__(P::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void stft_kernel(const StftArgs a0) {
   const StftArgs &a = a0;
@@ -132,11 +133,14 @@ void stft_kernel(const StftArgs a0) {
       a.pitch[fr] = p;
     }
   };
+  // CMAP (ranges mode): the row can also leave as RGB8 texels — SpecCache::populateTex's colormap
+  // (spec-cache.cpp:77-96) applied to the four consecutive bins a lane holds, 12 bytes per lane.
+  const bool want_rows = a.mags != nullptr || (CMAP && a.rgb != nullptr);
   auto flush_row = [&](int64_t fr, int tt) {  // after a barrier that follows the scatter of frame fr
 #ifdef MX_EXP_DIRECTOUT
     if (false) {
 #else
-    if (a.mags) {
+    if (want_rows) {
 #endif
       using f32x4 = float __attribute__((ext_vector_type(4)));
       const f32x4 *l4 = reinterpret_cast<const f32x4 *>(lout) + tt;
@@ -144,13 +148,29 @@ void stft_kernel(const StftArgs a0) {
       f32x4 q[C::M / 4 / C::T];
 #pragma unroll
       for (int i = 0; i < C::M / 4 / C::T; ++i) q[i] = l4[C::T * i];
+      if (!CMAP || a.mags) {
 #pragma unroll
-      for (int i = 0; i < C::M / 4 / C::T; ++i) {
+        for (int i = 0; i < C::M / 4 / C::T; ++i) {
 #if defined(MX_ABL_NOGSTORE)
-        asm volatile("" ::"v"(q[i]), "v"(row4));
+          asm volatile("" ::"v"(q[i]), "v"(row4));
 #else
-        __builtin_nontemporal_store(q[i], &row4[C::T * i]);
+          __builtin_nontemporal_store(q[i], &row4[C::T * i]);
 #endif
+        }
+      }
+      if constexpr (CMAP) {
+        if (a.rgb) {
+          uint32_t *trow = reinterpret_cast<uint32_t *>(a.rgb + (size_t)fr * (size_t)(N / 2) * 3) + 3 * tt;
+#pragma unroll 1
+          for (int i = 0; i < C::M / 4 / C::T; ++i) {
+            uint32_t w3[3];
+            texel4(q[i].x, q[i].y, q[i].z, q[i].w, a.cmap_k, w3);
+            uint32_t *o = trow + 3 * C::T * i;
+            o[0] = w3[0];
+            o[1] = w3[1];
+            o[2] = w3[2];
+          }
+        }
       }
     }
   };
@@ -328,7 +348,7 @@ void stft_kernel(const StftArgs a0) {
     if (false) {
       float *plo = lout + out_lo, *phi = lout + out_hi;
 #else
-    if (a.mags) {
+    if (want_rows) {
       float *plo = lout + out_lo, *phi = lout + out_hi;
 #endif
       float *mlo = lout + (C::M - out_lo), *mhi = lout + (C::M - out_hi);
@@ -341,7 +361,7 @@ void stft_kernel(const StftArgs a0) {
       }
     }
     if constexpr (!DEFER) {
-      if (a.mags) {
+      if (want_rows) {
         MX_BARRIER();  // (also: every wave is past load_t2, so the image may be refilled)
         flush_row(f, t);
         if constexpr (!OUTSEP) MX_BARRIER();  // image free again

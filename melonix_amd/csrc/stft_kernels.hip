@@ -61,7 +61,13 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
       else hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b);
       break;
     case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b); break;
-    case kRanges: hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b); break;
+    case kRanges:
+      // texel output (fused colormap) is its own instantiation: the binary64 cos/sin of the middle colour
+      // segment must not weigh on the register allocation of the plain kernels
+      // (and it gets the two-waves-per-SIMD register budget: screen-sized batches are not occupancy-bound)
+      if (a.rgb) hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, (W > 2 ? 2 : W), NH, true, TRD, OS, DF, false, EB, true>), grid, block, 0, s, b);
+      else hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b);
+      break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

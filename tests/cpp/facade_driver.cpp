@@ -88,6 +88,14 @@ int main(int argc, char **argv) {
       const auto r = spec.getSpec((int)(left * sr), (int)((left + 10.0 / 1280) * sr));
       texrows.insert(texrows.end(), r.begin(), r.end());
       check(cache.getTex(t) == name, "clean column returns the same texture");
+      // the texels came out of the STFT launch itself (fused colormap), not from the host loop
+      std::vector<unsigned char> fused;
+      check(spec.getTexRow((int)(left * sr), (int)((left + 10.0 / 1280) * sr), kk, fused), "row carries fused texels");
+      check(fused == g_tex[name], "the texture is the fused texel row");
+      std::vector<unsigned char> hostc(r.size() * 3);
+      melonixColormap(r.data(), r.size(), kk, hostc.data());
+      check(hostc == fused, "fused texels == the reference's UI-thread colormap of the same row");
+      check(!spec.getTexRow((int)(left * sr), (int)((left + 10.0 / 1280) * sr), kk * 2, fused), "other scale: no fused row");
     }
     dump(out + "/tex.u8", texels);
     dump(out + "/texrows.f32", texrows);

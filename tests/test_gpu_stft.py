@@ -156,7 +156,7 @@ def test_errors(gpu_ctx, mxlib):
     a.free()
 
 
-@pytest.mark.parametrize("N", [4096, 32768])
+@pytest.mark.parametrize("N", [4096, 16384, 32768])
 def test_fused_colormap(gpu_ctx, oracle, N):
     """mx_stft_ranges_rgb = oracle colormap (spec-cache.cpp:77-96) of the GPU's own magnitude rows, byte for
     byte, for brightness settings that exercise all three segments; vs the oracle's own magnitudes the
@@ -173,6 +173,15 @@ def test_fused_colormap(gpu_ctx, oracle, N):
         assert (np.abs(rgb.astype(int) - ref.astype(int)) <= 1).mean() > 0.999
     seg = np.stack([oracle.colormap(m, 2.0 ** 15) for m in mags])
     assert (seg[..., 1] > 0).any() and (seg[..., 2] > 0).any()  # the test really reaches segments 2 and 3
+    # texels and magnitudes out of one launch: the rows are the plain ranges call's, bit for bit
+    rgb2, mags2 = gpu_ctx.stft_ranges_rgb(a, N, ranges, 2.0 ** 15, want_mags=True)
+    assert np.array_equal(mags2, mags) and np.array_equal(rgb2, seg)
+    # a whole cold screen (1280 columns of 375 samples, spec-cache.cpp:63-65) in one call
+    cols = np.stack([np.arange(1280) * 375, (np.arange(1280) + 1) * 375], axis=1).astype(np.int32)
+    rgb3, mags3 = gpu_ctx.stft_ranges_rgb(a, N, cols, 2.0 ** 15, want_mags=True)
+    pick = [0, 1, 63, 64, 640, 1278, 1279]
+    assert np.array_equal(rgb3[pick], np.stack([oracle.colormap(mags3[i], 2.0 ** 15) for i in pick]))
+    assert np.array_equal(mags3, gpu_ctx.stft_ranges(a, N, cols)[0])
     a.free()
 
 
