@@ -104,6 +104,25 @@ int main(int argc, char **argv) {
     check(g_live == before - 4, "clear() releases the textures");
   }
 
+  {  // a cold 1280-column screen, drawn the way App::drawSpec does (app.cpp:489-491): every vsync asks for
+     // every column; the reference fills one column per worker iteration (~0.5 s for the screen)
+    Spec spec(std::span<float>{wav.data(), wav.size()}, N);
+    SpecCache cache(spec, 512.f * 64, 1280, 10.0, [&](double v) { return (int)(v * sr); });
+    const auto t0 = std::chrono::steady_clock::now();
+    int frames = 0, filled = 0;
+    for (; frames < 1000 && filled < 1280; ++frames) {
+      filled = 0;
+      for (int x = 0; x < 1280; ++x) {
+        const GLuint name = cache.getTex((x + 0.5) * 10.0 / 1280);
+        filled += g_tex[name].size() == (size_t)N / 2 * 3;
+      }
+      if (filled < 1280) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    check(filled == 1280, "cold screen fills");
+    printf("cold_screen: N=%d 1280 columns filled after %d draw passes, %.1f ms\n", N, frames, ms);
+  }
+
   {  // saveWav: reference signature, strict header
     std::vector<int16_t> pcm(1000);
     for (int i = 0; i < 1000; ++i) pcm[i] = (int16_t)(i * 37 - 12000);

@@ -31,6 +31,8 @@ def test_facade_end_to_end(driver, oracle, tmp_path, N):
     w.tofile(tmp_path / "audio.f32")
     r = subprocess.run([driver, str(tmp_path / "audio.f32"), str(tmp_path), str(N)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout)  # (pytest -s shows the cold-screen timing)
+    assert "cold_screen:" in r.stdout
     bins = N // 2
     # Spec::getSpec rows vs the oracle (N = 32768 is the reference's SpectrSize)
     keys = [(47000, 47375), (0, 256), (-500, -100), (100000, 100001)]
