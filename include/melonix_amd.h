@@ -104,6 +104,13 @@ int mx_audio_free(mx_ctx *ctx, mx_audio *a);
 /* Default pitch band for (N, sampleRate): kmin=ceil(55*N/sr), kmax=floor(1760*N/sr). */
 void mx_pitch_band(int N, int sampleRate, int *kmin, int *kmax);
 
+/* The editor's note <-> frequency law (app.cpp:498-499: f(note) = 55 * 2^((note-24)/12) Hz; bin k of an
+ * N-point frame sits at k*sampleRate/N Hz).  mx_bin_note turns a pitch record's bin into the value a
+ * Marker::note (marker.hpp:6) holds: 24 + 12*log2(k*sampleRate/N/55); -HUGE_VAL for k <= 0.
+ * mx_note_bin is its inverse (fractional bin).  Host, double. */
+double mx_bin_note(int bin, int N, int sampleRate);
+double mx_note_bin(double note, int N, int sampleRate);
+
 /* Arbitrary (start,end) pairs — the drop-in mode: one call drains a whole
  * batch of Spec::getSpec jobs (spec.cpp:18-42, 68-97).  ranges = count x {start,end}
  * (host).  mags_out = count x N/2 f32 (host, may be NULL); pitch_out = count

@@ -30,6 +30,15 @@ def pitch_band(N: int, sr: int = 48000):
     return a.value, b.value
 
 
+def bin_note(bin: int, N: int, sr: int = 48000) -> float:
+    """Marker::note of a pitch record's bin (app.cpp:498-499 note law)."""
+    return _capi.lib().mx_bin_note(int(bin), N, sr)
+
+
+def note_bin(note: float, N: int, sr: int = 48000) -> float:
+    return _capi.lib().mx_note_bin(float(note), N, sr)
+
+
 def frame_count(n: int, hop: int) -> int:
     return _capi.lib().mx_frame_count(n, hop)
 

@@ -60,6 +60,8 @@ SIGNATURES = {
     "mx_audio_length": (_i64, [_vp]),
     "mx_audio_free": (_i, [_vp, _vp]),
     "mx_pitch_band": (None, [_i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "mx_bin_note": (_d, [_i, _i, _i]),
+    "mx_note_bin": (_d, [_d, _i, _i]),
     "mx_stft_ranges": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp]),
     "mx_stft_hop": (_i, [_vp, _vp, _i, _i, _i64, _i64, _i, _i, _vp, _vp]),
     "mx_stft_hop_dev": (_i, [_vp, _vp, _i, _i, _i64, _i64, _i, _i, _vp, _vp]),

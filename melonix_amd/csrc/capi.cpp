@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -326,6 +327,15 @@ void mx_pitch_band(int N, int sampleRate, int *kmin, int *kmax) {
   if ((double)a < lo) ++a;
   if (kmin) *kmin = a;
   if (kmax) *kmax = (int)hi;
+}
+
+double mx_bin_note(int bin, int N, int sampleRate) {
+  if (bin <= 0 || N <= 0 || sampleRate <= 0) return -HUGE_VAL;
+  return 24. + 12. * std::log2((double)bin * sampleRate / N / 55.);
+}
+double mx_note_bin(double note, int N, int sampleRate) {
+  if (N <= 0 || sampleRate <= 0) return 0.;
+  return 55. * std::pow(2., (note - 24.) / 12.) * N / sampleRate;  // app.cpp:498
 }
 
 int64_t mx_frame_count(int64_t n, int hop) { return hop > 0 && n >= 0 ? (n + hop - 1) / hop : -1; }

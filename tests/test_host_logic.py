@@ -153,3 +153,19 @@ def test_minmax_range_matches_oracle(mxlib, oracle, n, seed):
     for _ in range(20):
         s_, e_ = (int(x) for x in rng.integers(-5, n + 5, 2))
         assert mxlib.minmax_range(w, lv, s_, e_) == oracle.minmax_range(w, lv, s_, e_)
+
+
+def test_bin_note_law(mxlib):
+    """app.cpp:498-499: f(note) = 55*2^((note-24)/12) Hz, bin = f*N/sr.  The default pitch band is notes
+    24..84 of the default view (app.hpp:45-46): its edge bins map back inside that note range."""
+    import math
+    for N in (4096, 16384, 32768):
+        kmin, kmax = mxlib.pitch_band(N, SR)
+        assert mxlib.bin_note(kmin - 1, N, SR) < 24.0 <= mxlib.bin_note(kmin, N, SR)
+        assert mxlib.bin_note(kmax, N, SR) <= 84.0 < mxlib.bin_note(kmax + 1, N, SR)
+        for note in (24.0, 33.0, 57.5, 84.0):
+            assert abs(mxlib.bin_note(1, N, SR) - (24 + 12 * math.log2(SR / N / 55))) < 1e-12
+            b = mxlib.note_bin(note, N, SR)
+            assert abs(b - 55 * 2 ** ((note - 24) / 12) * N / SR) < 1e-9 * b
+    assert mxlib.note_bin(36.0, 4096, SR) * SR / 4096 == pytest.approx(110.0)  # an octave above note 24 = 55 Hz
+    assert mxlib.bin_note(0, 4096, SR) == -math.inf
