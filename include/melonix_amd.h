@@ -85,7 +85,7 @@ const char *mx_version(void);
  * (spec.cpp:10-16, app.cpp:251): the samples are copied to HBM once. */
 int mx_audio_upload(mx_ctx *ctx, const float *host_wav, int64_t n, mx_audio **out);
 /* Zero-copy: wrap a device buffer already laid out [PAD zeros][n][PAD zeros]
- * (d_padded points at the first pad sample).  The caller keeps ownership. */
+ * (d_padded points at the first pad sample, 16-byte aligned).  The caller keeps ownership. */
 int mx_audio_wrap_device(mx_ctx *ctx, const float *d_padded, int64_t n, mx_audio **out);
 int64_t mx_audio_length(const mx_audio *a);
 int mx_audio_free(mx_ctx *ctx, mx_audio *a);

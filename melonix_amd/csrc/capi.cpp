@@ -295,6 +295,8 @@ int mx_audio_upload(mx_ctx *ctx, const float *host_wav, int64_t n, mx_audio **ou
 
 int mx_audio_wrap_device(mx_ctx *ctx, const float *d_padded, int64_t n, mx_audio **out) {
   if (!ctx || !out || !d_padded || n < 0) return fail(MX_ERR_INVALID, "bad argument");
+  if (reinterpret_cast<uintptr_t>(d_padded) & 15)  // the kernels use 8- and 16-byte loads of the samples
+    return fail(MX_ERR_INVALID, "device audio buffer must be 16-byte aligned");
   mx_audio *a = new (std::nothrow) mx_audio();
   if (!a) return fail(MX_ERR_NOMEM, "out of host memory");
   a->d_padded = const_cast<float *>(d_padded);

@@ -186,11 +186,11 @@ int main(int argc, char **argv) {
 #define BIGTR 2
 #endif
 #ifdef BIGSWEEP
-  for (int g : {2, 4, 8, 16}) {
+  for (int g : {4, 8, 16}) {
     a.frames_per_block = g;
-    time_variant<PB, kBulkAligned, SH, 2, true, true, 0>(a, reps, "tw global");
-    time_variant<PB, kBulkAligned, SH, 2, true, true, 3>(a, reps, "tw2 in LDS");
+    time_variant<PB, kBulkAligned, SH, 2, true, true, 3>(a, reps, "tw2 in LDS, tw3 from L2");
     time_variant<PB, kBulkAligned, SH, 2, true, true, 2>(a, reps, "tw2 LDS + tw3 regs");
+    time_variant<PB, kBulkAligned, SH, 2, true, true, 0>(a, reps, "tw global");
   }
 #else
   a.frames_per_block = 8;
