@@ -222,15 +222,15 @@ def main() -> None:
         t_sc = time.perf_counter() - t0
         d_steps = torch.from_numpy(steps_arr.view(np.uint8).copy()).to(dev)
         pcm_i = torch.empty(total, dtype=torch.int16, device=dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
             ctx.resynth_dev(audio, d_steps.data_ptr(), len(steps_arr), total, None, pcm_i.data_ptr())
-        e0.record()
-        for _ in range(10):
+        rev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a_, b_ in rev:  # one event pair per launch, like the STFT kernel above
+            a_.record()
             ctx.resynth_dev(audio, d_steps.data_ptr(), len(steps_arr), total, None, pcm_i.data_ptr())
-        e1.record()
+            b_.record()
         torch.cuda.synchronize()
-        r_ms = e0.elapsed_time(e1) / 10
+        r_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in rev]))
         rb = (4 * 2.0 ** (3 / 12) + 2) * total  # ~6.76 B per output sample at +3 st
         resynth = {"pitch_bend_semitones": 3, "pcm_samples": int(total), "steps": int(len(steps_arr)), "kernel_ms": r_ms,
                    "hop256_frames_per_s": total / 256 / (r_ms * 1e-3), "achieved_GBps": rb / (r_ms * 1e-3) / 1e9,

@@ -7,7 +7,9 @@ set -u
 TAG=${1:-r01}; shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out
-BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-resynth $*"
+# PROF_RESYNTH=1: keep the supplementary resynthesis in the run and summarise ITS kernel (PROF_KERNEL)
+NORES="--no-resynth"; [ "${PROF_RESYNTH:-0}" = "1" ] && NORES="" && export PROF_KERNEL=${PROF_KERNEL:-resynth_kernel_v}
+BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline $NORES $*"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o stft -- $BENCH > $OUT/prof_${TAG}_bench.log 2>&1
 PASSES=(
@@ -20,7 +22,7 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --output-format csv --pmc $P -d $OUT/pmc_${TAG}_$i -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-resynth $* > $OUT/pmc_${TAG}_$i.log 2>&1 || echo "pass $i failed" >> $OUT/pmc_${TAG}_fail.log
+  rocprofv3 --kernel-trace --output-format csv --pmc $P -d $OUT/pmc_${TAG}_$i -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline $NORES $* > $OUT/pmc_${TAG}_$i.log 2>&1 || echo "pass $i failed" >> $OUT/pmc_${TAG}_fail.log
 done
 python tools/summarize_prof.py $TAG > $OUT/prof_${TAG}_summary.txt 2>&1
 find $OUT -name "*.db" -delete; find $OUT -name "*agent_info*" -delete

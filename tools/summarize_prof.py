@@ -10,6 +10,7 @@ import os
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+KERNEL = os.environ.get("PROF_KERNEL", "stft_kernel")  # substring of the kernel the PMC rows are kept for
 OUT = "gpurun_out"
 res = {"tag": tag, "kernels": [], "pmc": {}}
 
@@ -34,7 +35,7 @@ for d in find(f"pmc_{tag}_*"):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row.get("Kernel_Name", "")
-                if "stft_kernel" not in name:
+                if KERNEL not in name:
                     continue
                 c = row.get("Counter_Name")
                 v = float(row.get("Counter_Value", 0))
@@ -44,7 +45,7 @@ for d in find(f"pmc_{tag}_*"):
         for c, per in acc.items():
             vals = list(per.values())
             res["pmc"][c] = {"per_launch_avg": sum(vals) / len(vals), "launches": len(vals)}
-print("== PMC per STFT launch ==")
+print(f"== PMC per launch of {KERNEL} ==")
 for c, v in sorted(res["pmc"].items()):
     print(f"{c:32s} {v['per_launch_avg']:.6g}  (n={v['launches']})")
 p = res["pmc"]
@@ -57,7 +58,7 @@ if "WRITE_SIZE" in p:
     res["write_bytes"] = p["WRITE_SIZE"]["per_launch_avg"] * 1024
     print("WRITE bytes:", res["write_bytes"])
 # bench.py reads profiles/pmc_latest.json for roofline.traffic (HBM bytes per launch from PMC)
-stft = [k for k in res["kernels"] if "stft_kernel" in k.get("Name", "")]
+stft = [k for k in res["kernels"] if KERNEL in k.get("Name", "")]
 if stft and "WRITE_SIZE" in p and "FETCH_SIZE" in p:
     res["stft_kernel_avg_ns"] = float(stft[0]["AverageNs"])
     res["hbm_bytes_per_launch"] = res["fetch_bytes_corrected"] + res["write_bytes"]
