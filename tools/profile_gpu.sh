@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out
 # PROF_RESYNTH=1: keep the supplementary resynthesis in the run and summarise ITS kernel (PROF_KERNEL)
 NORES="--no-resynth"; [ "${PROF_RESYNTH:-0}" = "1" ] && NORES="" && export PROF_KERNEL=${PROF_KERNEL:-resynth_kernel_v}
-BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline $NORES $*"
+BENCH="python bench.py --steps 50 --warmup 10 --no-cpu-baseline $NORES $*"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o stft -- $BENCH > $OUT/prof_${TAG}_bench.log 2>&1
 PASSES=(
