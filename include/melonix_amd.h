@@ -178,6 +178,16 @@ int mx_grains_dev(mx_ctx *ctx, const mx_audio *a, int32_t **starts, int32_t **le
 int mx_schedule_build(const float *host_wav, int64_t n, int sampleRate, const int32_t *grain_starts,
                       const int32_t *grain_lens, int64_t ngrains, const mx_marker *markers,
                       int nmarkers, mx_step **steps, int64_t *nsteps, int64_t *nsamples);
+/* The same chain of process() calls from any warped time: App::playback's refill loop
+ * (app.cpp:272-274, `while (restWav.size() < need) tmpCursor += process(tmpCursor, restWav)` from an
+ * empty restWav).  need >= 0: stop once *nsamples >= need; a call that finds no grain left adds 1500
+ * zeros and leaves the cursor where it is, as often as the loop asks (the zeros are the tail of the
+ * PCM, not steps).  need < 0: run to the end as mx_schedule_build does, from cursor0.
+ * *cursor_end (may be NULL): the loop's cursor on exit = where the next refill continues. */
+int mx_schedule_build_from(const float *host_wav, int64_t n, int sampleRate, const int32_t *grain_starts,
+                           const int32_t *grain_lens, int64_t ngrains, const mx_marker *markers,
+                           int nmarkers, double cursor0, int64_t need, mx_step **steps,
+                           int64_t *nsteps, int64_t *nsamples, double *cursor_end);
 void mx_free(void *p);
 
 /* Gather-lerp resampler + float->int16 (app.cpp:332-343, 1209-1212) over a

@@ -218,6 +218,22 @@ def schedule_build(wav, sr: int, starts, lens, markers):
     return steps, tot.value
 
 
+def schedule_build_from(wav, sr: int, starts, lens, markers, cursor0: float, need: int):
+    """App::playback's refill loop from warped time cursor0 -> (steps, nsamples, cursor_end)."""
+    wav = np.ascontiguousarray(wav, dtype=np.float32)
+    starts = np.ascontiguousarray(starts, dtype=np.int32)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    m = _capi.markers_array(markers)
+    p, ns, tot, end = C.POINTER(_capi.Step)(), C.c_int64(), C.c_int64(), C.c_double()
+    _capi.check(_capi.lib().mx_schedule_build_from(_ptr(wav), len(wav), sr, _ptr(starts), _ptr(lens), len(starts), m,
+                                                   len(markers), float(cursor0), int(need), C.byref(p), C.byref(ns),
+                                                   C.byref(tot), C.byref(end)))
+    steps = np.frombuffer(C.string_at(p, ns.value * C.sizeof(_capi.Step)), dtype=STEP_DTYPE).copy() if ns.value \
+        else np.zeros(0, STEP_DTYPE)
+    _capi.lib().mx_free(p)
+    return steps, tot.value, end.value
+
+
 def save_wav(path, pcm16, sr: int, strict: bool = True):
     pcm16 = np.ascontiguousarray(pcm16, dtype=np.int16)
     _capi.check(_capi.lib().mx_save_wav(str(path).encode(), _ptr(pcm16), len(pcm16), sr, 1 if strict else 0))

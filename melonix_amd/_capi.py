@@ -80,6 +80,8 @@ SIGNATURES = {
     "mx_grains_dev": (_i, [_vp, _vp, C.POINTER(_pi32), C.POINTER(_pi32), C.POINTER(_i64)]),
     "mx_schedule_build": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i, C.POINTER(C.POINTER(Step)),
                                C.POINTER(_i64), C.POINTER(_i64)]),
+    "mx_schedule_build_from": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i, _d, _i64, C.POINTER(C.POINTER(Step)),
+                                    C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_d)]),
     "mx_free": (None, [_vp]),
     "mx_resynth": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mx_resynth_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),

@@ -34,13 +34,15 @@ Resynth::~Resynth() {
   if (ctx) mx_ctx_destroy(ctx);
 }
 
-bool Resynth::run(const std::vector<Marker> &markers, std::vector<float> *f32, std::vector<int16_t> *i16) const {
+bool Resynth::run(const std::vector<Marker> &markers, std::vector<float> *f32, std::vector<int16_t> *i16,
+                  double cursor0, int64_t need, double *cursorEnd) const {
   if (!ok()) return false;
   mx_step *steps = nullptr;
   int64_t nsteps = 0, nsamples = 0;
   const mx_marker *mk = reinterpret_cast<const mx_marker *>(markers.data());
-  if (mx_schedule_build(host.data(), (int64_t)host.size(), sampleRate, starts.data(), lens.data(),
-                        (int64_t)starts.size(), mk, (int)markers.size(), &steps, &nsteps, &nsamples) != MX_OK)
+  if (mx_schedule_build_from(host.data(), (int64_t)host.size(), sampleRate, starts.data(), lens.data(),
+                             (int64_t)starts.size(), mk, (int)markers.size(), cursor0, need, &steps, &nsteps, &nsamples,
+                             cursorEnd) != MX_OK)
     return false;
   if (f32) f32->resize((size_t)nsamples);
   if (i16) i16->resize((size_t)nsamples);
@@ -58,6 +60,13 @@ std::vector<float> Resynth::render(const std::vector<Marker> &markers) const {
 std::vector<int16_t> Resynth::render16(const std::vector<Marker> &markers) const {
   std::vector<int16_t> pcm;
   if (!run(markers, nullptr, &pcm)) pcm.clear();
+  return pcm;
+}
+
+std::vector<float> Resynth::refill(const std::vector<Marker> &markers, double cursor, std::size_t need,
+                                   double *cursorEnd) const {
+  std::vector<float> pcm;
+  if (!run(markers, &pcm, nullptr, cursor, (int64_t)need, cursorEnd)) pcm.clear();
   return pcm;
 }
 

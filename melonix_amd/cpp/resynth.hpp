@@ -5,9 +5,16 @@
 //   r.exportWav(fileName, markers);                   // App::exportWav: schedule -> GPU -> saveWav
 //   auto pcm = r.render(markers);                     // the float PCM exportWav builds (app.cpp:1200-1207)
 //
-// The real-time playback path (App::playback, app.cpp:254-292: 1024-sample SDL callbacks) stays on
-// the CPU in the caller: it is latency-, not throughput-bound.
+//   double cur = cursorSec; auto buf = r.refill(markers, cur, dur + 1500, &cur);
+//                                                     // App::playback's refill loop (app.cpp:272-274):
+//                                                     // process() calls chained from `cur` until enough
+//                                                     // samples exist; cur leaves as the loop's tmpCursor
+//
+// refill() is meant for rendering ahead (seconds per call) from the UI or a worker thread; the
+// 1024-sample SDL callback itself (App::playback, app.cpp:254-292) keeps copying out of a restWav-like
+// buffer on the audio thread — it is latency-, not throughput-bound.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <span>
 #include <string>
@@ -35,6 +42,9 @@ public:
   std::vector<float> render(const std::vector<Marker> &markers) const;
   std::vector<int16_t> render16(const std::vector<Marker> &markers) const;
   bool exportWav(const std::string &fileName, const std::vector<Marker> &markers) const;
+  // what App::playback appends to an empty restWav when asked for `need` samples at warped time `cursor`
+  std::vector<float> refill(const std::vector<Marker> &markers, double cursor, std::size_t need,
+                            double *cursorEnd = nullptr) const;
 
 private:
   std::vector<float> host;  // the schedule's nextGrainFirstSample lookups read the source audio
@@ -42,7 +52,8 @@ private:
   mx_ctx *ctx = nullptr;
   mx_audio *audio = nullptr;
   std::vector<int32_t> starts, lens;
-  bool run(const std::vector<Marker> &markers, std::vector<float> *f32, std::vector<int16_t> *i16) const;
+  bool run(const std::vector<Marker> &markers, std::vector<float> *f32, std::vector<int16_t> *i16, double cursor0 = 0.,
+           int64_t need = -1, double *cursorEnd = nullptr) const;
 };
 
 }  // namespace melonix

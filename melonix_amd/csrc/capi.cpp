@@ -586,6 +586,14 @@ int mx_grains_dev(mx_ctx *ctx, const mx_audio *a, int32_t **starts, int32_t **le
 int mx_schedule_build(const float *host_wav, int64_t n, int sampleRate, const int32_t *grain_starts,
                       const int32_t *grain_lens, int64_t ngrains, const mx_marker *markers, int nmarkers,
                       mx_step **steps, int64_t *nsteps, int64_t *nsamples) {
+  return mx_schedule_build_from(host_wav, n, sampleRate, grain_starts, grain_lens, ngrains, markers, nmarkers, 0., -1,
+                                steps, nsteps, nsamples, nullptr);
+}
+
+int mx_schedule_build_from(const float *host_wav, int64_t n, int sampleRate, const int32_t *grain_starts,
+                           const int32_t *grain_lens, int64_t ngrains, const mx_marker *markers, int nmarkers,
+                           double cursor0, int64_t need, mx_step **steps, int64_t *nsteps, int64_t *nsamples,
+                           double *cursor_end) {
   if (!steps || !nsteps || !nsamples || n < 0 || ngrains < 0 || nmarkers < 0 || (n > 0 && !host_wav) ||
       (ngrains > 0 && (!grain_starts || !grain_lens)) || (nmarkers > 0 && !markers))
     return fail(MX_ERR_INVALID, "bad argument");
@@ -600,7 +608,7 @@ int mx_schedule_build(const float *host_wav, int64_t n, int sampleRate, const in
     int64_t total = 0;
     const auto t1 = std::chrono::steady_clock::now();
     const int rc = build_schedule(host_wav, n, sampleRate, grain_starts, grain_lens, ngrains, markers, nmarkers, v,
-                                  total, err);
+                                  total, err, cursor0, need, cursor_end);
     const auto t2 = std::chrono::steady_clock::now();
     if (tr)
       fprintf(stderr, "mx_schedule_build: validate %.2f ms, recurrence %.2f ms (%zu steps)\n",

@@ -187,7 +187,8 @@ int64_t step_size(float rate, int32_t L) {
 
 int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *gstarts,
                    const int32_t *glens, int64_t ngrains, const mx_marker *markers, int nmarkers,
-                   std::vector<mx_step> &steps, int64_t &nsamples, std::string &err) {
+                   std::vector<mx_step> &steps, int64_t &nsamples, std::string &err, double cursor0, int64_t need,
+                   double *cursor_end) {
   steps.clear();
   nsamples = 0;
   if (sampleRate <= 0) { err = "sampleRate must be positive"; return MX_ERR_INVALID; }
@@ -212,10 +213,11 @@ int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *g
     return gstarts + i;
   };
 
-  double cursor = 0.;  // app.cpp:1201
+  double cursor = cursor0;  // app.cpp:1201 (0) / :272 (playback position)
   int64_t hint = 0;
   float lastBend = 0.f, lastRate = powf(2, 0.f / 12);
   for (;;) {
+    if (need >= 0 && nsamples >= need) break;  // app.cpp:273
     const float pitchBend = tm.time2pitchbend(cursor);
     // app.cpp:297; the same libm call on the same argument, made once per distinct bend
     const float rate = (pitchBend == lastBend) ? lastRate : powf(2, pitchBend / 12);
@@ -224,6 +226,9 @@ int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *g
     const int32_t *it1 = first_ge(tm.time2sample(cursor), hint);  // app.cpp:298-301
     if (it1 == gend) {
       nsamples += 1500;  // app.cpp:303-309: preferredGrainSize zeros, then dt = 0 ends the export
+      if (need >= 0) {       // playback: the loop simply asks again until it has enough samples
+        if (nsamples < need) nsamples += 1500 * ((need - nsamples + 1499) / 1500);
+      }
       break;
     }
     const int64_t g = it1 - gstarts;
@@ -247,9 +252,10 @@ int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *g
     st.out_offset = nsamples;
     steps.push_back(st);
     nsamples += sz;
-    if (dt <= 0.) break;  // app.cpp:1204
-    cursor += dt;         // app.cpp:1206
+    if (need < 0 && dt <= 0.) break;  // app.cpp:1204
+    cursor += dt;                     // app.cpp:1206 / :274
   }
+  if (cursor_end) *cursor_end = cursor;
   return MX_OK;
 }
 

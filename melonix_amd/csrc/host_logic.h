@@ -79,9 +79,14 @@ void grains_from_bitmaps(const ZcBitmaps &zc, std::vector<int32_t> &starts, std:
                          const std::function<void()> &need_zc3 = {});
 
 // The export loop's serial recurrence.  Returns MX_OK or MX_ERR_INVALID.
+// need < 0: App::exportWav's loop — cursor from cursor0 (0 there) until a process() call finds no grain
+// (its 1500 zeros are counted in nsamples).  need >= 0: App::playback's refill loop (app.cpp:272-274) —
+// calls chained from cursor0 until nsamples >= need; a call that finds no grain adds 1500 zeros and
+// leaves the cursor where it is, as often as the loop asks.  cursor_end: the loop's cursor on exit.
 int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *gstarts,
                    const int32_t *glens, int64_t ngrains, const mx_marker *markers, int nmarkers,
-                   std::vector<mx_step> &steps, int64_t &nsamples, std::string &err);
+                   std::vector<mx_step> &steps, int64_t &nsamples, std::string &err, double cursor0 = 0.,
+                   int64_t need = -1, double *cursor_end = nullptr);
 
 // Number of samples one process() call emits: #{ i >= 0 : floor(float(i)*rate) < L }
 // (app.cpp:313-322), in closed form + exact float correction.  Returns -1 when the

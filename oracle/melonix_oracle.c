@@ -545,8 +545,11 @@ static void fvec_push(fvec *v, float x) {
   v->p[v->n++] = x;
 }
 
-int mxo_export_run(const float *wav, long n, int sampleRate, const mxo_marker *markers,
-                   int nmarkers, int memo, mxo_export *out) {
+/* need < 0: App::exportWav's loop (app.cpp:1200-1207), cursor from 0 until process() returns 0.
+ * need >= 0: App::playback's refill loop (app.cpp:272-274): tmpCursor = cursor0;
+ *            while (restWav.size() < need) tmpCursor += process(tmpCursor, restWav);  (restWav empty at entry) */
+static int run_chain(const float *wav, long n, int sampleRate, const mxo_marker *markers,
+                     int nmarkers, int memo, double cursor0, long need, mxo_export *out) {
   int *gs = NULL, *gl = NULL;
   const long ng = mxo_grains(wav, n, &gs, &gl);
   mxo_timemap *tm = mxo_timemap_new(markers, nmarkers, sampleRate, n, memo);
@@ -555,14 +558,16 @@ int mxo_export_run(const float *wav, long n, int sampleRate, const mxo_marker *m
   mxo_step *steps = (mxo_step *)malloc(sizeof(mxo_step) * (size_t)scap);
   const float bias = 0.f; /* app.hpp:66, never assigned */
 
-  double cursor = 0.; /* app.cpp:1201 */
+  double cursor = cursor0; /* app.cpp:1201 / :272 */
   for (;;) {
+    if (need >= 0 && pcm.n >= need) break; /* app.cpp:273 */
     /* ---- App::process(cursor, pcm), app.cpp:294-345 ---- */
     const float pitchBend = mxo_time2pitchbend(tm, cursor);
     const float rate = powf(2, pitchBend / 12);
     const long g1 = grain_lower_bound(gs, ng, mxo_time2sample(tm, cursor));
     if (g1 == ng) { /* app.cpp:303-309 */
       for (int i = 0; i < PREFERRED_GRAIN; ++i) fvec_push(&pcm, 0.f);
+      if (need >= 0) continue; /* playback: returns 0, tmpCursor stays, the while loop asks again */
       break; /* returns 0 -> exportWav's dt<=0 break, app.cpp:1204 */
     }
     const float *grain = wav + gs[g1];
@@ -596,10 +601,11 @@ int mxo_export_run(const float *wav, long n, int sampleRate, const mxo_marker *m
     }
     st->sz = sz2;
     const double dt = 1. * sz2 / sampleRate; /* app.cpp:344 */
-    if (dt <= 0.) break;
-    cursor += dt; /* app.cpp:1206 */
+    if (need < 0 && dt <= 0.) break; /* app.cpp:1204 */
+    cursor += dt; /* app.cpp:1206 / :274 */
   }
 
+  out->cursor_end = cursor;
   out->nsteps = ns;
   out->steps = steps;
   out->nsamples = pcm.n;
@@ -608,6 +614,17 @@ int mxo_export_run(const float *wav, long n, int sampleRate, const mxo_marker *m
   free(gs);
   free(gl);
   return 0;
+}
+
+int mxo_export_run(const float *wav, long n, int sampleRate, const mxo_marker *markers,
+                   int nmarkers, int memo, mxo_export *out) {
+  return run_chain(wav, n, sampleRate, markers, nmarkers, memo, 0., -1, out);
+}
+
+int mxo_playback_fill(const float *wav, long n, int sampleRate, const mxo_marker *markers,
+                      int nmarkers, int memo, double cursor0, long need, mxo_export *out) {
+  if (need < 0) return -1;
+  return run_chain(wav, n, sampleRate, markers, nmarkers, memo, cursor0, need, out);
 }
 
 void mxo_export_free(mxo_export *e) {

@@ -115,12 +115,18 @@ typedef struct mxo_export {
   mxo_step *steps;
   long nsamples;     /* incl. the 1500 trailing zeros of the terminating process() call */
   float *pcm;
+  double cursor_end; /* the loop's cursor after the last call */
 } mxo_export;
 
 /* Replays App::exportWav's loop (app.cpp:1200-1207) incl. the final
  * "no grain left" call that appends 1500 zeros (app.cpp:303-309). */
 int mxo_export_run(const float *wav, long n, int sampleRate, const mxo_marker *markers,
                    int nmarkers, int memo, mxo_export *out);
+/* Replays App::playback's refill loop (app.cpp:272-274) from an empty restWav: process() calls chained
+ * from warped time cursor0 until at least `need` samples exist.  A call that finds no grain left appends
+ * 1500 zeros and leaves the cursor where it is (app.cpp:303-309), as often as the loop asks. */
+int mxo_playback_fill(const float *wav, long n, int sampleRate, const mxo_marker *markers,
+                      int nmarkers, int memo, double cursor0, long need, mxo_export *out);
 void mxo_export_free(mxo_export *);
 
 /* app.cpp:1209-1212 */

@@ -45,7 +45,8 @@ class Step(C.Structure):
 
 
 class Export(C.Structure):
-    _fields_ = [("nsteps", C.c_long), ("steps", C.POINTER(Step)), ("nsamples", C.c_long), ("pcm", C.POINTER(C.c_float))]
+    _fields_ = [("nsteps", C.c_long), ("steps", C.POINTER(Step)), ("nsamples", C.c_long), ("pcm", C.POINTER(C.c_float)),
+                ("cursor_end", C.c_double)]
 
 
 STEP_DTYPE = np.dtype(
@@ -86,6 +87,8 @@ def lib():
         L.mxo_free.argtypes = [C.c_void_p]
         L.mxo_export_run.argtypes = [fp, C.c_long, C.c_int, C.POINTER(Marker), C.c_int, C.c_int, C.POINTER(Export)]
         L.mxo_export_free.argtypes = [C.POINTER(Export)]
+        L.mxo_playback_fill.argtypes = [fp, C.c_long, C.c_int, C.POINTER(Marker), C.c_int, C.c_int, C.c_double, C.c_long,
+                                        C.POINTER(Export)]
         L.mxo_pcm_to_i16.argtypes = [fp, C.c_long, C.POINTER(C.c_int16)]
         L.mxo_save_wav.argtypes = [C.c_char_p, C.POINTER(C.c_int16), C.c_long, C.c_int]
         L.mxo_wav_bytes.restype = C.c_long
@@ -230,6 +233,20 @@ def export_run(wav, sr, markers, memo=True):
     pcm = np.ctypeslib.as_array(e.pcm, shape=(max(e.nsamples, 1),))[: e.nsamples].copy()
     lib().mxo_export_free(C.byref(e))
     return steps, pcm
+
+
+def playback_fill(wav, sr, markers, cursor0, need, memo=False):
+    """App::playback's refill loop (app.cpp:272-274) from an empty restWav: -> (steps, pcm, cursor_end)."""
+    wav, p = _f32(wav)
+    e = Export()
+    rc = lib().mxo_playback_fill(p, len(wav), sr, _markers(markers), len(markers), 1 if memo else 0, float(cursor0),
+                                 int(need), C.byref(e))
+    assert rc == 0
+    steps = np.frombuffer(C.string_at(e.steps, e.nsteps * C.sizeof(Step)), dtype=STEP_DTYPE).copy() if e.nsteps else np.zeros(0, STEP_DTYPE)
+    pcm = np.ctypeslib.as_array(e.pcm, shape=(e.nsamples,)).copy() if e.nsamples else np.zeros(0, np.float32)
+    end = float(e.cursor_end)
+    lib().mxo_export_free(C.byref(e))
+    return steps, pcm, end
 
 
 def calc_picks(wav):

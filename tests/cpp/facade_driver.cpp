@@ -134,6 +134,12 @@ int main(int argc, char **argv) {
     std::vector<Marker> mk = {{1, 0, 0, 3.0}, {(int)wav.size() - 1, 0, 0, 3.0}};
     check(rs.exportWav(out + "/export.wav", mk), "exportWav");
     dump(out + "/pcm.f32", rs.render(mk));
+    // App::playback's refill (app.cpp:272-274) for one 1024-sample callback at t = 2.5 s
+    double cur = 2.5;
+    const std::vector<float> rest = rs.refill(mk, cur, 1024 + 1500, &cur);
+    check(rest.size() >= 2524 && cur > 2.5, "refill renders at least dur + preferredGrainSize samples");
+    dump(out + "/refill.f32", rest);
+    dump(out + "/refill_cursor.f64", std::vector<double>{cur});
     std::vector<int32_t> g = rs.grainStarts();
     dump(out + "/grains.i32", g);
   }

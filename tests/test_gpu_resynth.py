@@ -148,3 +148,21 @@ def test_resynth_long_and_fallback_grains_bit_exact(gpu_ctx, oracle, mxlib):
         only16 = gpu_ctx.resynth(a, st, total, want_f32=False)[1]
         assert np.array_equal(only16, i16)
     a.free()
+
+
+def test_playback_buffers_bit_exact(gpu_ctx, oracle, mxlib):
+    """A playback refill (app.cpp:272-274) rendered on the GPU: the schedule chain from an arbitrary cursor
+    through the resynthesis kernel gives the oracle's restWav bit for bit, trailing zeros included."""
+    w = noisy(accum_sweep(10 * SR), level=0.02)
+    n = len(w)
+    mk = [(1, 0, 0, 2.0), (n // 3, 0, -0.1, -5.0), (n - 1, 0, 0, 0.0)]
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    for cursor0, need in ((0.0, 2524), (2.71828, 2524), (4.0, 96000), (9.97, 6000)):
+        st, total, end = mxlib.schedule_build_from(w, SR, s, l, mk, cursor0, need)
+        f32, i16 = gpu_ctx.resynth(a, st, total)
+        osteps, opcm, oend = oracle.playback_fill(w, SR, mk, cursor0, need)
+        assert total == len(opcm) and end == oend
+        assert np.array_equal(f32.view(np.uint32), opcm.view(np.uint32))
+        assert np.array_equal(i16, oracle.pcm_to_i16(opcm))
+    a.free()

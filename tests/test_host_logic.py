@@ -169,3 +169,34 @@ def test_bin_note_law(mxlib):
             assert abs(b - 55 * 2 ** ((note - 24) / 12) * N / SR) < 1e-9 * b
     assert mxlib.note_bin(36.0, 4096, SR) * SR / 4096 == pytest.approx(110.0)  # an octave above note 24 = 55 Hz
     assert mxlib.bin_note(0, 4096, SR) == -math.inf
+
+
+@pytest.mark.parametrize("pb", [0.0, 3.0, -4.0])
+def test_playback_refill_chain(mxlib, oracle, sweep10, pb):
+    """App::playback's refill loop (app.cpp:272-274): process() calls chained from an arbitrary cursor until
+    at least dur + 1500 samples exist — schedule, sample count and exit cursor equal the oracle's; chaining
+    refills from each exit cursor walks the same steps as one export; past the last grain only zeros come."""
+    n = len(sweep10)
+    mk = [(1, 0, 0, pb), (n // 2, 0, 0.3, pb + 1.0), (n - 1, 0, 0, pb)]
+    s, l = mxlib.grains_host(sweep10)
+    for cursor0, need in ((0.0, 1024 + 1500), (1.2345, 1024 + 1500), (5.0, 48000), (9.9, 4096), (0.0, 0), (3.3, 1)):
+        steps, total, end = mxlib.schedule_build_from(sweep10, SR, s, l, mk, cursor0, need)
+        osteps, opcm, oend = oracle.playback_fill(sweep10, SR, mk, cursor0, need)
+        assert _same_steps(steps, osteps) and total == len(opcm) and end == oend
+        assert total >= need and (need == 0 or total - need < 2250 + 1500)
+    # audio callbacks in a row: every refill continues where the previous one stopped
+    cur, chain = 0.0, []
+    for _ in range(40):
+        steps, total, cur = mxlib.schedule_build_from(sweep10, SR, s, l, mk, cur, 2524)
+        chain.append(steps)
+    chain = np.concatenate(chain)
+    full, _ = mxlib.schedule_build(sweep10, SR, s, l, mk)
+    for f in ("cursor", "grain_start", "grain_len", "rate", "next_first", "sz"):
+        assert np.array_equal(chain[f], full[f][: len(chain)])
+    # beyond the last grain: no steps, zeros in multiples of 1500 (app.cpp:303-309), cursor stays
+    steps, total, end = mxlib.schedule_build_from(sweep10, SR, s, l, mk, 60.0, 4000)
+    assert len(steps) == 0 and total == 4500 and end == 60.0
+    # need < 0 from 0 is the export loop itself
+    a = mxlib.schedule_build_from(sweep10, SR, s, l, mk, 0.0, -1)
+    b = mxlib.schedule_build(sweep10, SR, s, l, mk)
+    assert _same_steps(a[0], b[0]) and a[1] == b[1]
