@@ -137,7 +137,7 @@ void stft_kernel(const StftArgs a0) {
   // (spec-cache.cpp:77-96) applied to the four consecutive bins a lane holds, 12 bytes per lane.
   const bool want_rows = a.mags != nullptr || (CMAP && a.rgb != nullptr);
   auto flush_row = [&](int64_t fr, int tt) {  // after a barrier that follows the scatter of frame fr
-#ifdef MX_EXP_DIRECTOUT
+#if defined(MX_EXP_DIRECTOUT) || defined(MX_ABL_NOOUTLDS)
     if (false) {
 #else
     if (want_rows) {
@@ -332,6 +332,19 @@ void stft_kernel(const StftArgs a0) {
     // consecutive bins, conflict-free), then every lane owns 4 consecutive bins and the row
     // leaves as global_store_dwordx4, 1 KiB contiguous per wavefront instruction, instead of E
     // dword stores with one stray element each (thread 0's self-paired bins).
+#ifdef MX_ABL_NOOUTLDS
+    // ablation (wrong rows): what the output path would cost with the transposition for free — four
+    // 16-byte stores per lane straight from the magnitude registers
+    if (a.mags) {
+      using f32x4 = float __attribute__((ext_vector_type(4)));
+      f32x4 *row4 = reinterpret_cast<f32x4 *>(a.mags + (size_t)f * (size_t)(N / 2)) + t;
+#pragma unroll
+      for (int i = 0; i < C::E / 4; ++i) {
+        f32x4 q = {mg[4 * i], mg[4 * i + 1], mg[4 * i + 2], mg[4 * i + 3]};
+        __builtin_nontemporal_store(q, &row4[C::T * i]);
+      }
+    }
+#endif
 #ifdef MX_EXP_DIRECTOUT
     if (a.mags) {  // experiment: E dword stores per lane straight to the row, no LDS transposition
       float *row = a.mags + (size_t)f * (size_t)(N / 2);
@@ -345,6 +358,9 @@ void stft_kernel(const StftArgs a0) {
         else __builtin_nontemporal_store(mg[2 * s + 1], &(s < H ? mlo : mhi)[-C::NS3 * s]);
       }
     }
+    if (false) {
+      float *plo = lout + out_lo, *phi = lout + out_hi;
+#elif defined(MX_ABL_NOOUTLDS)
     if (false) {
       float *plo = lout + out_lo, *phi = lout + out_hi;
 #else
