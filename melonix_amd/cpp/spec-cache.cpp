@@ -48,15 +48,16 @@ struct SpecCache::Impl {
     const double left = key * rangeTime / width;
     const double pixel = rangeTime / width;
     const int start = time2Sample(left), end = time2Sample(left + pixel);
-    const std::vector<float> row = spec.getSpec(start, end);
-    if (row.empty()) {
+    // the texels normally come out of the same launch as the magnitudes (colormap fused into the STFT
+    // kernel); only a row computed before this cache registered its scale is fetched by value and
+    // coloured here, as the reference colours every row (spec-cache.cpp:67-96)
+    const int state = spec.requestTexRow(start, end, k, texels);
+    if (state == 0) {
       texels.assign(16 * 3, 0);  // not ready: 16 black texels, retried on the next draw
     } else {
       c.filled = true;
-      // the texels normally come out of the same launch as the magnitudes (colormap fused into the STFT
-      // kernel); a row computed before this cache registered its scale is coloured here, as the
-      // reference colours every row (spec-cache.cpp:77-96)
-      if (!spec.getTexRow(start, end, k, texels)) {
+      if (state == 2) {
+        const std::vector<float> row = spec.getSpec(start, end);
         texels.resize(row.size() * 3);
         melonixColormap(row.data(), row.size(), k, texels.data());
       }

@@ -3,6 +3,9 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_set>
@@ -11,10 +14,17 @@
 #include "melonix_amd.h"
 
 struct Spec::Impl {
+  // One worker batch lands in one slab (the device->host copies write straight into it); the cached
+  // rows are views into the slab, which lives until the last of them is evicted.  Allocated without
+  // value-initialisation: every byte is overwritten by the copy.
+  struct Slab {
+    std::unique_ptr<float[]> mags;
+    std::unique_ptr<unsigned char[]> rgb;
+  };
   struct Row {
-    std::vector<float> mags;         // empty = requested, not computed yet
-    std::vector<unsigned char> rgb;  // texels of the same launch (empty unless a scale was set)
-    float k = 0.f;                   // the scale rgb was computed with
+    std::shared_ptr<const Slab> slab;  // null = requested, not computed yet
+    std::size_t index = 0;             // row number inside the slab
+    float k = 0.f;                     // the scale the slab's texels were computed with (0: none)
   };
 
   int N;
@@ -35,8 +45,6 @@ struct Spec::Impl {
   void drainLoop() {
     std::vector<Range> batch;
     std::vector<int32_t> flat;
-    std::vector<float> mags;
-    std::vector<unsigned char> rgb;
     const std::size_t bins = static_cast<std::size_t>(N) / 2;
     while (alive) {
       {
@@ -53,27 +61,31 @@ struct Spec::Impl {
         flat.push_back(r.first);
         flat.push_back(r.second);
       }
-      mags.resize(batch.size() * bins);
+      const bool trace = std::getenv("MELONIX_TIMING") != nullptr;
+      const auto t0 = std::chrono::steady_clock::now();
+      auto slab = std::make_shared<Slab>();
+      slab->mags.reset(new float[batch.size() * bins]);
       const float k = texScale.load();
       const auto count = static_cast<int64_t>(batch.size());
       if (k != 0.f) {  // one launch: magnitude rows for getSpec + texel rows for the SpecCache
-        rgb.resize(batch.size() * bins * 3);
-        if (mx_stft_ranges_rgb_mags(ctx, audio, N, flat.data(), count, k, mags.data(), rgb.data()) != MX_OK) continue;
-      } else if (mx_stft_ranges(ctx, audio, N, flat.data(), count, -1, -1, mags.data(), nullptr) != MX_OK) {
+        slab->rgb.reset(new unsigned char[batch.size() * bins * 3]);
+        if (mx_stft_ranges_rgb_mags(ctx, audio, N, flat.data(), count, k, slab->mags.get(), slab->rgb.get()) != MX_OK)
+          continue;
+      } else if (mx_stft_ranges(ctx, audio, N, flat.data(), count, -1, -1, slab->mags.get(), nullptr) != MX_OK) {
         continue;
       }
+      const auto t1 = std::chrono::steady_clock::now();
       std::lock_guard<std::mutex> lk(mu);
       for (std::size_t i = 0; i < batch.size(); ++i)
         if (Row *slot = rows.peek(batch[i])) {  // may have been evicted meanwhile (spec.cpp:91-93)
-          slot->mags.assign(mags.begin() + static_cast<std::ptrdiff_t>(i * bins),
-                            mags.begin() + static_cast<std::ptrdiff_t>((i + 1) * bins));
+          slot->slab = slab;
+          slot->index = i;
           slot->k = k;
-          if (k != 0.f)
-            slot->rgb.assign(rgb.begin() + static_cast<std::ptrdiff_t>(i * bins * 3),
-                             rgb.begin() + static_cast<std::ptrdiff_t>((i + 1) * bins * 3));
-          else
-            slot->rgb.clear();
         }
+      if (trace)
+        fprintf(stderr, "Spec worker: %zu columns, device call %.2f ms, cache fill %.2f ms\n", batch.size(),
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     }
   }
 };
@@ -101,7 +113,12 @@ bool Spec::ok() const { return impl->usable(); }
 auto Spec::getSpec(int start, int end) const -> std::vector<float> {
   const Range key{start, end};
   std::lock_guard<std::mutex> lk(impl->mu);
-  if (const Impl::Row *row = impl->rows.touch(key)) return row->mags;  // a copy; may still be empty
+  if (const Impl::Row *row = impl->rows.touch(key)) {  // a copy; {} while the row is still being computed
+    if (!row->slab) return {};
+    const std::size_t bins = static_cast<std::size_t>(impl->N) / 2;
+    const float *p = row->slab->mags.get() + row->index * bins;
+    return std::vector<float>(p, p + bins);
+  }
   impl->rows.insert(key, {});
   impl->pending.insert(key);
   if (impl->rows.size() > static_cast<std::size_t>(MaxRanges))
@@ -115,7 +132,28 @@ void Spec::setTexScale(float k) { impl->texScale = k; }
 bool Spec::getTexRow(int start, int end, float k, std::vector<unsigned char> &rgb) const {
   std::lock_guard<std::mutex> lk(impl->mu);
   const Impl::Row *row = impl->rows.peek(Range{start, end});
-  if (!row || row->rgb.empty() || row->k != k) return false;
-  rgb = row->rgb;
+  if (!row || !row->slab || !row->slab->rgb || row->k != k) return false;
+  const std::size_t nb = static_cast<std::size_t>(impl->N) / 2 * 3;
+  const unsigned char *p = row->slab->rgb.get() + row->index * nb;
+  rgb.assign(p, p + nb);
   return true;
+}
+
+int Spec::requestTexRow(int start, int end, float k, std::vector<unsigned char> &rgb) const {
+  const Range key{start, end};
+  std::lock_guard<std::mutex> lk(impl->mu);
+  if (const Impl::Row *row = impl->rows.touch(key)) {
+    if (!row->slab) return 0;
+    if (!row->slab->rgb || row->k != k) return 2;
+    const std::size_t nb = static_cast<std::size_t>(impl->N) / 2 * 3;
+    const unsigned char *p = row->slab->rgb.get() + row->index * nb;
+    rgb.assign(p, p + nb);
+    return 1;
+  }
+  impl->rows.insert(key, {});  // the same bookkeeping as getSpec's miss path (spec.cpp:30-41)
+  impl->pending.insert(key);
+  if (impl->rows.size() > static_cast<std::size_t>(MaxRanges))
+    if (auto old = impl->rows.evictOldest()) impl->pending.erase(old->first);
+  impl->wake.notify_one();
+  return 0;
 }

@@ -38,6 +38,10 @@ public:
   // the caller then colours the getSpec row itself, as the reference does).
   void setTexScale(float k);
   bool getTexRow(int start, int end, float k, std::vector<unsigned char> &rgb) const;
+  // getSpec's queue/LRU behaviour without the 64 KiB by-value copy, for a caller that only wants the
+  // texels: 0 = not computed yet (the key is queued exactly as getSpec queues it), 1 = rgb filled,
+  // 2 = the magnitudes are there but no texel row for this k (ask getSpec and colour them yourself).
+  int requestTexRow(int start, int end, float k, std::vector<unsigned char> &rgb) const;
 
   int fftSize() const;
   bool ok() const;  // false when no MI355X context / upload failed

@@ -63,6 +63,14 @@ struct mx_ctx {
   // pages that are already mapped runs at PCIe rate, a fresh 2 x n/8-byte buffer pays ~3 ms of faults
   std::mutex zc_mu;
   mx::ZcBitmaps zc_scratch;
+  // device staging of the host-pointer entry points (mx_stft_ranges, mx_stft_hop, mx_stft_ranges_rgb*):
+  // grow-only buffers kept between calls — a screen-sized batch otherwise spends more time in
+  // hipMalloc/hipFree than in the kernel.  One host-staged call per context at a time.
+  std::mutex stage_mu;
+  struct Stage {
+    void *p = nullptr;
+    size_t cap = 0;
+  } stage[4];
 };
 
 struct mx_audio {
@@ -192,6 +200,30 @@ int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_
 // frames per host-staging chunk: keep the device staging buffer <= ~1 GiB
 int64_t chunk_frames(int N) { return std::max<int64_t>(1, (int64_t)(1ull << 30) / ((int64_t)(N / 2) * 4)); }
 
+// Staging slot `i` with room for `bytes` (contents undefined).  Caller holds ctx->stage_mu.
+hipError_t stage_get(mx_ctx *ctx, int i, size_t bytes, void **out) {
+  mx_ctx::Stage &st = ctx->stage[i];
+  if (st.cap < bytes) {
+    if (st.p) hipFree(st.p);
+    st.p = nullptr;
+    st.cap = 0;
+    const hipError_t e = hipMalloc(&st.p, bytes);
+    if (e != hipSuccess) return e;
+    st.cap = bytes;
+  }
+  *out = st.p;
+  return hipSuccess;
+}
+// Bulk jobs stage up to 1 GiB per buffer: give those back, keep what a screen of columns needs.
+void stage_trim(mx_ctx *ctx) {
+  for (auto &st : ctx->stage)
+    if (st.cap > ((size_t)256 << 20)) {
+      hipFree(st.p);
+      st.p = nullptr;
+      st.cap = 0;
+    }
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -239,6 +271,7 @@ void mx_ctx_destroy(mx_ctx *ctx) {
     hipFree(kv.second.wext);
   }
   for (auto &kv : ctx->wtabs) hipFree(kv.second);
+  for (auto &st : ctx->stage) hipFree(st.p);
   hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -375,13 +408,11 @@ static int stft_host_common(mx_ctx *ctx, const mx_audio *a, int N, bool ranges_m
   int32_t *d_ranges = nullptr;
   const size_t row = (size_t)(N / 2);
   hipError_t e = hipSuccess;
-  if (mags_out) e = hipMalloc(&d_mags, (size_t)chunk * row * sizeof(float));
-  if (e == hipSuccess && pitch_out) e = hipMalloc(&d_pitch, (size_t)chunk * sizeof(mx_pitch));
-  if (e == hipSuccess && ranges_mode) e = hipMalloc(&d_ranges, (size_t)chunk * 2 * sizeof(int32_t));
-  if (e != hipSuccess) {
-    hipFree(d_mags); hipFree(d_pitch); hipFree(d_ranges);
-    return fail(MX_ERR_NOMEM, "device staging buffers: %s", hipGetErrorString(e));
-  }
+  std::lock_guard<std::mutex> slk(ctx->stage_mu);
+  if (mags_out) e = stage_get(ctx, 0, (size_t)chunk * row * sizeof(float), (void **)&d_mags);
+  if (e == hipSuccess && pitch_out) e = stage_get(ctx, 1, (size_t)chunk * sizeof(mx_pitch), (void **)&d_pitch);
+  if (e == hipSuccess && ranges_mode) e = stage_get(ctx, 2, (size_t)chunk * 2 * sizeof(int32_t), (void **)&d_ranges);
+  if (e != hipSuccess) return fail(MX_ERR_NOMEM, "device staging buffers: %s", hipGetErrorString(e));
   rc = MX_OK;
   for (int64_t done = 0; done < count && rc == MX_OK; done += chunk) {
     const int64_t c = std::min(chunk, count - done);
@@ -402,7 +433,7 @@ static int stft_host_common(mx_ctx *ctx, const mx_audio *a, int N, bool ranges_m
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "result download: %s", hipGetErrorString(e));
   }
-  hipFree(d_mags); hipFree(d_pitch); hipFree(d_ranges);
+  stage_trim(ctx);
   return rc;
 }
 
@@ -442,13 +473,11 @@ int mx_stft_ranges_rgb_mags(mx_ctx *ctx, const mx_audio *a, int N, const int32_t
   float *d_mags = nullptr;
   uint8_t *d_rgb = nullptr;
   int32_t *d_ranges = nullptr;
-  hipError_t e = hipMalloc(&d_rgb, (size_t)chunk * row * 3);
-  if (e == hipSuccess && mags_out) e = hipMalloc(&d_mags, (size_t)chunk * row * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&d_ranges, (size_t)chunk * 2 * sizeof(int32_t));
-  if (e != hipSuccess) {
-    hipFree(d_mags); hipFree(d_rgb); hipFree(d_ranges);
-    return fail(MX_ERR_NOMEM, "device staging buffers: %s", hipGetErrorString(e));
-  }
+  std::lock_guard<std::mutex> slk(ctx->stage_mu);
+  hipError_t e = stage_get(ctx, 3, (size_t)chunk * row * 3, (void **)&d_rgb);
+  if (e == hipSuccess && mags_out) e = stage_get(ctx, 0, (size_t)chunk * row * sizeof(float), (void **)&d_mags);
+  if (e == hipSuccess) e = stage_get(ctx, 2, (size_t)chunk * 2 * sizeof(int32_t), (void **)&d_ranges);
+  if (e != hipSuccess) return fail(MX_ERR_NOMEM, "device staging buffers: %s", hipGetErrorString(e));
   for (int64_t done = 0; done < count && rc == MX_OK; done += chunk) {
     const int64_t c = std::min(chunk, count - done);
     e = hipMemcpyAsync(d_ranges, ranges + 2 * done, (size_t)c * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
@@ -462,7 +491,7 @@ int mx_stft_ranges_rgb_mags(mx_ctx *ctx, const mx_audio *a, int N, const int32_t
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "texel download: %s", hipGetErrorString(e));
   }
-  hipFree(d_mags); hipFree(d_rgb); hipFree(d_ranges);
+  stage_trim(ctx);
   return rc;
 }
 

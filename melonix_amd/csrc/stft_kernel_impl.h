@@ -153,6 +153,8 @@ void stft_kernel(const StftArgs a0) {
         for (int i = 0; i < C::M / 4 / C::T; ++i) {
 #if defined(MX_ABL_NOGSTORE)
           asm volatile("" ::"v"(q[i]), "v"(row4));
+#elif defined(MX_EXP_PLAINSTORE)
+          row4[C::T * i] = q[i];
 #else
           __builtin_nontemporal_store(q[i], &row4[C::T * i]);
 #endif
