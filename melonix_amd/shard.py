@@ -62,3 +62,51 @@ def shard_steps(nsteps: int, rank: int, world: int):
     base, extra = divmod(nsteps, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+@dataclass(frozen=True)
+class StepShard:
+    rank: int
+    world: int
+    lo: int        # first step
+    hi: int        # one past the last step
+    pcm_lo: int    # global index of the first output sample this rank renders
+    pcm_hi: int    # one past the last (the last rank also owns the trailing zeros of the export)
+
+    @property
+    def samples(self) -> int:
+        return self.pcm_hi - self.pcm_lo
+
+
+def shard_schedule(steps, total: int, rank: int, world: int):
+    """Rank's part of an export schedule (mx_schedule_build): a contiguous step range and the PCM range it
+    fills.  Every rank builds the same schedule on its host (it is a deterministic scalar recurrence), so
+    no sizes are exchanged.  Returns (StepShard, local_steps): local_steps is the rank's slice with
+    out_offset rebased to its own PCM buffer, ready for mx_resynth(_dev) with nsamples = shard.samples.
+    Source audio: a step reads its grain [grain_start, grain_start + grain_len) from the rank's device
+    image — either the whole signal, or a time shard whose pads cover the neighbouring grain."""
+    lo, hi = shard_steps(len(steps), rank, world)
+    body = int(steps["out_offset"][-1] + steps["sz"][-1]) if len(steps) else 0
+    pcm_lo = int(steps["out_offset"][lo]) if lo < len(steps) else body
+    pcm_hi = int(steps["out_offset"][hi]) if hi < len(steps) else body
+    if rank == world - 1:
+        pcm_hi = int(total)  # the terminating process() call's zeros (app.cpp:303-309)
+    local = steps[lo:hi].copy()
+    local["out_offset"] -= pcm_lo
+    return StepShard(rank, world, lo, hi, pcm_lo, pcm_hi), local
+
+
+def gather_pcm(dist, local, shards):
+    """The PCM all-gather of SURVEY 8e(2): ranks' int16 (or f32) shards -> the whole stream on every rank.
+    `local` is this rank's 1-D torch tensor of shards[rank].samples elements; equal-sized exchange (padded
+    to the largest shard), true counts come from `shards` (known everywhere, see shard_schedule)."""
+    import torch
+
+    world = len(shards)
+    m = max(s.samples for s in shards)
+    buf = torch.zeros(m, dtype=local.dtype, device=local.device)
+    buf[: local.numel()] = local
+    out = torch.empty(world * m, dtype=local.dtype, device=local.device)
+    # exchanged as bytes: the payload is opaque to the collective (and gloo has no int16)
+    dist.all_gather_into_tensor(out.view(torch.uint8), buf.view(torch.uint8))
+    return torch.cat([out[r * m: r * m + shards[r].samples] for r in range(world)])

@@ -54,6 +54,20 @@ def _worker(rank, world, port, N, hop, n, q):
     dist.destroy_process_group()
 
 
+def _collect(procs, q, timeout=240):
+    """First queue item, failing at once (not after the timeout) if a worker dies."""
+    import queue as _q
+    import time as _t
+    t0 = _t.time()
+    while True:
+        try:
+            return q.get(timeout=1.0)
+        except _q.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"worker exited with {dead}"
+            assert _t.time() - t0 < timeout, "workers timed out"
+
+
 @pytest.mark.parametrize("N,hop,n", [(4096, 256, 48000 + 100), (4096, 375, 40000)])
 def test_two_rank_shards_equal_unsharded(oracle, N, hop, n):
     import torch.multiprocessing as mp
@@ -64,7 +78,7 @@ def test_two_rank_shards_equal_unsharded(oracle, N, hop, n):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, N, hop, n, q)) for r in range(2)]
     for p in procs:
         p.start()
-    track, _, s0 = q.get(timeout=240)
+    track, _, s0 = _collect(procs, q)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -90,3 +104,56 @@ def test_shard_arithmetic():
         for world in (1, 2, 8):
             r = [sh.shard_steps(nsteps, k, world) for k in range(world)]
             assert r[0][0] == 0 and r[-1][1] == nsteps and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
+def _pcm_worker(rank, world, port, pb, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import accum_sweep as sweep
+    import melonix_amd as mx
+    from melonix_amd import shard as sh
+    from oracle import pyoracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = sweep(10 * SR)
+    mk = [(1, 0, 0, pb), (len(w) - 1, 0, 0, pb)]
+    gs, gl = mx.grains_host(w)
+    steps, total = mx.schedule_build(w, SR, gs, gl, mk)  # identical on every rank
+    shards = [sh.shard_schedule(steps, total, r, world)[0] for r in range(world)]
+    mine, local_steps = sh.shard_schedule(steps, total, rank, world)
+    # stand-in for the rank's GPU render of its steps (no GPU here): the oracle's samples of that range
+    _, opcm = O.export_run(w, SR, mk)
+    i16 = torch.from_numpy(O.pcm_to_i16(opcm)[mine.pcm_lo:mine.pcm_hi].copy())
+    assert i16.numel() == mine.samples
+    assert local_steps["out_offset"][0] == 0 and (np.diff(local_steps["out_offset"]) == local_steps["sz"][:-1]).all()
+    whole = sh.gather_pcm(dist, i16, shards)
+    if rank == 0:
+        q.put((whole.numpy(), [(s.lo, s.hi, s.pcm_lo, s.pcm_hi) for s in shards], total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pcm_gather_equals_export(oracle):
+    """contiguous step ranges per rank, disjoint PCM ranges, one all-gather -> the export's
+    int16 stream (trailing zeros included) on every rank."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pcm_worker, args=(r, 2, port, 3.0, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    whole, parts, total = _collect(procs, q)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = accum_sweep(10 * SR)
+    _, opcm = oracle.export_run(w, SR, [(1, 0, 0, 3.0), (len(w) - 1, 0, 0, 3.0)])
+    assert total == len(opcm) == 478903 and len(whole) == total
+    assert np.array_equal(whole, oracle.pcm_to_i16(opcm))
+    assert parts[0][2] == 0 and parts[0][3] == parts[1][2] and parts[1][3] == total and parts[0][1] == parts[1][0]

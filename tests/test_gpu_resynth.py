@@ -166,3 +166,29 @@ def test_playback_buffers_bit_exact(gpu_ctx, oracle, mxlib):
         assert np.array_equal(f32.view(np.uint32), opcm.view(np.uint32))
         assert np.array_equal(i16, oracle.pcm_to_i16(opcm))
     a.free()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_render_equals_whole(gpu_ctx, oracle, mxlib, world):
+    """The multi-GPU resynthesis path on one device: every rank's step range rendered on its own (offsets
+    rebased by shard_schedule) — the concatenation is the whole export, bit for bit."""
+    from melonix_amd import shard as sh
+    w = noisy(accum_sweep(10 * SR), level=0.02)
+    n = len(w)
+    mk = [(1, 0, 0, 4.0), (n // 2, 0, 0.2, -3.0), (n - 1, 0, 0, 1.0)]
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    steps, total = mxlib.schedule_build(w, SR, s, l, mk)
+    f_all, i_all = gpu_ctx.resynth(a, steps, total)
+    f_parts, i_parts = [], []
+    for r in range(world):
+        shd, local = sh.shard_schedule(steps, total, r, world)
+        f, i = gpu_ctx.resynth(a, local, shd.samples)
+        assert len(f) == shd.samples
+        f_parts.append(f)
+        i_parts.append(i)
+    assert np.array_equal(np.concatenate(f_parts).view(np.uint32), f_all.view(np.uint32))
+    assert np.array_equal(np.concatenate(i_parts), i_all)
+    _, opcm = oracle.export_run(w, SR, mk)
+    assert np.array_equal(f_all.view(np.uint32), opcm.view(np.uint32))
+    a.free()
