@@ -205,6 +205,20 @@ int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate,
                   const mx_marker *markers, int nmarkers, const char *path,
                   int strict_reference_header);
 
+/* ---- phase-vocoder pitch shift (BUILD-DEFINED) ------------------------------------
+ * The reference has no phase vocoder (its pitch shift is the granular resampler above); BASELINE.json's
+ * north_star names one, so the build defines it: N = 4096, synthesis hop 256, periodic Hann analysis and
+ * synthesis windows, time-stretch by r = 2^(semitones/12) with integer phase propagation, overlap-add,
+ * linear resampling by r back to the input length (definition: oracle/pv_oracle.py).  Constant shift over
+ * the whole file; output has mx_audio_length(a) samples.  int16 = (int16)(clamp(v,-1,1) * 32767.).
+ * Parity is unpinned by construction: the only oracle is the build's own CPU restatement. */
+int mx_pv_pitch_shift(mx_ctx *ctx, const mx_audio *a, double semitones, float *pcm_f32_out,
+                      int16_t *pcm_i16_out);
+/* Same, outputs stay in HBM (either may be NULL); blocks until done.  The work buffers (about 44 KiB per
+ * 256 output samples) stay with the context for the next call and are released by mx_ctx_destroy. */
+int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32,
+                          int16_t *d_pcm_i16);
+
 /* ---- waveform min/max pyramid ---------------------------------------------------
  * Replaces App::calcPicks (app.cpp:347-378): level l = floor(n / 2^(l+1)) {min,max} pairs over blocks
  * of 2^(l+1) samples, for every l with n > 2^(l+1).  picks_out (host, caller-allocated, 2*n floats

@@ -170,6 +170,18 @@ class Context:
         _capi.check(_capi.lib().mx_resynth_dev(self.handle, audio.handle, C.c_void_p(d_steps), nsteps, nsamples,
                                                C.c_void_p(d_f32 or 0), C.c_void_p(d_i16 or 0)))
 
+    def pv_pitch_shift(self, audio: Audio, semitones: float, want_f32: bool = True, want_i16: bool = True):
+        """Build-defined phase-vocoder pitch shift (no reference counterpart) -> (f32 | None, int16 | None)."""
+        f32 = np.empty(audio.n, dtype=np.float32) if want_f32 else None
+        i16 = np.empty(audio.n, dtype=np.int16) if want_i16 else None
+        _capi.check(_capi.lib().mx_pv_pitch_shift(self.handle, audio.handle, float(semitones), _ptr(f32), _ptr(i16)))
+        return f32, i16
+
+    def pv_pitch_shift_dev(self, audio: Audio, semitones: float, d_f32: int | None, d_i16: int | None):
+        _capi.check(_capi.lib().mx_pv_pitch_shift_dev(self.handle, audio.handle, float(semitones),
+                                                      C.c_void_p(d_f32) if d_f32 else None,
+                                                      C.c_void_p(d_i16) if d_i16 else None))
+
     def minmax_pyramid(self, audio: Audio):
         """App::calcPicks on the GPU -> list of (count_l, 2) float32 arrays {min,max}, one per level."""
         picks = np.empty(2 * max(audio.n, 1), dtype=np.float32)

@@ -86,6 +86,8 @@ SIGNATURES = {
     "mx_resynth": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mx_resynth_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mx_export_wav": (_i, [_vp, _vp, _i64, _i, _vp, _i, C.c_char_p, _i]),
+    "mx_pv_pitch_shift": (_i, [_vp, _vp, _d, _vp, _vp]),
+    "mx_pv_pitch_shift_dev": (_i, [_vp, _vp, _d, _vp, _vp]),
     "mx_minmax_pyramid": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "mx_minmax_pyramid_dev": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "mx_minmax_range": (None, [_vp, _i64, _vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f)]),

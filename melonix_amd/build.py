@@ -31,11 +31,13 @@ UNITS = [
     # bit-exact PCM: no FMA contraction in the resampler
     ("resynth_kernels.hip", "hip", ["-ffp-contract=off"]),
     ("colormap_kernel.hip", "hip", ["-ffp-contract=off"]),
+    # build-defined phase vocoder: shares the FFT passes of stft_core.h (explicit FMAs)
+    ("pv_kernels.hip", "hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
     ("capi.cpp", "hip", []),
     # pure host logic: plain g++, no contraction, no -march (SURVEY §7 "Bit-exact schedule")
     ("host_logic.cpp", "cxx", ["-ffp-contract=off"]),
 ]
-HEADERS = ["kernels.h", "stft_kernel_impl.h", "stft_core.h", "stft_tables.h", "stft_consts.inc", "host_logic.h",
+HEADERS = ["kernels.h", "colormap_core.h", "stft_kernel_impl.h", "stft_core.h", "stft_tables.h", "stft_consts.inc", "host_logic.h",
            os.path.join("..", "..", "include", "melonix_amd.h")]
 
 

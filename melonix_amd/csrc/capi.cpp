@@ -71,6 +71,10 @@ struct mx_ctx {
     void *p = nullptr;
     size_t cap = 0;
   } stage[4];
+  // work buffers of the phase vocoder (tens of GB for an hour of audio): hipMalloc of that size takes of the
+  // order of a second, so the arena is kept for the next call; mx_ctx_destroy releases it
+  std::mutex pv_mu;
+  Stage pv_arena;
 };
 
 struct mx_audio {
@@ -272,6 +276,7 @@ void mx_ctx_destroy(mx_ctx *ctx) {
   }
   for (auto &kv : ctx->wtabs) hipFree(kv.second);
   for (auto &st : ctx->stage) hipFree(st.p);
+  hipFree(ctx->pv_arena.p);
   hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -506,6 +511,105 @@ int mx_colormap_dev(mx_ctx *ctx, const float *d_mags, int64_t nbins_total, float
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(launch_colormap(d_mags, d_rgb, nbins_total, k, ctx->stream));
   return MX_OK;
+}
+
+// ---- build-defined phase-vocoder pitch shift (no reference counterpart) ---------------------------
+int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32, int16_t *d_pcm_i16) {
+  if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
+  if (!(semitones >= -48.0 && semitones <= 48.0)) return fail(MX_ERR_INVALID, "semitones out of range [-48, 48]");
+  if (a->n == 0 || (!d_pcm_f32 && !d_pcm_i16)) return MX_OK;
+  constexpr int N = 4096, M = N / 2, Hs = 256;
+  NTables t;
+  int rc = get_tables(ctx, N, t);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const double r = std::pow(2.0, semitones / 12.0);
+  const int64_t F = (int64_t)std::ceil((double)a->n * r / Hs) + 1;
+  std::vector<int64_t> apos((size_t)F);
+  for (int64_t f = 0; f < F; ++f) apos[(size_t)f] = (int64_t)std::floor((double)(f * Hs) / r);
+  std::vector<float> hann((size_t)N), hann_sc((size_t)N);
+  for (int j = 0; j < N; ++j) {
+    hann[(size_t)j] = (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * j / N));
+    hann_sc[(size_t)j] = hann[(size_t)j] * fold_scale(N);  // exact: a power of two
+  }
+  PvArgs p{};
+  p.audio = a->d_padded;
+  p.n = a->n;
+  p.ratio = r;
+  p.frames = F;
+  p.tw2 = t.tw2;
+  p.tw3 = t.tw3;
+  p.ubase = t.ubase;
+  p.scan_chunk = 512;
+  p.s_len = F * Hs + N;
+  p.pcm_f32 = d_pcm_f32;
+  p.pcm_i16 = d_pcm_i16;
+  const int64_t nchunks = (F + p.scan_chunk - 1) / p.scan_chunk;
+  // one arena: apos, the two windows, mags, phase, phi, chunk sums, frames, s (+1 for s[m+1]), frame peaks
+  const size_t rowsz = (size_t)F * M;
+  size_t off = 0;
+  auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_apos = take((size_t)F * 8), o_h = take(N * 4), o_hs = take(N * 4), o_m = take(rowsz * 4),
+               o_p = take(rowsz * 4), o_i = take(rowsz * 4), o_c = take((size_t)nchunks * M * 4),
+               o_f = take((size_t)F * N * 4), o_s = take(((size_t)p.s_len + 1) * 4),
+               o_x = take((size_t)F * 4), o_a = take((size_t)nchunks * M);
+  std::lock_guard<std::mutex> plk(ctx->pv_mu);
+  if (ctx->pv_arena.cap < off) {
+    if (ctx->pv_arena.p) hipFree(ctx->pv_arena.p);
+    ctx->pv_arena = {};
+    const hipError_t em = hipMalloc(&ctx->pv_arena.p, off);
+    if (em != hipSuccess) {
+      ctx->pv_arena = {};
+      return fail(MX_ERR_NOMEM, "phase-vocoder work buffers (%zu MiB): %s", off >> 20, hipGetErrorString(em));
+    }
+    ctx->pv_arena.cap = off;
+  }
+  char *arena = static_cast<char *>(ctx->pv_arena.p);
+  hipError_t e = hipMemcpyAsync(arena + o_apos, apos.data(), (size_t)F * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(arena + o_h, hann.data(), N * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hs, hann_sc.data(), N * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(arena + o_s + (size_t)p.s_len * 4, 0, 4, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(arena + o_x, 0, (size_t)F * 4, ctx->stream);
+  p.fmax = reinterpret_cast<float *>(arena + o_x);
+  p.chunk_any = reinterpret_cast<uint8_t *>(arena + o_a);
+  p.apos = reinterpret_cast<const int64_t *>(arena + o_apos);
+  p.hann = reinterpret_cast<const float *>(arena + o_h);
+  p.hann_scaled = reinterpret_cast<const float *>(arena + o_hs);
+  p.mags = reinterpret_cast<float *>(arena + o_m);
+  p.phase = reinterpret_cast<uint32_t *>(arena + o_p);
+  p.phi = reinterpret_cast<uint32_t *>(arena + o_i);
+  p.chunk_sums = reinterpret_cast<uint32_t *>(arena + o_c);
+  p.frames_out = reinterpret_cast<float *>(arena + o_f);
+  p.s = reinterpret_cast<float *>(arena + o_s);
+  if (e == hipSuccess) e = launch_pv(p, ctx->stream);
+  // the host tables above must outlive the copies queued on the stream
+  const hipError_t es = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = es;
+  if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(e));
+  return MX_OK;
+}
+
+int mx_pv_pitch_shift(mx_ctx *ctx, const mx_audio *a, double semitones, float *pcm_f32_out, int16_t *pcm_i16_out) {
+  if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
+  if (a->n == 0 || (!pcm_f32_out && !pcm_i16_out)) return MX_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  float *d_f = nullptr;
+  int16_t *d_i = nullptr;
+  hipError_t e = hipSuccess;
+  if (pcm_f32_out) e = hipMalloc(&d_f, (size_t)a->n * sizeof(float));
+  if (e == hipSuccess && pcm_i16_out) e = hipMalloc(&d_i, (size_t)a->n * sizeof(int16_t));
+  if (e != hipSuccess) {
+    hipFree(d_f); hipFree(d_i);
+    return fail(MX_ERR_NOMEM, "device PCM buffers: %s", hipGetErrorString(e));
+  }
+  int rc = mx_pv_pitch_shift_dev(ctx, a, semitones, d_f, d_i);
+  if (rc == MX_OK) {
+    if (d_f) e = hipMemcpy(pcm_f32_out, d_f, (size_t)a->n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && d_i) e = hipMemcpy(pcm_i16_out, d_i, (size_t)a->n * sizeof(int16_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
+  }
+  hipFree(d_f); hipFree(d_i);
+  return rc;
 }
 
 // ---- time maps -----------------------------------------------------------------

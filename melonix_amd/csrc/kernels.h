@@ -54,6 +54,32 @@ struct ResynthArgs {
 };
 hipError_t launch_resynth(const ResynthArgs &a, hipStream_t s);
 
+// Build-defined phase-vocoder pitch shifter (pv_kernels.hip; no reference counterpart).
+struct PvArgs {
+  const float *audio;  // padded image (zeros in the pads)
+  int64_t n;
+  double ratio;            // r = 2^(semitones/12)
+  const int64_t *apos;     // analysis centres a_f = floor(f*Hs/r), frames entries
+  int64_t frames;
+  const float *hann_scaled;  // periodic Hann * 1/(2N): the analysis window with the transform's folded scale
+  const float *hann;         // periodic Hann (synthesis window)
+  const float2 *tw2, *tw3, *ubase;  // Plan<4096,16> tables
+  float *mags;        // [frames][N/2]
+  uint32_t *phase;    // [frames][N/2] analysis phases, turns * 2^32
+  uint32_t *phi;      // [frames][N/2] synthesis phases (output of the scan)
+  float *fmax;        // [frames] peak magnitude of the frame (zeroed before pv_analysis)
+  uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2]
+  uint8_t *chunk_any;    // same shape: the chunk contains a restart
+  int scan_chunk;
+  float *frames_out;  // [frames][N] windowed synthesis frames
+  float *s;           // stretched signal, s_len = frames*Hs + N, index 0 = stretched time -N/2
+  int64_t s_len;
+  float *pcm_f32;     // n, may be null
+  int16_t *pcm_i16;   // n, may be null
+  int frames_per_block;
+};
+hipError_t launch_pv(const PvArgs &a, hipStream_t s);
+
 // spec-cache.cpp:77-96 colormap: nbins_total magnitudes -> 3*nbins_total bytes (both device).
 hipError_t launch_colormap(const float *mags, uint8_t *rgb, int64_t nbins_total, float k, hipStream_t s);
 

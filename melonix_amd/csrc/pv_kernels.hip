@@ -1,0 +1,287 @@
+// pv_kernels.hip — BUILD-DEFINED phase-vocoder pitch shifter.
+//
+// The reference has no phase vocoder: its pitch shift is the granular resampler of app.cpp:294-345,
+// which resynth_kernels.hip reproduces bit for bit.  BASELINE.json's north_star names a phase-vocoder /
+// overlap-add resynthesis, so the build defines one; its only oracle is the build's own restatement
+// (oracle/pv_oracle.py, whose header is the definition: N = 4096, Hs = 256, stretch by r then resample
+// by r).  PARITY UNPINNED — there is no reference arithmetic to match.
+//
+// Stages (all frame-parallel; the phase recurrence is an integer prefix sum over frames, so the parallel
+// scan gives exactly the serial result):
+//   pv_analysis   one workgroup walks consecutive frames: Hann-windowed frame at a_f -> the LDS-resident
+//                 real FFT of stft_core.h -> |X|/N and arg X as uint32 turns, rows [F][N/2]
+//   pv_scan_*     per (frame, bin): wrapped deviation from the bin's nominal advance -> synthesis phase
+//                 advance (integer arithmetic); a bin accumulates only while it is active in this frame
+//                 and the previous one (|X| >= 1e-3 of the frame's peak), otherwise it restarts from its
+//                 analysis phase.  Chunked SEGMENTED inclusive scan of those steps along the frame axis
+//                 (uint32 wrap = mod 1 turn); the steps are recomputed in both sweeps, never stored
+//   pv_synthesis  |X| e^{i Phi} -> inverse real FFT (the same three passes run on the conjugated,
+//                 pre-split spectrum) -> Hann-windowed frame, row [F][N]
+//   pv_ola        overlap-add of the 16 frames that cover a stretched sample, in frame order
+//                 (deterministic: no atomics), normalised by sum w^2 = 3N/(8 Hs)
+//   pv_resample   linear interpolation at i*r -> f32 / int16 PCM
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "stft_core.h"
+
+namespace mx {
+namespace {
+
+using PV = Plan<4096, 16>;
+constexpr int kPvN = 4096, kPvM = kPvN / 2, kPvHs = 256;
+static_assert(kPlan4096E == 16, "pv kernels use the 16-points-per-thread tables of N = 4096");
+
+__device__ __forceinline__ uint32_t to_turns(float re, float im) {
+  // arg in turns, rounded to 2^-32 (the float carries 24 bits of it); atan2f(0,0) = 0
+  const float turns = atan2f(im, re) * 0.15915494309189535f;
+  return (uint32_t)(int64_t)llrintf(turns * 4294967296.0f);
+}
+
+__global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
+  using P = PV;
+  __shared__ __attribute__((aligned(16))) float2 lds[P::M];
+  const int t = threadIdx.x;
+  const bool wave0 = __builtin_amdgcn_readfirstlane(t) < 64;
+  cpx u[P::R3];
+  post_twiddles<P>(t, a.ubase, u);
+  const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_block;
+  const int64_t f1 = f0 + a.frames_per_block < a.frames ? f0 + a.frames_per_block : a.frames;
+  for (int64_t f = f0; f < f1; ++f) {
+    const float *x = a.audio + MX_AUDIO_PAD + (a.apos[f] - P::N / 2);
+    cpx Y[P::E], v[P::E];
+    load_frame<P, 1, false>(t, Y, x, a.hann_scaled);
+    pass1<P>(Y, v);
+    __syncthreads();  // every wave is past the previous frame's load_t2
+    store_t1<P>(t, v, lds);
+    __syncthreads();
+    load_t1<P>(t, v, lds);
+    __syncthreads();
+    pass2<P>(t, v, a.tw2);
+    store_t2<P>(t, v, lds);
+    __syncthreads();
+    load_t2<P>(t, v, lds);
+    cpx X[P::E];
+    if (wave0) {
+      pass3<P, true>(t, v, a.tw3);
+      post_cplx<P, true>(t, v, u, X);
+    } else {
+      pass3<P, false>(t, v, a.tw3);
+      post_cplx<P, false>(t, v, u, X);
+    }
+    float *mrow = a.mags + (size_t)f * P::M;
+    uint32_t *prow = a.phase + (size_t)f * P::M;
+    float mx = 0.f;
+#pragma unroll
+    for (int o = 0; o < P::E; ++o) {
+      const int k = out_bin<P>(t, o);
+      const float m = fast_sqrt(cnorm2(X[o]));
+      mrow[k] = m;
+      prow[k] = to_turns(X[o].x, X[o].y);
+      mx = m > mx ? m : mx;
+    }
+    // the frame's peak magnitude (non-negative floats order like their bit patterns); fmax is zeroed beforehand
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float o = __shfl_xor(mx, d);
+      mx = o > mx ? o : mx;
+    }
+    if ((t & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(a.fmax) + f, __float_as_uint(mx));
+  }
+}
+
+// One step of a bin's phase bookkeeping.  A bin that is active (|X| >= 1e-3 * frame peak) in this frame and the
+// previous one advances its synthesis phase by
+//   d   = int32(P_f - P_{f-1} - (k*h mod N) * 2^32/N)        deviation from the nominal advance over h samples
+//   inc = (k*Hs mod N) * 2^32/N + trunc(d * Hs / h)
+// (d*Hs < 2^39 and the quotient's distance to the next integer is >= 1/h, far above a binary64 ulp, so the
+// truncated binary64 quotient IS the C integer quotient); any other bin, and every bin of frame 0, restarts from
+// its analysis phase.  Returns true for a restart; `val` is the new phase (restart) or the advance.
+constexpr float kPvActiveRel = 1e-3f;
+struct PvBinState {
+  uint32_t p;  // analysis phase of the previous frame
+  bool act;    // the bin was active in the previous frame
+};
+__device__ __forceinline__ bool pv_step(const PvArgs &a, int k, int64_t f, PvBinState &st, uint32_t &val) {
+  const size_t i = (size_t)f * kPvM + k;
+  const uint32_t p = a.phase[i];
+  const bool act = a.mags[i] >= kPvActiveRel * a.fmax[f];
+  const bool cont = f > 0 && act && st.act;
+  if (cont) {
+    constexpr uint32_t unit = (uint32_t)(4294967296ull / kPvN);
+    const int64_t h = a.apos[f] - a.apos[f - 1];
+    const uint32_t expect = (uint32_t)(((int64_t)k * h) & (kPvN - 1)) * unit;
+    const int32_t d = (int32_t)(p - st.p - expect);
+    const int64_t q = (int64_t)(((double)d * (double)kPvHs) / (double)h);
+    val = (uint32_t)(((int64_t)k * kPvHs) & (kPvN - 1)) * unit + (uint32_t)(int32_t)q;
+  } else {
+    val = p;
+  }
+  st.p = p;
+  st.act = act;
+  return !cont;
+}
+__device__ __forceinline__ PvBinState pv_state_before(const PvArgs &a, int k, int64_t f) {  // state after frame f-1
+  PvBinState st{0u, false};
+  if (f > 0) {
+    const size_t i = (size_t)(f - 1) * kPvM + k;
+    st.p = a.phase[i];
+    st.act = a.mags[i] >= kPvActiveRel * a.fmax[f - 1];
+  }
+  return st;
+}
+
+// Segmented inclusive scan of those steps along the frame axis, per bin, in chunks of a.scan_chunk frames.  The
+// operator on (restart, value) pairs — (r1,v1)+(r2,v2) = (r1|r2, r2 ? v2 : v1+v2) — is associative, so chunk
+// totals are combined before the chunks are swept again; a thread walks one bin, so the previous frame's phase
+// and activity are simply the previous iteration's.
+__global__ __launch_bounds__(256) void pv_scan_sums(const PvArgs a) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int64_t c = blockIdx.y;
+  const int64_t r0 = c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
+  PvBinState st = pv_state_before(a, k, r0);
+  uint32_t acc = 0, any = 0;
+  for (int64_t r = r0; r < r1; ++r) {
+    uint32_t v;
+    if (pv_step(a, k, r, st, v)) { acc = v; any = 1; }
+    else acc += v;
+  }
+  a.chunk_sums[c * kPvM + k] = acc;
+  a.chunk_any[c * kPvM + k] = (uint8_t)any;
+}
+__global__ __launch_bounds__(256) void pv_scan_chunks(const PvArgs a, int64_t nchunks) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  uint32_t carry = 0;
+  for (int64_t c = 0; c < nchunks; ++c) {  // carry into chunk c = phase at the end of chunk c-1
+    const uint32_t v = a.chunk_sums[c * kPvM + k];
+    const bool any = a.chunk_any[c * kPvM + k] != 0;
+    a.chunk_sums[c * kPvM + k] = carry;
+    carry = any ? v : carry + v;
+  }
+}
+__global__ __launch_bounds__(256) void pv_scan_apply(const PvArgs a) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int64_t c = blockIdx.y;
+  const int64_t r0 = c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
+  PvBinState st = pv_state_before(a, k, r0);
+  uint32_t acc = a.chunk_sums[c * kPvM + k];
+  for (int64_t r = r0; r < r1; ++r) {
+    uint32_t v;
+    acc = pv_step(a, k, r, st, v) ? v : acc + v;
+    a.phi[r * kPvM + k] = acc;
+  }
+}
+
+// One synthesis coefficient Yhat[k] = |X[k]|/N * e^{2 pi i Phi/2^32}; the Nyquist bin (k = M) is zero.
+__device__ __forceinline__ cpx pv_coef(const float *mrow, const uint32_t *prow, int k) {
+  if (k >= kPvM) return mk(0.f, 0.f);
+  const float m = mrow[k];
+  const float turns = (float)(int32_t)prow[k] * 2.3283064365386963e-10f;  // [-1/2, 1/2)
+  // v_sin_f32 / v_cos_f32 take their argument in turns
+  return mk(m * __builtin_amdgcn_cosf(turns), m * __builtin_amdgcn_sinf(turns));
+}
+
+// y[j] = sum_{k<N} Yhat[k] e^{+2 pi i jk/N} (Hermitian extension, real).  Packed z[m] = y[2m] + i y[2m+1] is
+// 2*conj(DFT_M(conj Z')) with Z'[c] = (A+B)/2 + i e^{+2 pi i c/N} (A-B)/2, A = Yhat[c], B = conj(Yhat[M-c]):
+// the forward passes of stft_core.h run on G[c] = conj((A+B) + i w_c (A-B)) and the frame is conj of the result.
+__global__ __launch_bounds__(PV::T) void pv_synthesis(const PvArgs a) {
+  using P = PV;
+  __shared__ __attribute__((aligned(16))) float2 lds[P::M];
+  const int t = threadIdx.x;
+  const bool wave0 = __builtin_amdgcn_readfirstlane(t) < 64;
+  cpx wc[P::E];  // e^{+2 pi i c/N}, c = t + T*e
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    float sn, cs;
+    sincospif(2.0f * (float)(t + P::T * e) / (float)P::N, &sn, &cs);
+    wc[e] = mk(cs, sn);
+  }
+  const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_block;
+  const int64_t f1 = f0 + a.frames_per_block < a.frames ? f0 + a.frames_per_block : a.frames;
+  for (int64_t f = f0; f < f1; ++f) {
+    const float *mrow = a.mags + (size_t)f * P::M;
+    const uint32_t *prow = a.phi + (size_t)f * P::M;
+    cpx Y[P::E], v[P::E];
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      const int c = t + P::T * e;
+      const cpx A = pv_coef(mrow, prow, c);
+      const cpx B = cconj(pv_coef(mrow, prow, P::M - c));
+      const cpx Sm = cadd(A, B), Dm = csub(A, B);
+      const cpx wd = cmul(wc[e], Dm);              // w_c (A-B)
+      Y[e] = mk(Sm.x - wd.y, -(Sm.y + wd.x));      // conj((A+B) + i*wd)
+    }
+    pass1<P>(Y, v);
+    __syncthreads();
+    store_t1<P>(t, v, lds);
+    __syncthreads();
+    load_t1<P>(t, v, lds);
+    __syncthreads();
+    pass2<P>(t, v, a.tw2);
+    store_t2<P>(t, v, lds);
+    __syncthreads();
+    load_t2<P>(t, v, lds);
+    if (wave0) pass3<P, true>(t, v, a.tw3);
+    else pass3<P, false>(t, v, a.tw3);
+    // v[r] = D[k0p + NS3 r], v[q_index(r)] = D[k0q + NS3 r]; sample pair m: y[2m] = Re D[m], y[2m+1] = -Im D[m]
+    const int kp = k0p<P>(t), kq = k0q<P>(t);
+    float2 *row = reinterpret_cast<float2 *>(a.frames_out + (size_t)f * P::N);
+    const float2 *w2 = reinterpret_cast<const float2 *>(a.hann);
+#pragma unroll
+    for (int r = 0; r < P::R3; ++r) {
+      const int mp = kp + P::NS3 * r, mq = kq + P::NS3 * r;
+      const cpx dp = v[r], dq = v[q_index<P>(r)];
+      const float2 hp = w2[mp], hq = w2[mq];
+      row[mp] = make_float2(dp.x * hp.x, -dp.y * hp.y);
+      row[mq] = make_float2(dq.x * hq.x, -dq.y * hq.y);
+    }
+  }
+}
+
+// s[q] (q = stretched time + N/2) = sum over the frames f with f*Hs <= q < f*Hs + N, in frame order.
+__global__ __launch_bounds__(256) void pv_ola(const PvArgs a) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.s_len) return;
+  int64_t fl = (q - kPvN + kPvHs) / kPvHs;  // smallest f with f*Hs + N > q
+  if (q - kPvN + 1 <= 0) fl = 0;
+  int64_t fh = q / kPvHs;
+  if (fh > a.frames - 1) fh = a.frames - 1;
+  float acc = 0.f;
+  for (int64_t f = fl; f <= fh; ++f) acc += a.frames_out[(size_t)f * kPvN + (q - f * kPvHs)];
+  a.s[q] = acc * (1.0f / (3.0f * kPvN / (8.0f * kPvHs)));
+}
+
+__global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const double pos = (double)i * a.ratio + (double)(kPvN / 2);
+  const double fl = floor(pos);
+  const int64_t m = (int64_t)fl;
+  const float tt = (float)(pos - fl);
+  const float v = (1.0f - tt) * a.s[m] + tt * a.s[m + 1];
+  if (a.pcm_f32) a.pcm_f32[i] = v;
+  if (a.pcm_i16) {
+    const float c = v < -1.f ? -1.f : (1.f < v ? 1.f : v);  // the reference's cast is UB beyond +-1 (app.cpp:1211)
+    a.pcm_i16[i] = (int16_t)((double)c * 32767.);
+  }
+}
+
+}  // namespace
+
+hipError_t launch_pv(const PvArgs &a0, hipStream_t s) {
+  PvArgs a = a0;
+  if (a.frames <= 0 || a.n <= 0) return hipSuccess;
+  a.frames_per_block = 8;
+  const unsigned fb = (unsigned)((a.frames + a.frames_per_block - 1) / a.frames_per_block);
+  const int64_t nchunks = (a.frames + a.scan_chunk - 1) / a.scan_chunk;
+  hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
+  hipLaunchKernelGGL(pv_scan_sums, dim3(kPvM / 256, (unsigned)nchunks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(pv_scan_chunks, dim3(kPvM / 256), dim3(256), 0, s, a, nchunks);
+  hipLaunchKernelGGL(pv_scan_apply, dim3(kPvM / 256, (unsigned)nchunks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(pv_synthesis, dim3(fb), dim3(PV::T), 0, s, a);
+  hipLaunchKernelGGL(pv_ola, dim3((unsigned)((a.s_len + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(pv_resample, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace mx

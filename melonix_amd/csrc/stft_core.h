@@ -792,6 +792,39 @@ MX_HD void post(int t, const cpx (&v)[P::E], const cpx (&u)[P::R3], float (&mg)[
   PostSlot<P, 0>::run(MAY0 && t == 0, v, u, mg);
 }
 
+// The same split with the complex bins kept (phase-vocoder analysis, pv_kernels.hip):
+// X[2s] = X[k_s]/N, X[2s+1] = X[M-k_s]/N, same slot -> bin map as post() (out_bin), thread 0's
+// slot R3/2 again yields bin 0 and bin M/2 (X[M/2] = conj(Z[M/2])) instead of the Nyquist bin.
+template <class P, int S>
+struct PostSlotC {
+  static MX_HD void run(bool t0, const cpx (&v)[P::E], const cpx (&u)[P::R3], cpx (&X)[P::E]) {
+    constexpr int R = P::R3, H = R / 2;
+    cpx A, B;
+    if constexpr (S < H) {
+      A = csel(t0, v[q_index<P>(S)], v[S]);
+      B = v[q_index<P>(R - 1 - S)];
+    } else {
+      A = csel(t0, v[S - H], v[S]);
+      B = csel(t0, v[(3 * H - S) & (R - 1)], v[q_index<P>(R - 1 - S)]);
+    }
+    B = cconj(B);
+    const cpx Sm = cadd(A, B);
+    const cpx Dm = csub(A, B);
+    const cpx D = cmul(u[S], Dm);
+    X[2 * S] = csub(Sm, D);
+    X[2 * S + 1] = cconj(cadd(Sm, D));
+    if constexpr (S == H) {
+      const cpx z = v[H];
+      X[2 * S + 1] = csel(t0, mk(2.0f * z.x, -2.0f * z.y), X[2 * S + 1]);
+    }
+    if constexpr (S + 1 < R) PostSlotC<P, S + 1>::run(t0, v, u, X);
+  }
+};
+template <class P, bool MAY0 = true>
+MX_HD void post_cplx(int t, const cpx (&v)[P::E], const cpx (&u)[P::R3], cpx (&X)[P::E]) {
+  PostSlotC<P, 0>::run(MAY0 && t == 0, v, u, X);
+}
+
 // Bin of output slot o (= 2s or 2s+1) of thread t:
 //   even o: k_s = (s < R3/2 ? lo : hi) + NS3*s;  odd o: M - k_s  (thread 0, s = R3/2: M/2)
 // with lo = hi = t for t > 0 and lo = NS3/2, hi = -(R3/2)*NS3 for thread 0.

@@ -1,0 +1,126 @@
+"""pv_oracle.py — CPU restatement (numpy, binary64) of the BUILD-DEFINED phase-vocoder pitch shifter.
+
+TEST INFRASTRUCTURE ONLY (same rule as melonix_oracle.h): tests/ and bench.py's CPU leg may import this;
+nothing under melonix_amd/ may.
+
+PARITY UNPINNED: the reference has no phase vocoder (its pitch shift is the granular
+resampler of app.cpp:294-345, which melonix_amd reproduces bit for bit).  BASELINE.json's north_star names a
+phase-vocoder / overlap-add resynthesis, so this build defines one; there is no reference arithmetic to match
+and this file is the only oracle it can have.  The definition (N = 4096, Hs = 256, ratio r = 2^(st/12)):
+
+  frames f = 0..F-1, F = ceil(n*r/Hs) + 1
+  analysis centre   a_f = floor(f*Hs/r)                     (input advances Hs/r per frame: stretch by r)
+  frame             x_f[j] = w[j] * x[a_f - N/2 + j],  w = periodic Hann, zeros outside the file
+  spectrum          X_f[k] = sum_j x_f[j] e^{-2 pi i jk/N} / N,  k = 0..N/2-1    (Nyquist bin dropped)
+  phase in turns    P_f[k] = round(arg X_f[k] / 2pi * 2^32) mod 2^32          (uint32)
+  hop               h_f = a_f - a_{f-1}
+  deviation         d = int32( P_f - P_{f-1} - (k*h_f mod N) * 2^32/N )        (wraps to [-1/2, 1/2) turn)
+  synthesis advance inc = (k*Hs mod N) * 2^32/N + trunc(d * Hs / h_f)          (uint32, integer arithmetic)
+  active bin        act_f[k] = |X_f[k]| >= 1e-3 * max_k |X_f[k]|              (60 dB below the frame's peak)
+  synthesis phase   Phi_f = Phi_{f-1} + inc  where act_f and act_{f-1}, else Phi_f = P_f   (uint32 wrap = mod 1 turn)
+                    (a bin only accumulates while it carries signal and restarts from its analysis phase
+                     when signal arrives: the wrap of d is then never decided by rounding noise, and what a
+                     bin did while it was silent leaves no trace)
+  synthesis frame   y_f[j] = Re sum_k c_k |X_f[k]| e^{2 pi i (Phi_f[k]/2^32 + jk/N)},  c_0 = 1, c_k = 2
+  overlap-add       s[f*Hs - N/2 + j] += w[j] * y_f[j];   s /= sum_f w^2 = 3N/(8 Hs) = 6
+  resample          out[i] = (1-t) s[m] + t s[m+1],  m = floor(i*r), t = i*r - m,  i = 0..n-1
+
+The phase bookkeeping is integer, so a parallel segmented scan over frames gives exactly the serial result.
+"""
+import numpy as np
+
+N = 4096
+HS = 256
+
+
+def ratio(semitones: float) -> float:
+    return float(2.0 ** (float(semitones) / 12.0))
+
+
+def plan(n: int, r: float):
+    F = int(np.ceil(n * r / HS)) + 1
+    a = np.floor(np.arange(F, dtype=np.float64) * HS / r).astype(np.int64)
+    return F, a
+
+
+def window():
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(N) / N)
+
+
+def analysis(x, a, chunk=256):
+    """-> mags (F, N/2) f64 = |X|/N, phases (F, N/2) uint32 turns."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    w = window()
+    F = len(a)
+    mags = np.empty((F, N // 2))
+    ph = np.empty((F, N // 2), dtype=np.uint32)
+    xp = np.concatenate([np.zeros(N), x, np.zeros(N + HS)])  # zeros outside the file
+    j = np.arange(N)
+    for f0 in range(0, F, chunk):
+        af = a[f0:f0 + chunk]
+        idx = af[:, None] - N // 2 + j[None, :] + N  # a frame never leaves [-N/2, n + Hs + N/2)
+        fr = xp[idx] * w[None, :]
+        X = np.fft.rfft(fr, axis=1)[:, : N // 2] / N
+        mags[f0:f0 + chunk] = np.abs(X)
+        turns = np.angle(X) / (2.0 * np.pi)
+        ph[f0:f0 + chunk] = (np.rint(turns * 4294967296.0).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+    return mags, ph
+
+
+ACTIVE_REL = 1e-3
+
+
+def synthesis_phases(ph, a, mags):
+    """Integer phase propagation -> Phi (F, N/2) uint32."""
+    F = len(a)
+    act = mags >= np.float32(ACTIVE_REL) * mags.max(axis=1, keepdims=True)
+    k = np.arange(N // 2, dtype=np.int64)
+    unit = 4294967296 // N
+    h = np.diff(a)
+    assert (h >= 1).all(), "ratio too large: the analysis hop must stay >= 1 sample"
+    Phi = np.zeros((F, N // 2), dtype=np.uint32)
+    Phi[0] = ph[0]
+    for f in range(1, F):
+        expect = ((k * int(h[f - 1])) % N) * unit
+        d = (ph[f].astype(np.int64) - ph[f - 1].astype(np.int64) - expect) & 0xFFFFFFFF
+        d = np.where(d >= 2147483648, d - 4294967296, d)  # int32 reinterpretation
+        q = np.sign(d) * ((np.abs(d) * HS) // int(h[f - 1]))  # C's truncating int64 division
+        inc = (((k * HS) % N) * unit + q) & 0xFFFFFFFF
+        cont = act[f] & act[f - 1]
+        Phi[f] = np.where(cont, (Phi[f - 1].astype(np.int64) + inc) & 0xFFFFFFFF, ph[f]).astype(np.uint32)
+    return Phi
+
+
+def synthesis(mags, Phi, chunk=256):
+    """Overlap-added, normalised stretched signal s (index 0 = stretched time -N/2)."""
+    F = mags.shape[0]
+    w = window()
+    s = np.zeros(F * HS + N)
+    for f0 in range(0, F, chunk):
+        m = mags[f0:f0 + chunk]
+        Y = np.zeros((m.shape[0], N // 2 + 1), dtype=np.complex128)
+        Y[:, : N // 2] = m * np.exp(2j * np.pi * (Phi[f0:f0 + chunk].astype(np.float64) / 4294967296.0))
+        # irfft treats bin 0 (and the zeroed Nyquist) as real: Re of the one-sided sum with c_0 = 1, c_k = 2
+        y = np.fft.irfft(Y, n=N, axis=1) * N
+        for i in range(m.shape[0]):
+            f = f0 + i
+            s[f * HS: f * HS + N] += w * y[i]
+    return s / (3.0 * N / (8.0 * HS))
+
+
+def resample(s, n, r):
+    pos = np.arange(n, dtype=np.float64) * r + N // 2  # s[0] is stretched time -N/2
+    m = np.floor(pos).astype(np.int64)
+    t = pos - m
+    return (1.0 - t) * s[m] + t * s[m + 1]
+
+
+def pitch_shift(x, semitones):
+    """-> float64 PCM of len(x) samples."""
+    r = ratio(semitones)
+    F, a = plan(len(x), r)
+    mags, ph = analysis(x, a)
+    Phi = synthesis_phases(ph, a, mags)
+    s = synthesis(mags, Phi)
+    return resample(s, len(x), r)
