@@ -532,6 +532,11 @@ int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, floa
     hann[(size_t)j] = (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * j / N));
     hann_sc[(size_t)j] = hann[(size_t)j] * fold_scale(N);  // exact: a power of two
   }
+  std::vector<float2> wsplit((size_t)M);
+  for (int c = 0; c < M; ++c) {
+    const double ang = 2.0 * 3.14159265358979323846 * c / N;
+    wsplit[(size_t)c] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+  }
   PvArgs p{};
   p.audio = a->d_padded;
   p.n = a->n;
@@ -551,7 +556,7 @@ int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, floa
   auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_apos = take((size_t)F * 8), o_h = take(N * 4), o_hs = take(N * 4), o_m = take(rowsz * 4),
                o_p = take(rowsz * 4), o_i = take(rowsz * 4), o_c = take((size_t)nchunks * M * 4),
-               o_f = take((size_t)F * N * 4), o_s = take(((size_t)p.s_len + 1) * 4),
+               o_f = take((size_t)pv_halo_floats(F) * 4), o_s = take(((size_t)p.s_len + 1) * 4), o_w = take((size_t)M * 8),
                o_x = take((size_t)F * 4), o_a = take((size_t)nchunks * M);
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
   if (ctx->pv_arena.cap < off) {
@@ -568,7 +573,9 @@ int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, floa
   hipError_t e = hipMemcpyAsync(arena + o_apos, apos.data(), (size_t)F * 8, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(arena + o_h, hann.data(), N * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hs, hann_sc.data(), N * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(arena + o_s + (size_t)p.s_len * 4, 0, 4, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(arena + o_w, wsplit.data(), (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream);
+  // the last hop of s is beyond every frame, and s[s_len] backs the interpolation's m+1
+  if (e == hipSuccess) e = hipMemsetAsync(arena + o_s + (size_t)(p.s_len - Hs) * 4, 0, (size_t)(Hs + 1) * 4, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(arena + o_x, 0, (size_t)F * 4, ctx->stream);
   p.fmax = reinterpret_cast<float *>(arena + o_x);
   p.chunk_any = reinterpret_cast<uint8_t *>(arena + o_a);
@@ -579,7 +586,8 @@ int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, floa
   p.phase = reinterpret_cast<uint32_t *>(arena + o_p);
   p.phi = reinterpret_cast<uint32_t *>(arena + o_i);
   p.chunk_sums = reinterpret_cast<uint32_t *>(arena + o_c);
-  p.frames_out = reinterpret_cast<float *>(arena + o_f);
+  p.halo = reinterpret_cast<float *>(arena + o_f);
+  p.wsplit = reinterpret_cast<const float2 *>(arena + o_w);
   p.s = reinterpret_cast<float *>(arena + o_s);
   if (e == hipSuccess) e = launch_pv(p, ctx->stream);
   // the host tables above must outlive the copies queued on the stream

@@ -63,6 +63,7 @@ struct PvArgs {
   int64_t frames;
   const float *hann_scaled;  // periodic Hann * 1/(2N): the analysis window with the transform's folded scale
   const float *hann;         // periodic Hann (synthesis window)
+  const float2 *wsplit;      // e^{+2 pi i c/N}, c = 0..N/2-1 (pre-split of the inverse transform)
   const float2 *tw2, *tw3, *ubase;  // Plan<4096,16> tables
   float *mags;        // [frames][N/2]
   uint32_t *phase;    // [frames][N/2] analysis phases, turns * 2^32
@@ -71,7 +72,7 @@ struct PvArgs {
   uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2]
   uint8_t *chunk_any;    // same shape: the chunk contains a restart
   int scan_chunk;
-  float *frames_out;  // [frames][N] windowed synthesis frames
+  float *halo;        // pv_halo_floats(frames): partial sums right of each synthesis-workgroup boundary
   float *s;           // stretched signal, s_len = frames*Hs + N, index 0 = stretched time -N/2
   int64_t s_len;
   float *pcm_f32;     // n, may be null
@@ -79,6 +80,7 @@ struct PvArgs {
   int frames_per_block;
 };
 hipError_t launch_pv(const PvArgs &a, hipStream_t s);
+int64_t pv_halo_floats(int64_t frames);
 
 // spec-cache.cpp:77-96 colormap: nbins_total magnitudes -> 3*nbins_total bytes (both device).
 hipError_t launch_colormap(const float *mags, uint8_t *rgb, int64_t nbins_total, float k, hipStream_t s);

@@ -15,10 +15,13 @@
 //                 and the previous one (|X| >= 1e-3 of the frame's peak), otherwise it restarts from its
 //                 analysis phase.  Chunked SEGMENTED inclusive scan of those steps along the frame axis
 //                 (uint32 wrap = mod 1 turn); the steps are recomputed in both sweeps, never stored
-//   pv_synthesis  |X| e^{i Phi} -> inverse real FFT (the same three passes run on the conjugated,
-//                 pre-split spectrum) -> Hann-windowed frame, row [F][N]
-//   pv_ola        overlap-add of the 16 frames that cover a stretched sample, in frame order
-//                 (deterministic: no atomics), normalised by sum w^2 = 3N/(8 Hs)
+//   pv_synthesis  a workgroup walks >= 32 consecutive frames: |X| e^{i Phi} -> inverse real FFT (the same
+//                 three passes run on the conjugated, pre-split spectrum) -> Hann window -> overlap-add in
+//                 an LDS ring of N samples; after each frame the oldest hop is complete and leaves as one
+//                 1 KiB store, normalised by sum w^2 = 3N/(8 Hs).  Only the N - Hs samples either side of
+//                 a workgroup boundary see two workgroups: the left one leaves its partial sums in s, the
+//                 right one in a halo buffer
+//   pv_fixup      adds the halo to s across each boundary (in frame order: deterministic, no atomics)
 //   pv_resample   linear interpolation at i*r -> f32 / int16 PCM
 #include <hip/hip_runtime.h>
 
@@ -41,32 +44,37 @@ __device__ __forceinline__ uint32_t to_turns(float re, float im) {
 __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   using P = PV;
   __shared__ __attribute__((aligned(16))) float2 lds[P::M];
-  const int t = threadIdx.x;
-  const bool wave0 = __builtin_amdgcn_readfirstlane(t) < 64;
+  const int t_ = threadIdx.x;
+  const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;
   cpx u[P::R3];
-  post_twiddles<P>(t, a.ubase, u);
+  post_twiddles<P>(t_, a.ubase, u);
   const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_block;
   const int64_t f1 = f0 + a.frames_per_block < a.frames ? f0 + a.frames_per_block : a.frames;
   for (int64_t f = f0; f < f1; ++f) {
+    // as in stft_kernel: re-materialise the thread index and a zero table offset per frame, or LICM hoists every
+    // frame-invariant table value and address out of the loop (256 VGPRs and spills instead of ~150)
+    int t = t_, zoff = 0;
+    asm volatile("" : "+v"(t), "+s"(zoff));
+    const float2 *tw2 = a.tw2 + zoff, *tw3 = a.tw3 + zoff;
     const float *x = a.audio + MX_AUDIO_PAD + (a.apos[f] - P::N / 2);
     cpx Y[P::E], v[P::E];
-    load_frame<P, 1, false>(t, Y, x, a.hann_scaled);
+    load_frame<P, 1, false>(t, Y, x, a.hann_scaled + zoff);
     pass1<P>(Y, v);
     __syncthreads();  // every wave is past the previous frame's load_t2
     store_t1<P>(t, v, lds);
     __syncthreads();
     load_t1<P>(t, v, lds);
     __syncthreads();
-    pass2<P>(t, v, a.tw2);
+    pass2<P>(t, v, tw2);
     store_t2<P>(t, v, lds);
     __syncthreads();
     load_t2<P>(t, v, lds);
     cpx X[P::E];
     if (wave0) {
-      pass3<P, true>(t, v, a.tw3);
+      pass3<P, true>(t, v, tw3);
       post_cplx<P, true>(t, v, u, X);
     } else {
-      pass3<P, false>(t, v, a.tw3);
+      pass3<P, false>(t, v, tw3);
       post_cplx<P, false>(t, v, u, X);
     }
     float *mrow = a.mags + (size_t)f * P::M;
@@ -93,10 +101,10 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
 // One step of a bin's phase bookkeeping.  A bin that is active (|X| >= 1e-3 * frame peak) in this frame and the
 // previous one advances its synthesis phase by
 //   d   = int32(P_f - P_{f-1} - (k*h mod N) * 2^32/N)        deviation from the nominal advance over h samples
-//   inc = (k*Hs mod N) * 2^32/N + trunc(d * Hs / h)
-// (d*Hs < 2^39 and the quotient's distance to the next integer is >= 1/h, far above a binary64 ulp, so the
-// truncated binary64 quotient IS the C integer quotient); any other bin, and every bin of frame 0, restarts from
-// its analysis phase.  Returns true for a restart; `val` is the new phase (restart) or the advance.
+//   inc = (k*Hs mod N) * 2^32/N + trunc(double(d) * (Hs/h))  one binary64 product of a binary64 quotient: the
+//                                                             same two roundings on every IEEE machine
+// any other bin, and every bin of frame 0, restarts from its analysis phase.  Returns true for a restart; `val` is
+// the new phase (restart) or the advance.
 constexpr float kPvActiveRel = 1e-3f;
 struct PvBinState {
   uint32_t p;  // analysis phase of the previous frame
@@ -109,11 +117,11 @@ __device__ __forceinline__ bool pv_step(const PvArgs &a, int k, int64_t f, PvBin
   const bool cont = f > 0 && act && st.act;
   if (cont) {
     constexpr uint32_t unit = (uint32_t)(4294967296ull / kPvN);
-    const int64_t h = a.apos[f] - a.apos[f - 1];
-    const uint32_t expect = (uint32_t)(((int64_t)k * h) & (kPvN - 1)) * unit;
+    const uint32_t h = (uint32_t)(a.apos[f] - a.apos[f - 1]);
+    const uint32_t expect = (((uint32_t)k * h) & (uint32_t)(kPvN - 1)) * unit;
     const int32_t d = (int32_t)(p - st.p - expect);
-    const int64_t q = (int64_t)(((double)d * (double)kPvHs) / (double)h);
-    val = (uint32_t)(((int64_t)k * kPvHs) & (kPvN - 1)) * unit + (uint32_t)(int32_t)q;
+    const int64_t q = (int64_t)((double)d * ((double)kPvHs / (double)h));  // truncates toward zero
+    val = (((uint32_t)k * (uint32_t)kPvHs) & (uint32_t)(kPvN - 1)) * unit + (uint32_t)q;
   } else {
     val = p;
   }
@@ -184,21 +192,36 @@ __device__ __forceinline__ cpx pv_coef(const float *mrow, const uint32_t *prow, 
 // y[j] = sum_{k<N} Yhat[k] e^{+2 pi i jk/N} (Hermitian extension, real).  Packed z[m] = y[2m] + i y[2m+1] is
 // 2*conj(DFT_M(conj Z')) with Z'[c] = (A+B)/2 + i e^{+2 pi i c/N} (A-B)/2, A = Yhat[c], B = conj(Yhat[M-c]):
 // the forward passes of stft_core.h run on G[c] = conj((A+B) + i w_c (A-B)) and the frame is conj of the result.
+constexpr int kPvBlockFrames = 32;       // frames per synthesis workgroup (the last one takes the remainder too)
+constexpr int kPvHalo = kPvN - kPvHs;    // samples either side of a workgroup boundary that two workgroups feed
+constexpr float kPvNorm = 1.0f / (3.0f * kPvN / (8.0f * kPvHs));
+static_assert(kPvBlockFrames >= kPvN / kPvHs, "a workgroup must cover a full overlap depth");
+__host__ __device__ constexpr int64_t pv_blocks(int64_t frames) {
+  return frames / kPvBlockFrames > 0 ? frames / kPvBlockFrames : 1;
+}
+
 __global__ __launch_bounds__(PV::T) void pv_synthesis(const PvArgs a) {
   using P = PV;
   __shared__ __attribute__((aligned(16))) float2 lds[P::M];
-  const int t = threadIdx.x;
-  const bool wave0 = __builtin_amdgcn_readfirstlane(t) < 64;
-  cpx wc[P::E];  // e^{+2 pi i c/N}, c = t + T*e
-#pragma unroll
-  for (int e = 0; e < P::E; ++e) {
-    float sn, cs;
-    sincospif(2.0f * (float)(t + P::T * e) / (float)P::N, &sn, &cs);
-    wc[e] = mk(cs, sn);
-  }
-  const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_block;
-  const int64_t f1 = f0 + a.frames_per_block < a.frames ? f0 + a.frames_per_block : a.frames;
+  __shared__ __attribute__((aligned(16))) float ring[P::N];  // overlap-add accumulator, stretched time mod N
+  const int t_ = threadIdx.x;
+  const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;
+  for (int i = t_; i < P::N; i += P::T) ring[i] = 0.f;
+  const int64_t nb = pv_blocks(a.frames);
+  const int64_t blk = blockIdx.x;
+  const int64_t f0 = blk * kPvBlockFrames;
+  const int64_t f1 = blk == nb - 1 ? a.frames : f0 + kPvBlockFrames;
+  float2 *ring2 = reinterpret_cast<float2 *>(ring);
   for (int64_t f = f0; f < f1; ++f) {
+    // LICM may keep this thread's window and split twiddles in registers for the whole walk (twice as fast as
+    // reloading them per frame), but not the pass twiddles as well: those would push the kernel past 256 VGPRs
+    const int t = t_;
+    int zoff = 0;
+    asm volatile("" : "+s"(zoff));
+    const float2 *tw2 = a.tw2 + zoff, *tw3 = a.tw3 + zoff;
+    const float2 *wsp = a.wsplit;  // e^{+2 pi i c/N}, c < M
+    const float2 *w2 = reinterpret_cast<const float2 *>(a.hann);
+    const int kp = k0p<P>(t), kq = k0q<P>(t);
     const float *mrow = a.mags + (size_t)f * P::M;
     const uint32_t *prow = a.phi + (size_t)f * P::M;
     cpx Y[P::E], v[P::E];
@@ -208,47 +231,70 @@ __global__ __launch_bounds__(PV::T) void pv_synthesis(const PvArgs a) {
       const cpx A = pv_coef(mrow, prow, c);
       const cpx B = cconj(pv_coef(mrow, prow, P::M - c));
       const cpx Sm = cadd(A, B), Dm = csub(A, B);
-      const cpx wd = cmul(wc[e], Dm);              // w_c (A-B)
+      const cpx wd = cmul(wsp[c], Dm);             // w_c (A-B)
       Y[e] = mk(Sm.x - wd.y, -(Sm.y + wd.x));      // conj((A+B) + i*wd)
     }
     pass1<P>(Y, v);
-    __syncthreads();
+    __syncthreads();  // (also: the previous frame's hop has left the ring and its slots are zero)
     store_t1<P>(t, v, lds);
     __syncthreads();
     load_t1<P>(t, v, lds);
     __syncthreads();
-    pass2<P>(t, v, a.tw2);
+    pass2<P>(t, v, tw2);
     store_t2<P>(t, v, lds);
     __syncthreads();
     load_t2<P>(t, v, lds);
-    if (wave0) pass3<P, true>(t, v, a.tw3);
-    else pass3<P, false>(t, v, a.tw3);
-    // v[r] = D[k0p + NS3 r], v[q_index(r)] = D[k0q + NS3 r]; sample pair m: y[2m] = Re D[m], y[2m+1] = -Im D[m]
-    const int kp = k0p<P>(t), kq = k0q<P>(t);
-    float2 *row = reinterpret_cast<float2 *>(a.frames_out + (size_t)f * P::N);
-    const float2 *w2 = reinterpret_cast<const float2 *>(a.hann);
+    if (wave0) pass3<P, true>(t, v, tw3);
+    else pass3<P, false>(t, v, tw3);
+    // v[r] = D[k0p + NS3 r], v[q_index(r)] = D[k0q + NS3 r]; sample pair m: y[2m] = Re D[m], y[2m+1] = -Im D[m].
+    // Pair m of frame f sits at stretched sample f*Hs + 2m: ring slot (g*Hs/2 + m) mod M, g = f - f0.  Every slot
+    // is touched by exactly one thread per frame.
+    const int g2 = (int)(((f - f0) * (kPvHs / 2)) & (P::M - 1));
 #pragma unroll
     for (int r = 0; r < P::R3; ++r) {
       const int mp = kp + P::NS3 * r, mq = kq + P::NS3 * r;
       const cpx dp = v[r], dq = v[q_index<P>(r)];
       const float2 hp = w2[mp], hq = w2[mq];
-      row[mp] = make_float2(dp.x * hp.x, -dp.y * hp.y);
-      row[mq] = make_float2(dq.x * hq.x, -dq.y * hq.y);
+      float2 *sp = ring2 + ((g2 + mp) & (P::M - 1)), *sq = ring2 + ((g2 + mq) & (P::M - 1));
+      const float2 op = *sp, oq = *sq;
+      *sp = make_float2(op.x + dp.x * hp.x, op.y - dp.y * hp.y);
+      *sq = make_float2(oq.x + dq.x * hq.x, oq.y - dq.y * hq.y);
     }
+    __syncthreads();
+    // the hop [f*Hs, (f+1)*Hs) has now received every frame of this workgroup that reaches it
+    {
+      float2 *slot = ring2 + ((g2 + t) & (P::M - 1));
+      const float2 accv = *slot;
+      *slot = make_float2(0.f, 0.f);
+      const bool final_here = (f - f0 >= kPvN / kPvHs - 1) || blk == 0;  // all 16 contributors are ours
+      if (final_here) {
+        reinterpret_cast<float2 *>(a.s + f * kPvHs)[t] = make_float2(accv.x * kPvNorm, accv.y * kPvNorm);
+      } else {
+        reinterpret_cast<float2 *>(a.halo + (size_t)blk * kPvHalo + (f - f0) * kPvHs)[t] = accv;
+      }
+    }
+  }
+  // what is left in the ring: this workgroup's share of the N - Hs samples after its last hop (raw sums; pv_fixup
+  // adds the next workgroup's halo and normalises)
+  __syncthreads();
+  {
+    const int g2 = (int)(((f1 - f0) * (kPvHs / 2)) & (P::M - 1));
+    for (int i = t_; i < kPvHalo / 2; i += P::T)
+      reinterpret_cast<float2 *>(a.s + f1 * kPvHs)[i] = ring2[(g2 + i) & (P::M - 1)];
   }
 }
 
-// s[q] (q = stretched time + N/2) = sum over the frames f with f*Hs <= q < f*Hs + N, in frame order.
-__global__ __launch_bounds__(256) void pv_ola(const PvArgs a) {
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (q >= a.s_len) return;
-  int64_t fl = (q - kPvN + kPvHs) / kPvHs;  // smallest f with f*Hs + N > q
-  if (q - kPvN + 1 <= 0) fl = 0;
-  int64_t fh = q / kPvHs;
-  if (fh > a.frames - 1) fh = a.frames - 1;
-  float acc = 0.f;
-  for (int64_t f = fl; f <= fh; ++f) acc += a.frames_out[(size_t)f * kPvN + (q - f * kPvHs)];
-  a.s[q] = acc * (1.0f / (3.0f * kPvN / (8.0f * kPvHs)));
+// Boundary b (1..nb): s over [f0_b*Hs, f0_b*Hs + N - Hs) holds the left workgroup's raw sums; add the right
+// workgroup's (none after the last one) and normalise.
+__global__ __launch_bounds__(256) void pv_fixup(const PvArgs a) {
+  const int64_t nb = pv_blocks(a.frames);
+  const int64_t b = (int64_t)blockIdx.y + 1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kPvHalo) return;
+  const int64_t fb = b == nb ? a.frames : b * kPvBlockFrames;
+  float v = a.s[fb * kPvHs + i];
+  if (b < nb) v += a.halo[(size_t)b * kPvHalo + i];
+  a.s[fb * kPvHs + i] = v * kPvNorm;
 }
 
 __global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
@@ -268,6 +314,8 @@ __global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
 
 }  // namespace
 
+int64_t pv_halo_floats(int64_t frames) { return pv_blocks(frames) * (int64_t)kPvHalo; }
+
 hipError_t launch_pv(const PvArgs &a0, hipStream_t s) {
   PvArgs a = a0;
   if (a.frames <= 0 || a.n <= 0) return hipSuccess;
@@ -278,8 +326,9 @@ hipError_t launch_pv(const PvArgs &a0, hipStream_t s) {
   hipLaunchKernelGGL(pv_scan_sums, dim3(kPvM / 256, (unsigned)nchunks), dim3(256), 0, s, a);
   hipLaunchKernelGGL(pv_scan_chunks, dim3(kPvM / 256), dim3(256), 0, s, a, nchunks);
   hipLaunchKernelGGL(pv_scan_apply, dim3(kPvM / 256, (unsigned)nchunks), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(pv_synthesis, dim3(fb), dim3(PV::T), 0, s, a);
-  hipLaunchKernelGGL(pv_ola, dim3((unsigned)((a.s_len + 255) / 256)), dim3(256), 0, s, a);
+  const int64_t nb = pv_blocks(a.frames);
+  hipLaunchKernelGGL(pv_synthesis, dim3((unsigned)nb), dim3(PV::T), 0, s, a);
+  hipLaunchKernelGGL(pv_fixup, dim3((kPvHalo + 255) / 256, (unsigned)nb), dim3(256), 0, s, a);
   hipLaunchKernelGGL(pv_resample, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }

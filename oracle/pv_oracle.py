@@ -15,7 +15,8 @@ and this file is the only oracle it can have.  The definition (N = 4096, Hs = 25
   phase in turns    P_f[k] = round(arg X_f[k] / 2pi * 2^32) mod 2^32          (uint32)
   hop               h_f = a_f - a_{f-1}
   deviation         d = int32( P_f - P_{f-1} - (k*h_f mod N) * 2^32/N )        (wraps to [-1/2, 1/2) turn)
-  synthesis advance inc = (k*Hs mod N) * 2^32/N + trunc(d * Hs / h_f)          (uint32, integer arithmetic)
+  synthesis advance inc = (k*Hs mod N) * 2^32/N + trunc(float64(d) * (Hs / h_f))   (uint32; one binary64 product,
+                    Hs/h_f itself a binary64 quotient: the same two roundings on every IEEE machine)
   active bin        act_f[k] = |X_f[k]| >= 1e-3 * max_k |X_f[k]|              (60 dB below the frame's peak)
   synthesis phase   Phi_f = Phi_{f-1} + inc  where act_f and act_{f-1}, else Phi_f = P_f   (uint32 wrap = mod 1 turn)
                     (a bin only accumulates while it carries signal and restarts from its analysis phase
@@ -25,7 +26,8 @@ and this file is the only oracle it can have.  The definition (N = 4096, Hs = 25
   overlap-add       s[f*Hs - N/2 + j] += w[j] * y_f[j];   s /= sum_f w^2 = 3N/(8 Hs) = 6
   resample          out[i] = (1-t) s[m] + t s[m+1],  m = floor(i*r), t = i*r - m,  i = 0..n-1
 
-The phase bookkeeping is integer, so a parallel segmented scan over frames gives exactly the serial result.
+The phase bookkeeping is integer (the one binary64 product is rounded identically everywhere), so a parallel
+segmented scan over frames gives exactly the serial result.
 """
 import numpy as np
 
@@ -85,7 +87,7 @@ def synthesis_phases(ph, a, mags):
         expect = ((k * int(h[f - 1])) % N) * unit
         d = (ph[f].astype(np.int64) - ph[f - 1].astype(np.int64) - expect) & 0xFFFFFFFF
         d = np.where(d >= 2147483648, d - 4294967296, d)  # int32 reinterpretation
-        q = np.sign(d) * ((np.abs(d) * HS) // int(h[f - 1]))  # C's truncating int64 division
+        q = np.trunc(d.astype(np.float64) * (np.float64(HS) / np.float64(int(h[f - 1])))).astype(np.int64)
         inc = (((k * HS) % N) * unit + q) & 0xFFFFFFFF
         cont = act[f] & act[f - 1]
         Phi[f] = np.where(cont, (Phi[f - 1].astype(np.int64) + inc) & 0xFFFFFFFF, ph[f]).astype(np.uint32)

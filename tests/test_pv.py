@@ -63,6 +63,23 @@ def test_gpu_matches_oracle(gpu_ctx, pv, st):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 300, 4096, 8191, 8192 + 17, 33 * 256 + 3])
+def test_gpu_short_inputs(gpu_ctx, pv, n):
+    """Fewer frames than one synthesis workgroup walks, one frame, sizes around the block and hop sizes."""
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / SR
+    w = (0.4 * np.sin(2 * np.pi * 330.0 * t + 0.5) + 0.01 * rng.standard_normal(n)).astype(np.float32)
+    a = gpu_ctx.upload(w)
+    for st in (4.0, -9.0):
+        f32, _ = gpu_ctx.pv_pitch_shift(a, st)
+        ref = pv.pitch_shift(w.astype(np.float64), st)
+        assert f32.shape == ref.shape
+        err = np.abs(f32 - ref)  # (the noise makes every bin active: see test_gpu_noisy_input_close_to_oracle)
+        assert err.max() <= 1e-3 and np.sqrt((err ** 2).mean()) <= 5e-5
+    a.free()
+
+
+@pytest.mark.gpu
 def test_gpu_properties(gpu_ctx):
     """No oracle needed: identity at 0 semitones, the pitch really moves, length and level are kept, the
     result is deterministic (the overlap-add uses no atomics), silence stays silence."""
