@@ -237,6 +237,26 @@ def main() -> None:
                    "frac_of_hbm_peak": rb / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "grain_scan_s": t_gr, "grain_scan_warm_s": t_gr2,
                    "schedule_host_s": t_sc, "outputs": "int16 PCM, HBM-resident"}
 
+    # supplementary: the build-defined phase-vocoder pitch shift (+3 st) of the same audio — the reference has no
+    # phase vocoder (parity unpinned); whole call incl. its seven kernels, second call timed
+    pv = None
+    if rank == 0 and world == 1 and not args.no_resynth:
+        try:
+            out16 = torch.empty(n, dtype=torch.int16, device=dev)
+            ctx.pv_pitch_shift_dev(audio, 3.0, None, out16.data_ptr())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.pv_pitch_shift_dev(audio, 3.0, None, out16.data_ptr())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            fpv = int(np.ceil(n * 2.0 ** (3 / 12) / 256)) + 1
+            pv = {"pitch_shift_semitones": 3, "frames": fpv, "call_ms": dt * 1e3, "frames_per_s": fpv / dt,
+                  "output_rms": float(out16.float().pow(2).mean().sqrt().item() / 32767.0),
+                  "note": "build-defined (no reference counterpart); N=4096, synthesis hop 256"}
+            del out16
+        except Exception as exc:  # never let a supplementary figure take the headline line down
+            pv = {"error": str(exc)}
+
     if rank == 0:
         balg = b_alg(N, hop, mags=not args.pitch_only)
         achieved = balg * F / (kern_ms * 1e-3) / 1e9
@@ -290,6 +310,8 @@ def main() -> None:
         }
         if resynth is not None:
             line["resynth_supplementary"] = resynth
+        if pv is not None:
+            line["phase_vocoder_supplementary"] = pv
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, hop)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]

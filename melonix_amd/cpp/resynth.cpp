@@ -70,6 +70,14 @@ std::vector<float> Resynth::refill(const std::vector<Marker> &markers, double cu
   return pcm;
 }
 
+std::vector<float> Resynth::phaseVocoder(double semitones) const {
+  std::vector<float> pcm;
+  if (!ok()) return pcm;
+  pcm.resize(host.size());
+  if (mx_pv_pitch_shift(ctx, audio, semitones, pcm.data(), nullptr) != MX_OK) pcm.clear();
+  return pcm;
+}
+
 bool Resynth::exportWav(const std::string &fileName, const std::vector<Marker> &markers) const {
   std::vector<int16_t> pcm16;
   if (!run(markers, nullptr, &pcm16)) return false;

@@ -42,6 +42,9 @@ public:
   std::vector<float> render(const std::vector<Marker> &markers) const;
   std::vector<int16_t> render16(const std::vector<Marker> &markers) const;
   bool exportWav(const std::string &fileName, const std::vector<Marker> &markers) const;
+  // NOT in the reference: a constant pitch shift by a phase vocoder (build-defined, mx_pv_pitch_shift) — same
+  // length as the input.  The reference's own pitch shift is render()/exportWav()'s granular resampler.
+  std::vector<float> phaseVocoder(double semitones) const;
   // what App::playback appends to an empty restWav when asked for `need` samples at warped time `cursor`
   std::vector<float> refill(const std::vector<Marker> &markers, double cursor, std::size_t need,
                             double *cursorEnd = nullptr) const;

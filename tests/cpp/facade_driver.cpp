@@ -140,6 +140,7 @@ int main(int argc, char **argv) {
     check(rest.size() >= 2524 && cur > 2.5, "refill renders at least dur + preferredGrainSize samples");
     dump(out + "/refill.f32", rest);
     dump(out + "/refill_cursor.f64", std::vector<double>{cur});
+    dump(out + "/pv.f32", rs.phaseVocoder(3.0));  // build-defined extra (no reference counterpart)
     std::vector<int32_t> g = rs.grainStarts();
     dump(out + "/grains.i32", g);
   }

@@ -61,6 +61,10 @@ def test_facade_end_to_end(driver, oracle, tmp_path, N):
     assert np.array_equal(got.view(np.uint32), opcm.view(np.uint32))
     assert (tmp_path / "export.wav").read_bytes() == oracle.wav_bytes(oracle.pcm_to_i16(opcm), SR)
     assert np.array_equal(np.fromfile(tmp_path / "grains.i32", np.int32), oracle.grains(w)[0])
+    # Resynth::phaseVocoder == the build's own oracle (the reference has no phase vocoder)
+    from oracle import pv_oracle
+    pvgot = np.fromfile(tmp_path / "pv.f32", np.float32)
+    assert np.abs(pvgot - pv_oracle.pitch_shift(w.astype(np.float64), 3.0)).max() <= 2e-5
     # Resynth::refill == App::playback's refill loop at t = 2.5 s (oracle), bit for bit, and its exit cursor
     _, rest, cend = oracle.playback_fill(w, SR, mk, 2.5, 1024 + 1500)
     got = np.fromfile(tmp_path / "refill.f32", np.float32)
