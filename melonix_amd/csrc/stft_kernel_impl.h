@@ -137,7 +137,7 @@ void stft_kernel(const StftArgs a0) {
   // (spec-cache.cpp:77-96) applied to the four consecutive bins a lane holds, 12 bytes per lane.
   const bool want_rows = a.mags != nullptr || (CMAP && a.rgb != nullptr);
   auto flush_row = [&](int64_t fr, int tt) {  // after a barrier that follows the scatter of frame fr
-#if defined(MX_EXP_DIRECTOUT) || defined(MX_ABL_NOOUTLDS)
+#if defined(MX_ABL_NOOUTLDS)
     if (false) {
 #else
     if (want_rows) {
@@ -153,8 +153,6 @@ void stft_kernel(const StftArgs a0) {
         for (int i = 0; i < C::M / 4 / C::T; ++i) {
 #if defined(MX_ABL_NOGSTORE)
           asm volatile("" ::"v"(q[i]), "v"(row4));
-#elif defined(MX_EXP_PLAINSTORE)
-          row4[C::T * i] = q[i];
 #else
           __builtin_nontemporal_store(q[i], &row4[C::T * i]);
 #endif
@@ -346,29 +344,12 @@ void stft_kernel(const StftArgs a0) {
         __builtin_nontemporal_store(q, &row4[C::T * i]);
       }
     }
-#endif
-#ifdef MX_EXP_DIRECTOUT
-    if (a.mags) {  // experiment: E dword stores per lane straight to the row, no LDS transposition
-      float *row = a.mags + (size_t)f * (size_t)(N / 2);
-      float *plo = row + out_lo, *phi = row + out_hi;
-      float *mlo = row + (C::M - out_lo), *mhi = row + (C::M - out_hi);
-#pragma unroll
-      for (int s = 0; s < C::R3; ++s) {
-        constexpr int H = C::R3 / 2;
-        __builtin_nontemporal_store(mg[2 * s], &(s < H ? plo : phi)[C::NS3 * s]);
-        if (s == H) __builtin_nontemporal_store(mg[2 * s + 1], (t == 0 ? row + C::M / 2 : mhi - C::NS3 * H));
-        else __builtin_nontemporal_store(mg[2 * s + 1], &(s < H ? mlo : mhi)[-C::NS3 * s]);
-      }
-    }
-    if (false) {
-      float *plo = lout + out_lo, *phi = lout + out_hi;
-#elif defined(MX_ABL_NOOUTLDS)
-    if (false) {
-      float *plo = lout + out_lo, *phi = lout + out_hi;
+    constexpr bool kScatter = false;
 #else
-    if (want_rows) {
-      float *plo = lout + out_lo, *phi = lout + out_hi;
+    constexpr bool kScatter = true;
 #endif
+    if (kScatter && want_rows) {
+      float *plo = lout + out_lo, *phi = lout + out_hi;
       float *mlo = lout + (C::M - out_lo), *mhi = lout + (C::M - out_hi);
 #pragma unroll
       for (int s = 0; s < C::R3; ++s) {
