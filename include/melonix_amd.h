@@ -219,6 +219,26 @@ int mx_pv_pitch_shift(mx_ctx *ctx, const mx_audio *a, double semitones, float *p
 int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32,
                           int16_t *d_pcm_i16);
 
+/* One rank of a multi-GPU phase-vocoder run (the overlap-add seams).  Every rank holds the whole
+ * input and takes a contiguous range of frames (boundaries on multiples of 32 frames, so the sums group exactly
+ * as in a single-GPU run and the concatenated outputs are bit-identical to mx_pv_pitch_shift's).  The caller does
+ * the two small exchanges between the stages with its own collective (melonix_amd/shard.py: RCCL / gloo
+ * all-gathers): the per-rank phase totals after stage 1, the seams after stage 2.
+ *   mx_pv_shard_frames      the rank's frame range and the output samples [out_lo, out_hi) it will deliver
+ *   mx_pv_shard_analyze     stage 1; tot_sums_out[2048] / tot_any_out[2048]: this rank's (phase, restart) totals
+ *   mx_pv_shard_synthesize  stage 2; carry_in[2048]: the totals of all lower ranks folded left to right with
+ *                           (r1,v1)+(r2,v2) = (r1|r2, r2 ? v2 : v1+v2 mod 2^32) (NULL on rank 0);
+ *                           head_out / tail_out[3840]: raw partial sums either side of the rank's frames
+ *   mx_pv_shard_finish      stage 3; prev_tail = rank-1's tail_out (NULL on rank 0), next_head = rank+1's head_out
+ *                           (NULL on the last rank); out_hi-out_lo samples each (host, either may be NULL) */
+int mx_pv_shard_frames(int64_t n, double semitones, int rank, int world, int64_t *frame_lo, int64_t *frame_hi,
+                       int64_t *out_lo, int64_t *out_hi);
+int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world,
+                        uint32_t *tot_sums_out, uint8_t *tot_any_out);
+int mx_pv_shard_synthesize(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out);
+int mx_pv_shard_finish(mx_ctx *ctx, const float *prev_tail, const float *next_head, float *pcm_f32_out,
+                       int16_t *pcm_i16_out);
+
 /* ---- waveform min/max pyramid ---------------------------------------------------
  * Replaces App::calcPicks (app.cpp:347-378): level l = floor(n / 2^(l+1)) {min,max} pairs over blocks
  * of 2^(l+1) samples, for every l with n > 2^(l+1).  picks_out (host, caller-allocated, 2*n floats

@@ -39,6 +39,13 @@ def note_bin(note: float, N: int, sr: int = 48000) -> float:
     return _capi.lib().mx_note_bin(float(note), N, sr)
 
 
+def pv_shard_frames(n: int, semitones: float, rank: int, world: int):
+    """-> (frame_lo, frame_hi, out_lo, out_hi) of one rank of a multi-GPU phase-vocoder run."""
+    v = [C.c_int64() for _ in range(4)]
+    _capi.check(_capi.lib().mx_pv_shard_frames(n, float(semitones), rank, world, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
 def frame_count(n: int, hop: int) -> int:
     return _capi.lib().mx_frame_count(n, hop)
 
@@ -181,6 +188,32 @@ class Context:
         _capi.check(_capi.lib().mx_pv_pitch_shift_dev(self.handle, audio.handle, float(semitones),
                                                       C.c_void_p(d_f32) if d_f32 else None,
                                                       C.c_void_p(d_i16) if d_i16 else None))
+
+    # ---- one rank of a multi-GPU phase-vocoder run (melonix_amd.shard.pv_pitch_shift_rank drives these) ----
+    def pv_shard_analyze(self, audio: Audio, semitones: float, rank: int, world: int):
+        """Stage 1 -> (tot_sums uint32[2048], tot_any uint8[2048]): this rank's phase totals."""
+        sums = np.empty(2048, dtype=np.uint32)
+        anyf = np.empty(2048, dtype=np.uint8)
+        _capi.check(_capi.lib().mx_pv_shard_analyze(self.handle, audio.handle, float(semitones), rank, world,
+                                                    _ptr(sums), _ptr(anyf)))
+        return sums, anyf
+
+    def pv_shard_synthesize(self, carry_in):
+        """Stage 2 -> (head, tail) float32[3840] raw seams; carry_in: uint32[2048] or None on rank 0."""
+        head = np.empty(3840, dtype=np.float32)
+        tail = np.empty(3840, dtype=np.float32)
+        c = None if carry_in is None else np.ascontiguousarray(carry_in, dtype=np.uint32)
+        _capi.check(_capi.lib().mx_pv_shard_synthesize(self.handle, _ptr(c), _ptr(head), _ptr(tail)))
+        return head, tail
+
+    def pv_shard_finish(self, count: int, prev_tail, next_head, want_f32: bool = True, want_i16: bool = True):
+        """Stage 3 -> (f32 | None, int16 | None) of `count` = out_hi - out_lo samples (pv_shard_frames)."""
+        f32 = np.empty(count, dtype=np.float32) if want_f32 else None
+        i16 = np.empty(count, dtype=np.int16) if want_i16 else None
+        pt = None if prev_tail is None else np.ascontiguousarray(prev_tail, dtype=np.float32)
+        nh = None if next_head is None else np.ascontiguousarray(next_head, dtype=np.float32)
+        _capi.check(_capi.lib().mx_pv_shard_finish(self.handle, _ptr(pt), _ptr(nh), _ptr(f32), _ptr(i16)))
+        return f32, i16
 
     def minmax_pyramid(self, audio: Audio):
         """App::calcPicks on the GPU -> list of (count_l, 2) float32 arrays {min,max}, one per level."""

@@ -88,6 +88,10 @@ SIGNATURES = {
     "mx_export_wav": (_i, [_vp, _vp, _i64, _i, _vp, _i, C.c_char_p, _i]),
     "mx_pv_pitch_shift": (_i, [_vp, _vp, _d, _vp, _vp]),
     "mx_pv_pitch_shift_dev": (_i, [_vp, _vp, _d, _vp, _vp]),
+    "mx_pv_shard_frames": (_i, [_i64, _d, _i, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "mx_pv_shard_analyze": (_i, [_vp, _vp, _d, _i, _i, _vp, _vp]),
+    "mx_pv_shard_synthesize": (_i, [_vp, _vp, _vp, _vp]),
+    "mx_pv_shard_finish": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mx_minmax_pyramid": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "mx_minmax_pyramid_dev": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "mx_minmax_range": (None, [_vp, _i64, _vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f)]),

@@ -78,8 +78,21 @@ struct PvArgs {
   float *pcm_f32;     // n, may be null
   int16_t *pcm_i16;   // n, may be null
   int frames_per_block;
+  // multi-GPU (one rank's part of the frame axis; all zero / null for a whole-signal run)
+  int64_t first;             // local frames [first, frames) are this rank's; first = 1: row 0 is the frame before them
+  int global_first;          // this rank holds the signal's frame 0
+  const uint32_t *carry_in;  // [N/2] synthesis phase at the end of the previous rank's last frame (null: zero)
+  uint32_t *tot_sums;        // [N/2] out: this rank's total (restart, phase) over its frames (null: not wanted)
+  uint8_t *tot_any;
+  const float *prev_tail;    // [N-Hs] the previous rank's tail seam (raw sums), null on the first rank
+  const float *next_head;    // [N-Hs] the next rank's head seam, null on the last rank
+  int64_t out_lo, out_hi;    // output samples [out_lo, out_hi) of the whole signal are resampled here
+  int64_t s_origin;          // stretched sample index (incl. the N/2 offset) of s[0]
 };
 hipError_t launch_pv(const PvArgs &a, hipStream_t s);
+hipError_t launch_pv_analyze(const PvArgs &a, hipStream_t s);
+hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s);
+hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s);
 int64_t pv_halo_floats(int64_t frames);
 
 // spec-cache.cpp:77-96 colormap: nbins_total magnitudes -> 3*nbins_total bytes (both device).

@@ -146,7 +146,7 @@ __device__ __forceinline__ PvBinState pv_state_before(const PvArgs &a, int k, in
 __global__ __launch_bounds__(256) void pv_scan_sums(const PvArgs a) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int64_t c = blockIdx.y;
-  const int64_t r0 = c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
+  const int64_t r0 = a.first + c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
   PvBinState st = pv_state_before(a, k, r0);
   uint32_t acc = 0, any = 0;
   for (int64_t r = r0; r < r1; ++r) {
@@ -157,9 +157,22 @@ __global__ __launch_bounds__(256) void pv_scan_sums(const PvArgs a) {
   a.chunk_sums[c * kPvM + k] = acc;
   a.chunk_any[c * kPvM + k] = (uint8_t)any;
 }
+// This rank's total over its own frames (multi-GPU: what the other ranks need to know of it); leaves the chunk
+// totals as they are.
+__global__ __launch_bounds__(256) void pv_scan_totals(const PvArgs a, int64_t nchunks) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  uint32_t acc = 0, any = 0;
+  for (int64_t c = 0; c < nchunks; ++c) {
+    const uint32_t v = a.chunk_sums[c * kPvM + k];
+    if (a.chunk_any[c * kPvM + k]) { acc = v; any = 1; }
+    else acc += v;
+  }
+  a.tot_sums[k] = acc;
+  a.tot_any[k] = (uint8_t)any;
+}
 __global__ __launch_bounds__(256) void pv_scan_chunks(const PvArgs a, int64_t nchunks) {
   const int k = blockIdx.x * 256 + threadIdx.x;
-  uint32_t carry = 0;
+  uint32_t carry = a.carry_in ? a.carry_in[k] : 0u;  // the phase at the end of the previous rank's last frame
   for (int64_t c = 0; c < nchunks; ++c) {  // carry into chunk c = phase at the end of chunk c-1
     const uint32_t v = a.chunk_sums[c * kPvM + k];
     const bool any = a.chunk_any[c * kPvM + k] != 0;
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(256) void pv_scan_chunks(const PvArgs a, int64_t nc
 __global__ __launch_bounds__(256) void pv_scan_apply(const PvArgs a) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int64_t c = blockIdx.y;
-  const int64_t r0 = c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
+  const int64_t r0 = a.first + c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
   PvBinState st = pv_state_before(a, k, r0);
   uint32_t acc = a.chunk_sums[c * kPvM + k];
   for (int64_t r = r0; r < r1; ++r) {
@@ -207,9 +220,9 @@ __global__ __launch_bounds__(PV::T) void pv_synthesis(const PvArgs a) {
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;
   for (int i = t_; i < P::N; i += P::T) ring[i] = 0.f;
-  const int64_t nb = pv_blocks(a.frames);
+  const int64_t nb = pv_blocks(a.frames - a.first);
   const int64_t blk = blockIdx.x;
-  const int64_t f0 = blk * kPvBlockFrames;
+  const int64_t f0 = a.first + blk * kPvBlockFrames;  // local frame indices; s[0] belongs to local frame a.first
   const int64_t f1 = blk == nb - 1 ? a.frames : f0 + kPvBlockFrames;
   float2 *ring2 = reinterpret_cast<float2 *>(ring);
   for (int64_t f = f0; f < f1; ++f) {
@@ -266,9 +279,10 @@ __global__ __launch_bounds__(PV::T) void pv_synthesis(const PvArgs a) {
       float2 *slot = ring2 + ((g2 + t) & (P::M - 1));
       const float2 accv = *slot;
       *slot = make_float2(0.f, 0.f);
-      const bool final_here = (f - f0 >= kPvN / kPvHs - 1) || blk == 0;  // all 16 contributors are ours
+      // all 16 contributors are this workgroup's (or there are none before the signal's first frame)
+      const bool final_here = (f - f0 >= kPvN / kPvHs - 1) || (blk == 0 && a.global_first);
       if (final_here) {
-        reinterpret_cast<float2 *>(a.s + f * kPvHs)[t] = make_float2(accv.x * kPvNorm, accv.y * kPvNorm);
+        reinterpret_cast<float2 *>(a.s + (f - a.first) * kPvHs)[t] = make_float2(accv.x * kPvNorm, accv.y * kPvNorm);
       } else {
         reinterpret_cast<float2 *>(a.halo + (size_t)blk * kPvHalo + (f - f0) * kPvHs)[t] = accv;
       }
@@ -280,35 +294,45 @@ __global__ __launch_bounds__(PV::T) void pv_synthesis(const PvArgs a) {
   {
     const int g2 = (int)(((f1 - f0) * (kPvHs / 2)) & (P::M - 1));
     for (int i = t_; i < kPvHalo / 2; i += P::T)
-      reinterpret_cast<float2 *>(a.s + f1 * kPvHs)[i] = ring2[(g2 + i) & (P::M - 1)];
+      reinterpret_cast<float2 *>(a.s + (f1 - a.first) * kPvHs)[i] = ring2[(g2 + i) & (P::M - 1)];
   }
 }
 
-// Boundary b (1..nb): s over [f0_b*Hs, f0_b*Hs + N - Hs) holds the left workgroup's raw sums; add the right
-// workgroup's (none after the last one) and normalise.
+// Boundary b (0..nb): s over [f0_b*Hs, f0_b*Hs + N - Hs) holds the left workgroup's raw sums (none at b = 0); add the
+// right workgroup's halo (none at b = nb) and normalise.  Across ranks (multi-GPU) the missing side comes from the
+// neighbour: prev_tail at b = 0, next_head at b = nb — the overlap-add seams of SURVEY 8e(3).
 __global__ __launch_bounds__(256) void pv_fixup(const PvArgs a) {
-  const int64_t nb = pv_blocks(a.frames);
-  const int64_t b = (int64_t)blockIdx.y + 1;
+  const int64_t fs = a.frames - a.first;
+  const int64_t nb = pv_blocks(fs);
+  const int64_t b = (int64_t)blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= kPvHalo) return;
-  const int64_t fb = b == nb ? a.frames : b * kPvBlockFrames;
+  if (b == 0) {
+    if (a.global_first) return;  // the first hops of the signal were complete when they left the ring
+    const float v = a.halo[i] + (a.prev_tail ? a.prev_tail[i] : 0.f);
+    a.s[i] = v * kPvNorm;
+    return;
+  }
+  const int64_t fb = b == nb ? fs : b * kPvBlockFrames;
   float v = a.s[fb * kPvHs + i];
   if (b < nb) v += a.halo[(size_t)b * kPvHalo + i];
+  else if (a.next_head) v += a.next_head[i];
   a.s[fb * kPvHs + i] = v * kPvNorm;
 }
 
 __global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;  // output sample out_lo + j of the whole signal
+  const int64_t i = a.out_lo + j;
+  if (i >= a.out_hi) return;
   const double pos = (double)i * a.ratio + (double)(kPvN / 2);
   const double fl = floor(pos);
-  const int64_t m = (int64_t)fl;
+  const int64_t m = (int64_t)fl - a.s_origin;  // s[0] is stretched sample s_origin of the whole signal
   const float tt = (float)(pos - fl);
   const float v = (1.0f - tt) * a.s[m] + tt * a.s[m + 1];
-  if (a.pcm_f32) a.pcm_f32[i] = v;
+  if (a.pcm_f32) a.pcm_f32[j] = v;
   if (a.pcm_i16) {
     const float c = v < -1.f ? -1.f : (1.f < v ? 1.f : v);  // the reference's cast is UB beyond +-1 (app.cpp:1211)
-    a.pcm_i16[i] = (int16_t)((double)c * 32767.);
+    a.pcm_i16[j] = (int16_t)((double)c * 32767.);
   }
 }
 
@@ -316,21 +340,42 @@ __global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
 
 int64_t pv_halo_floats(int64_t frames) { return pv_blocks(frames) * (int64_t)kPvHalo; }
 
-hipError_t launch_pv(const PvArgs &a0, hipStream_t s) {
+// Stage 1: analysis rows and this rank's phase totals.  Stage 2: carries (from carry_in), synthesis phases, synthesis
+// with the overlap-add ring (afterwards halo[0 .. N-Hs) is this rank's head seam and s[(frames-first)*Hs ..) its
+// tail seam, both raw).  Stage 3: boundary fix-up (with the neighbours' seams) and resampling.
+hipError_t launch_pv_analyze(const PvArgs &a0, hipStream_t s) {
   PvArgs a = a0;
-  if (a.frames <= 0 || a.n <= 0) return hipSuccess;
+  if (a.frames - a.first <= 0) return hipSuccess;
   a.frames_per_block = 8;
   const unsigned fb = (unsigned)((a.frames + a.frames_per_block - 1) / a.frames_per_block);
-  const int64_t nchunks = (a.frames + a.scan_chunk - 1) / a.scan_chunk;
+  const int64_t nchunks = (a.frames - a.first + a.scan_chunk - 1) / a.scan_chunk;
   hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
   hipLaunchKernelGGL(pv_scan_sums, dim3(kPvM / 256, (unsigned)nchunks), dim3(256), 0, s, a);
+  if (a.tot_sums) hipLaunchKernelGGL(pv_scan_totals, dim3(kPvM / 256), dim3(256), 0, s, a, nchunks);
+  return hipGetLastError();
+}
+hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s) {
+  if (a.frames - a.first <= 0) return hipSuccess;
+  const int64_t nchunks = (a.frames - a.first + a.scan_chunk - 1) / a.scan_chunk;
   hipLaunchKernelGGL(pv_scan_chunks, dim3(kPvM / 256), dim3(256), 0, s, a, nchunks);
   hipLaunchKernelGGL(pv_scan_apply, dim3(kPvM / 256, (unsigned)nchunks), dim3(256), 0, s, a);
-  const int64_t nb = pv_blocks(a.frames);
-  hipLaunchKernelGGL(pv_synthesis, dim3((unsigned)nb), dim3(PV::T), 0, s, a);
-  hipLaunchKernelGGL(pv_fixup, dim3((kPvHalo + 255) / 256, (unsigned)nb), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(pv_resample, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(pv_synthesis, dim3((unsigned)pv_blocks(a.frames - a.first)), dim3(PV::T), 0, s, a);
   return hipGetLastError();
+}
+hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s) {
+  if (a.frames - a.first <= 0) return hipSuccess;
+  const int64_t nb = pv_blocks(a.frames - a.first);
+  hipLaunchKernelGGL(pv_fixup, dim3((kPvHalo + 255) / 256, (unsigned)(nb + 1)), dim3(256), 0, s, a);
+  if (a.out_hi > a.out_lo)
+    hipLaunchKernelGGL(pv_resample, dim3((unsigned)((a.out_hi - a.out_lo + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_pv(const PvArgs &a, hipStream_t s) {
+  if (a.frames <= 0 || a.n <= 0) return hipSuccess;
+  hipError_t e = launch_pv_analyze(a, s);
+  if (e == hipSuccess) e = launch_pv_synthesize(a, s);
+  if (e == hipSuccess) e = launch_pv_finish(a, s);
+  return e;
 }
 
 }  // namespace mx

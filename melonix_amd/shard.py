@@ -110,3 +110,47 @@ def gather_pcm(dist, local, shards):
     # exchanged as bytes: the payload is opaque to the collective (and gloo has no int16)
     dist.all_gather_into_tensor(out.view(torch.uint8), buf.view(torch.uint8))
     return torch.cat([out[r * m: r * m + shards[r].samples] for r in range(world)])
+
+
+# ---- phase vocoder across ranks (the overlap-add seams) ------------------------------------------
+def pv_fold_carry(tot_sums, tot_any, rank: int):
+    """Synthesis phase at the end of rank-1's last frame from the per-rank totals (arrays [world][2048]): the ranks
+    below `rank` folded left to right with (r1,v1)+(r2,v2) = (r1|r2, r2 ? v2 : v1+v2 mod 2^32)."""
+    import numpy as np
+
+    carry = np.zeros(np.asarray(tot_sums).shape[1], dtype=np.uint32)
+    for r in range(rank):
+        s_r = np.asarray(tot_sums[r], dtype=np.uint32)
+        carry = np.where(np.asarray(tot_any[r]) != 0, s_r, carry + s_r).astype(np.uint32)  # uint32 wraps = mod 1 turn
+    return carry
+
+
+def pv_pitch_shift_rank(ctx, audio, semitones: float, dist, rank: int, world: int, want_i16: bool = True):
+    """One rank's part of a multi-GPU phase-vocoder pitch shift.  `audio` is the WHOLE signal on this rank's GPU.
+    Two small all-gathers (any torch.distributed backend; payloads are host tensors moved to `device` when the
+    backend needs device memory): 10 KiB of phase totals per rank, then the two 15 KiB seams per rank.
+    -> (out_lo, out_hi, f32, int16 | None): the rank's slice of the output."""
+    import numpy as np
+    import torch
+
+    n = audio.n
+    _, _, out_lo, out_hi = __import__("melonix_amd").pv_shard_frames(n, semitones, rank, world)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+    def all_gather_bytes(arr):
+        mine = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).copy()).to(dev)
+        out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, mine)
+        return out.cpu().numpy().reshape(world, -1)
+
+    sums, anyf = ctx.pv_shard_analyze(audio, semitones, rank, world)
+    tot = all_gather_bytes(np.concatenate([sums.view(np.uint8), anyf]))
+    all_sums = np.ascontiguousarray(tot[:, : 4 * 2048]).view(np.uint32).reshape(world, 2048)
+    all_any = tot[:, 4 * 2048:]
+    carry = pv_fold_carry(all_sums, all_any, rank) if rank > 0 else None
+    head, tail = ctx.pv_shard_synthesize(carry)
+    seams = all_gather_bytes(np.concatenate([head, tail])).view(np.float32).reshape(world, 2, 3840)
+    prev_tail = seams[rank - 1, 1] if rank > 0 else None
+    next_head = seams[rank + 1, 0] if rank < world - 1 else None
+    f32, i16 = ctx.pv_shard_finish(out_hi - out_lo, prev_tail, next_head, True, want_i16)
+    return out_lo, out_hi, f32, i16

@@ -116,3 +116,110 @@ def test_gpu_noisy_input_close_to_oracle(gpu_ctx, pv):
     err = np.abs(f32 - ref)
     assert np.sqrt((err ** 2).mean()) < 1e-4 and err.max() < 5e-3
     a.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_gpu_sharded_equals_whole(gpu_ctx, world):
+    """The multi-GPU path on one device: `world` contexts play the ranks, the two exchanges (phase totals, seams)
+    are done by hand.  Rank boundaries sit on synthesis-workgroup boundaries, so the concatenated slices are the
+    single-call result bit for bit."""
+    import melonix_amd as mx
+    from melonix_amd import shard as sh
+    w = (accum_sweep(4 * SR) + _tone(3000.0, 4.0, 0.05)).astype(np.float32)
+    n = len(w)
+    a = gpu_ctx.upload(w)
+    for st in (3.0, -5.0):
+        whole_f, whole_i = gpu_ctx.pv_pitch_shift(a, st)
+        ctxs = [mx.Context(0) for _ in range(world)]
+        auds = [c.upload(w) for c in ctxs]
+        tots = [c.pv_shard_analyze(x, st, r, world) for r, (c, x) in enumerate(zip(ctxs, auds))]
+        all_sums = np.stack([t[0] for t in tots])
+        all_any = np.stack([t[1] for t in tots])
+        seams = [c.pv_shard_synthesize(sh.pv_fold_carry(all_sums, all_any, r) if r else None) for r, c in enumerate(ctxs)]
+        parts_f, parts_i, ranges = [], [], []
+        for r, c in enumerate(ctxs):
+            _, _, lo, hi = mx.pv_shard_frames(n, st, r, world)
+            f, i = c.pv_shard_finish(hi - lo, seams[r - 1][1] if r else None, seams[r + 1][0] if r < world - 1 else None)
+            parts_f.append(f)
+            parts_i.append(i)
+            ranges.append((lo, hi))
+        assert ranges[0][0] == 0 and ranges[-1][1] == n and all(x[1] == y[0] for x, y in zip(ranges, ranges[1:]))
+        got_f = np.concatenate(parts_f)
+        assert np.array_equal(got_f.view(np.uint32), whole_f.view(np.uint32))
+        assert np.array_equal(np.concatenate(parts_i), whole_i)
+        for c, x in zip(ctxs, auds):
+            x.free()
+            c.close()
+    a.free()
+
+
+def test_pv_fold_carry():
+    from melonix_amd import shard as sh
+    sums = np.array([[10, 4000000000], [5, 500000000], [7, 9]], dtype=np.uint32)
+    anyf = np.array([[1, 0], [0, 0], [1, 1]], dtype=np.uint8)
+    assert np.array_equal(sh.pv_fold_carry(sums, anyf, 0), [0, 0])
+    assert np.array_equal(sh.pv_fold_carry(sums, anyf, 1), [10, 4000000000])
+    assert np.array_equal(sh.pv_fold_carry(sums, anyf, 2), [15, (4000000000 + 500000000) % 2**32])
+    assert np.array_equal(sh.pv_fold_carry(sums, anyf, 3), [7, 9])
+
+
+def _pv_rank_worker(rank, world, port, st, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch
+    import torch.distributed as dist
+    import melonix_amd as mx
+    from melonix_amd import shard as sh
+    from conftest import accum_sweep as sweep
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = sweep(4 * 48000)
+    ctx = mx.Context(0)  # every rank on the one GPU of the test box
+    a = ctx.upload(w)
+    lo, hi, f32, i16 = sh.pv_pitch_shift_rank(ctx, a, st, dist, rank, world)
+    q.put((rank, lo, hi, f32, i16))
+    dist.barrier()
+    a.free()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gpu_two_processes_all_gather(gpu_ctx):
+    """shard.pv_pitch_shift_rank under torch.distributed (gloo, two processes on the test box's one GPU): the two
+    all-gathers (phase totals, overlap-add seams) and the three stages give the single-call output bit for bit."""
+    import os
+    import torch.multiprocessing as mp
+    w = accum_sweep(4 * SR)
+    a = gpu_ctx.upload(w)
+    whole, whole16 = gpu_ctx.pv_pitch_shift(a, 3.0)
+    a.free()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pv_rank_worker, args=(r, 2, port, 3.0, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    import queue as _q
+    import time as _t
+    t0 = _t.time()
+    while len(got) < 2:
+        try:
+            r, lo, hi, f32, i16 = q.get(timeout=1.0)
+            got[r] = (lo, hi, f32, i16)
+        except _q.Empty:
+            assert not [p.exitcode for p in procs if p.exitcode not in (None, 0)], "a rank died"
+            assert _t.time() - t0 < 240
+    for p in procs:
+        p.join(timeout=60)
+    assert got[0][0] == 0 and got[0][1] == got[1][0] and got[1][1] == len(w)
+    f = np.concatenate([got[0][2], got[1][2]])
+    assert np.array_equal(f.view(np.uint32), whole.view(np.uint32))
+    assert np.array_equal(np.concatenate([got[0][3], got[1][3]]), whole16)
