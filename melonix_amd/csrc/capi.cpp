@@ -566,7 +566,9 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   p.tw2 = t.tw2;
   p.tw3 = t.tw3;
   p.ubase = t.ubase;
-  p.scan_chunk = 512;
+  // chunks of the frame axis for the scan: about a thousand of them (the sweep over the chunk totals is serial per
+  // bin), at least 64 frames each
+  p.scan_chunk = (int)std::max<int64_t>(64, (Fl - first + 1023) / 1024);
   p.s_len = (Fl - first) * Hs + N;
   p.s_origin = F_lo * Hs;
   const int64_t nchunks = (Fl - first + p.scan_chunk - 1) / p.scan_chunk;
