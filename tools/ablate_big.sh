@@ -4,7 +4,7 @@ N=${1:-32768}; HOP=${2:-512}
 mkdir -p tools/bin
 build() { # name flags...
   local name=$1; shift
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -ffp-contract=off -I melonix_amd/csrc -DBIGN=$N -DBIGHOP=$HOP "-DBIGNAME=\"$name\"" "$@" tools/stft_variants_big.hip -o tools/bin/abl_${N}_${name} 2>&1 | grep -E "error" 
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -ffp-contract=off -I melonix_amd/csrc -DBIGN=$N -DBIGHOP=$HOP -DBIGTR=${BIGTR:-2} "-DBIGNAME=\"$name\"" "$@" tools/stft_variants_big.hip -o tools/bin/abl_${N}_${name} 2>&1 | grep -E "error" 
 }
 build base &
 build nowin -DMX_ABL_NOW &
