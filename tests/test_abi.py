@@ -51,6 +51,9 @@ def test_no_oracle_in_product():
             if f.endswith((".py", ".cpp", ".h", ".hip", ".hpp")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "pyoracle" not in txt and "melonix_oracle" not in txt and "liboracle" not in txt, f
+                if f.endswith(".py"):  # (comments may cite oracle/pv_oracle.py as the definition; code may not load it)
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M) and "import_module(\"oracle" not in txt, f
+                    assert not re.search(r"(from|import)\s+\S*pv_oracle", txt), f
 
 
 def test_fails_loudly_without_gpu(mxlib):

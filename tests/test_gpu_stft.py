@@ -145,6 +145,42 @@ def test_sinusoid_pitch(gpu_ctx):
         a.free()
 
 
+def test_errors_newer_entry_points(gpu_ctx, mxlib):
+    """Every failure is a negative status + message, never a crash: staged phase-vocoder calls out of order or with
+    a missing neighbour seam, a shard request on too short a signal, misaligned device audio, bad colormap sizes."""
+    import ctypes as C
+    from melonix_amd import _capi
+    L = _capi.lib()
+    w = np.zeros(50000, np.float32)
+    a = gpu_ctx.upload(w)
+    c2 = mxlib.Context(0)
+    with pytest.raises(mxlib.MxError):
+        c2.pv_shard_synthesize(None)                      # no analyze before
+    a2 = c2.upload(w)
+    c2.pv_shard_analyze(a2, 3.0, 1, 2)
+    with pytest.raises(mxlib.MxError):
+        c2.pv_shard_synthesize(None)                      # rank 1 needs a carry
+    c2.pv_shard_synthesize(np.zeros(2048, np.uint32))
+    with pytest.raises(mxlib.MxError):
+        c2.pv_shard_finish(10, None, None)                # rank 1 needs the previous rank's tail
+    with pytest.raises(mxlib.MxError):
+        mxlib.pv_shard_frames(5000, 0.0, 0, 8)            # 21 frames cannot feed 8 ranks
+    with pytest.raises(mxlib.MxError):
+        mxlib.pv_shard_frames(50000, 0.0, 3, 2)
+    a2.free()
+    c2.close()
+    hip = C.CDLL("libamdhip64.so")  # the runtime the library itself uses (no torch: one HIP runtime per process)
+    buf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(buf), C.c_size_t(4 * (50000 + 2 * mxlib.MX_AUDIO_PAD) + 64)) == 0
+    out = C.c_void_p()
+    rc = L.mx_audio_wrap_device(gpu_ctx.handle, C.c_void_p(buf.value + 4), 50000, C.byref(out))
+    assert rc == -1 and b"aligned" in L.mx_last_error()
+    rc = L.mx_colormap_dev(gpu_ctx.handle, buf, 2049, 1.0, buf)
+    assert rc == -1
+    hip.hipFree(buf)
+    a.free()
+
+
 def test_errors(gpu_ctx, mxlib):
     a = gpu_ctx.upload(np.zeros(1000, np.float32))
     with pytest.raises(mxlib.MxError):
