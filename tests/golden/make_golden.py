@@ -54,6 +54,16 @@ def main():
             pass
         ranges[f"mags_{N}"] = m
     np.savez_compressed(os.path.join(HERE, "c1_mag_rows.npz"), **ranges)
+    # build-defined phase vocoder (no reference counterpart): pins oracle/pv_oracle.py — the definition — against
+    # accidental change; 2 s of the same kind of sweep, +3 / -4 semitones, every 997th sample + level
+    from oracle import pv_oracle as pv
+    w2 = accum_sweep(2 * SR).astype(np.float64)
+    pvg = {"signal": "accum_sweep(2 s)", "stride": 997}
+    for st in (3.0, -4.0):
+        y = pv.pitch_shift(w2, st)
+        pvg[f"st_{st:+.0f}"] = {"samples": y[::997].tolist(), "rms": float(np.sqrt((y ** 2).mean())), "len": len(y)}
+    with open(os.path.join(HERE, "pv_sweep2.json"), "w") as f:
+        json.dump(pvg, f)
     print("wrote", os.listdir(HERE))
 
 

@@ -36,6 +36,20 @@ def test_oracle_identity_and_pitch(pv):
         assert 0.30 < np.sqrt((mid ** 2).mean()) < 0.37  # a 0.5-amplitude sine keeps its level
 
 
+def test_oracle_matches_committed_fixture(pv):
+    """tests/golden/pv_sweep2.json (make_golden.py): the definition has not drifted."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pv_sweep2.json")))
+    w = accum_sweep(2 * SR).astype(np.float64)
+    for st in (3.0, -4.0):
+        y = pv.pitch_shift(w, st)
+        ref = g[f"st_{st:+.0f}"]
+        assert len(y) == ref["len"]
+        assert np.abs(y[::g["stride"]] - np.array(ref["samples"])).max() < 1e-9
+        assert abs(np.sqrt((y ** 2).mean()) - ref["rms"]) < 1e-12
+
+
 def test_oracle_plan(pv):
     for n, st in ((48000, 3.0), (1000, -12.0), (5, 0.0)):
         r = pv.ratio(st)
