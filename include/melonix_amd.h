@@ -219,6 +219,21 @@ int mx_pv_pitch_shift(mx_ctx *ctx, const mx_audio *a, double semitones, float *p
 int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32,
                           int16_t *d_pcm_i16);
 
+/* The same vocoder steered by the editor's markers the way App::exportWav is (app.cpp:1194-1207, 296-301): the
+ * output runs over warped time t in [0, duration()); around warped time t the source is read at time2Sample(t)
+ * and shifted by 2^(time2PitchBend(t)/12), the bend taken constant over a frame's hop (definition:
+ * oracle/pv_oracle.py marker_plan / render).  Still build-defined, parity unpinned.
+ * mx_pv_render_length: the number of output samples (those with i/sampleRate < duration()), < 0 on error. */
+int64_t mx_pv_render_length(int64_t n, int sampleRate, const mx_marker *markers, int nmarkers);
+/* The frame plan itself (library-allocated, free each with mx_free): per frame the analysis centre, warped time and
+ * ratio, and i0[f] = first output sample of frame f (frames + 1 entries, the last = *nsamples). */
+int mx_pv_plan(int64_t n, int sampleRate, const mx_marker *markers, int nmarkers, int64_t **apos, double **tf,
+               double **rf, int64_t **i0, int64_t *frames, int64_t *nsamples);
+int mx_pv_render(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_marker *markers, int nmarkers,
+                 float *pcm_f32_out, int16_t *pcm_i16_out);
+int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_marker *markers, int nmarkers,
+                     float *d_pcm_f32, int16_t *d_pcm_i16);
+
 /* One rank of a multi-GPU phase-vocoder run (the overlap-add seams).  Every rank holds the whole
  * input and takes a contiguous range of frames (boundaries on multiples of 32 frames, so the sums group exactly
  * as in a single-GPU run and the concatenated outputs are bit-identical to mx_pv_pitch_shift's).  The caller does

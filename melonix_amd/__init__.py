@@ -39,6 +39,25 @@ def note_bin(note: float, N: int, sr: int = 48000) -> float:
     return _capi.lib().mx_note_bin(float(note), N, sr)
 
 
+def pv_plan(n: int, sr: int, markers):
+    """Frame plan of the marker-driven phase vocoder -> (n_out, apos int64[F], tf f64[F], rf f64[F], i0 int64[F+1])."""
+    m = _capi.markers_array(markers)
+    pa, pt, pr, pi = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    F, cnt = C.c_int64(), C.c_int64()
+    L = _capi.lib()
+    _capi.check(L.mx_pv_plan(n, sr, m, len(markers), C.byref(pa), C.byref(pt), C.byref(pr), C.byref(pi),
+                             C.byref(F), C.byref(cnt)))
+    f = F.value
+    out = (cnt.value,
+           np.frombuffer(C.string_at(pa, f * 8), dtype=np.int64).copy(),
+           np.frombuffer(C.string_at(pt, f * 8), dtype=np.float64).copy(),
+           np.frombuffer(C.string_at(pr, f * 8), dtype=np.float64).copy(),
+           np.frombuffer(C.string_at(pi, (f + 1) * 8), dtype=np.int64).copy())
+    for q in (pa, pt, pr, pi):
+        L.mx_free(q)
+    return out
+
+
 def pv_shard_frames(n: int, semitones: float, rank: int, world: int):
     """-> (frame_lo, frame_hi, out_lo, out_hi) of one rank of a multi-GPU phase-vocoder run."""
     v = [C.c_int64() for _ in range(4)]
@@ -188,6 +207,17 @@ class Context:
         _capi.check(_capi.lib().mx_pv_pitch_shift_dev(self.handle, audio.handle, float(semitones),
                                                       C.c_void_p(d_f32) if d_f32 else None,
                                                       C.c_void_p(d_i16) if d_i16 else None))
+
+    def pv_render(self, audio: Audio, sr: int, markers, want_f32: bool = True, want_i16: bool = True):
+        """Marker-driven phase vocoder (build-defined) -> (f32 | None, int16 | None) over the warped duration."""
+        m = _capi.markers_array(markers)
+        cnt = _capi.lib().mx_pv_render_length(audio.n, sr, m, len(markers))
+        if cnt < 0:
+            _capi.check(int(cnt))
+        f32 = np.empty(cnt, dtype=np.float32) if want_f32 else None
+        i16 = np.empty(cnt, dtype=np.int16) if want_i16 else None
+        _capi.check(_capi.lib().mx_pv_render(self.handle, audio.handle, sr, m, len(markers), _ptr(f32), _ptr(i16)))
+        return f32, i16
 
     # ---- one rank of a multi-GPU phase-vocoder run (melonix_amd.shard.pv_pitch_shift_rank drives these) ----
     def pv_shard_analyze(self, audio: Audio, semitones: float, rank: int, world: int):

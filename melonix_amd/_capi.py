@@ -88,6 +88,11 @@ SIGNATURES = {
     "mx_export_wav": (_i, [_vp, _vp, _i64, _i, _vp, _i, C.c_char_p, _i]),
     "mx_pv_pitch_shift": (_i, [_vp, _vp, _d, _vp, _vp]),
     "mx_pv_pitch_shift_dev": (_i, [_vp, _vp, _d, _vp, _vp]),
+    "mx_pv_render_length": (_i64, [_i64, _i, _vp, _i]),
+    "mx_pv_plan": (_i, [_i64, _i, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                        C.POINTER(_i64), C.POINTER(_i64)]),
+    "mx_pv_render": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "mx_pv_render_dev": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mx_pv_shard_frames": (_i, [_i64, _d, _i, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "mx_pv_shard_analyze": (_i, [_vp, _vp, _d, _i, _i, _vp, _vp]),
     "mx_pv_shard_synthesize": (_i, [_vp, _vp, _vp, _vp]),

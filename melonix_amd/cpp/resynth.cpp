@@ -78,6 +78,28 @@ std::vector<float> Resynth::phaseVocoder(double semitones) const {
   return pcm;
 }
 
+std::vector<float> Resynth::renderPV(const std::vector<Marker> &markers) const {
+  std::vector<float> pcm;
+  if (!ok()) return pcm;
+  const mx_marker *mk = reinterpret_cast<const mx_marker *>(markers.data());
+  const int64_t m = mx_pv_render_length((int64_t)host.size(), sampleRate, mk, (int)markers.size());
+  if (m <= 0) return pcm;
+  pcm.resize((size_t)m);
+  if (mx_pv_render(ctx, audio, sampleRate, mk, (int)markers.size(), pcm.data(), nullptr) != MX_OK) pcm.clear();
+  return pcm;
+}
+
+bool Resynth::exportWavPV(const std::string &fileName, const std::vector<Marker> &markers) const {
+  if (!ok()) return false;
+  const mx_marker *mk = reinterpret_cast<const mx_marker *>(markers.data());
+  const int64_t m = mx_pv_render_length((int64_t)host.size(), sampleRate, mk, (int)markers.size());
+  if (m <= 0) return false;
+  std::vector<int16_t> pcm16((size_t)m);
+  if (mx_pv_render(ctx, audio, sampleRate, mk, (int)markers.size(), nullptr, pcm16.data()) != MX_OK) return false;
+  saveWav(fileName, pcm16, sampleRate);
+  return true;
+}
+
 bool Resynth::exportWav(const std::string &fileName, const std::vector<Marker> &markers) const {
   std::vector<int16_t> pcm16;
   if (!run(markers, nullptr, &pcm16)) return false;

@@ -45,6 +45,10 @@ public:
   // NOT in the reference: a constant pitch shift by a phase vocoder (build-defined, mx_pv_pitch_shift) — same
   // length as the input.  The reference's own pitch shift is render()/exportWav()'s granular resampler.
   std::vector<float> phaseVocoder(double semitones) const;
+  // ... and the same vocoder steered by the markers as exportWav() is (warped time, pitch bend; mx_pv_render):
+  // renderPV() is what exportWavPV() hands to saveWav.
+  std::vector<float> renderPV(const std::vector<Marker> &markers) const;
+  bool exportWavPV(const std::string &fileName, const std::vector<Marker> &markers) const;
   // what App::playback appends to an empty restWav when asked for `need` samples at warped time `cursor`
   std::vector<float> refill(const std::vector<Marker> &markers, double cursor, std::size_t need,
                             double *cursorEnd = nullptr) const;

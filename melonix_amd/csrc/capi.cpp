@@ -534,8 +534,9 @@ int64_t pv_first_output_at(int64_t q, double r, int64_t n) {
 
 // Lays out the work arena for frames [F_lo, F_hi) of the signal's F frames (plus, when F_lo > 0, the frame before
 // them as local row 0) and fills every PvArgs field but the output pointers.  Caller holds ctx->pv_mu.
+// `plan` (marker-driven variant, whole signal only): the analysis positions come from it instead of floor(f*Hs/r).
 int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, int64_t F_hi, bool want_totals,
-               PvArgs &p) {
+               PvArgs &p, const PvPlan *plan = nullptr) {
   constexpr int N = kPvN, M = kPvM, Hs = kPvHs;
   NTables t;
   int rc = get_tables(ctx, N, t);
@@ -545,7 +546,8 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   const int64_t first = F_lo > 0 ? 1 : 0;
   const int64_t Fl = F_hi - F_lo + first;  // local rows
   std::vector<int64_t> apos((size_t)Fl);
-  for (int64_t j = 0; j < Fl; ++j) apos[(size_t)j] = (int64_t)std::floor((double)((F_lo - first + j) * Hs) / r);
+  for (int64_t j = 0; j < Fl; ++j)
+    apos[(size_t)j] = plan ? plan->apos[(size_t)j] : (int64_t)std::floor((double)((F_lo - first + j) * Hs) / r);
   std::vector<float> hann((size_t)N), hann_sc((size_t)N);
   for (int j = 0; j < N; ++j) {
     hann[(size_t)j] = (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * j / N));
@@ -582,7 +584,9 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
                o_f = take((size_t)pv_halo_floats(Fl - first) * 4), o_s = take(((size_t)p.s_len + 1) * 4),
                o_w = take((size_t)M * 8), o_x = take((size_t)Fl * 4), o_a = take((size_t)nchunks * M),
                o_ts = take((size_t)M * 4), o_ta = take((size_t)M), o_ci = take((size_t)M * 4),
-               o_pt = take((size_t)kPvSeam * 4), o_nh = take((size_t)kPvSeam * 4);
+               o_pt = take((size_t)kPvSeam * 4), o_nh = take((size_t)kPvSeam * 4),
+               o_tf = take(plan ? (size_t)Fl * 8 : 0), o_rf = take(plan ? (size_t)Fl * 8 : 0),
+               o_i0 = take(plan ? ((size_t)Fl + 1) * 8 : 0);
   if (ctx->pv_arena.cap < off) {
     if (ctx->pv_arena.p) hipFree(ctx->pv_arena.p);
     ctx->pv_arena = {};
@@ -601,6 +605,12 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   // the last hop of s is beyond every frame, and s[s_len] backs the interpolation's m+1
   if (e == hipSuccess) e = hipMemsetAsync(arena + o_s + (size_t)(p.s_len - Hs) * 4, 0, (size_t)(Hs + 1) * 4, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(arena + o_x, 0, (size_t)Fl * 4, ctx->stream);
+  if (plan) {
+    if (e == hipSuccess) e = hipMemcpyAsync(arena + o_tf, plan->tf.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(arena + o_rf, plan->rf.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(arena + o_i0, plan->i0.data(), ((size_t)Fl + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host tables above die with this frame
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder setup: %s", hipGetErrorString(e));
   p.fmax = reinterpret_cast<float *>(arena + o_x);
@@ -615,6 +625,11 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   p.halo = reinterpret_cast<float *>(arena + o_f);
   p.wsplit = reinterpret_cast<const float2 *>(arena + o_w);
   p.s = reinterpret_cast<float *>(arena + o_s);
+  if (plan) {
+    p.tf = reinterpret_cast<const double *>(arena + o_tf);
+    p.rf = reinterpret_cast<const double *>(arena + o_rf);
+    p.i0 = reinterpret_cast<const int64_t *>(arena + o_i0);
+  }
   if (want_totals) {
     p.tot_sums = reinterpret_cast<uint32_t *>(arena + o_ts);
     p.tot_any = reinterpret_cast<uint8_t *>(arena + o_ta);
@@ -645,6 +660,102 @@ int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, floa
   if (e == hipSuccess) e = es;
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(e));
   return MX_OK;
+}
+
+// Marker-driven variant: the vocoder steered by the editor's markers as App::exportWav is (warped time, pitch bend).
+int64_t mx_pv_render_length(int64_t n, int sampleRate, const mx_marker *markers, int nmarkers) {
+  if (n < 0 || nmarkers < 0 || (nmarkers > 0 && !markers)) return fail(MX_ERR_INVALID, "bad argument");
+  PvPlan plan;
+  std::string err;
+  const int rc = build_pv_plan(markers, nmarkers, sampleRate, n, plan, err);
+  if (rc) return fail(rc, "%s", err.c_str());
+  return plan.n_out;
+}
+
+int mx_pv_plan(int64_t n, int sampleRate, const mx_marker *markers, int nmarkers, int64_t **apos, double **tf,
+               double **rf, int64_t **i0, int64_t *frames, int64_t *nsamples) {
+  if (n < 0 || nmarkers < 0 || (nmarkers > 0 && !markers) || !apos || !tf || !rf || !i0 || !frames || !nsamples)
+    return fail(MX_ERR_INVALID, "bad argument");
+  try {
+    PvPlan plan;
+    std::string err;
+    const int rc = build_pv_plan(markers, nmarkers, sampleRate, n, plan, err);
+    if (rc) return fail(rc, "%s", err.c_str());
+    const size_t F = plan.apos.size();
+    int64_t *pa = (int64_t *)malloc(F * 8), *pi = (int64_t *)malloc((F + 1) * 8);
+    double *pt = (double *)malloc(F * 8), *pr = (double *)malloc(F * 8);
+    if (!pa || !pi || !pt || !pr) {
+      free(pa); free(pi); free(pt); free(pr);
+      return fail(MX_ERR_NOMEM, "out of host memory");
+    }
+    memcpy(pa, plan.apos.data(), F * 8);
+    memcpy(pi, plan.i0.data(), (F + 1) * 8);
+    memcpy(pt, plan.tf.data(), F * 8);
+    memcpy(pr, plan.rf.data(), F * 8);
+    *apos = pa; *i0 = pi; *tf = pt; *rf = pr;
+    *frames = (int64_t)F;
+    *nsamples = plan.n_out;
+    return MX_OK;
+  } catch (const std::bad_alloc &) {
+    return fail(MX_ERR_NOMEM, "out of host memory");
+  }
+}
+
+int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_marker *markers, int nmarkers,
+                     float *d_pcm_f32, int16_t *d_pcm_i16) {
+  if (!ctx || !a || nmarkers < 0 || (nmarkers > 0 && !markers)) return fail(MX_ERR_INVALID, "bad argument");
+  if (a->n == 0 || (!d_pcm_f32 && !d_pcm_i16)) return MX_OK;
+  try {
+    PvPlan plan;
+    std::string err;
+    int rc = build_pv_plan(markers, nmarkers, sampleRate, a->n, plan, err);
+    if (rc) return fail(rc, "%s", err.c_str());
+    if (plan.n_out == 0) return MX_OK;
+    for (int64_t c : plan.apos)
+      if (c < -(int64_t)MX_AUDIO_PAD / 2 || c > a->n + (int64_t)MX_AUDIO_PAD / 2)
+        return fail(MX_ERR_INVALID, "a marker maps warped time outside the audio");
+    std::lock_guard<std::mutex> plk(ctx->pv_mu);
+    ctx->pv_job_active = false;
+    PvArgs p;
+    rc = pv_prepare(ctx, a, 0.0, 0, (int64_t)plan.apos.size(), false, p, &plan);
+    if (rc) return rc;
+    p.sample_rate = sampleRate;
+    p.pcm_f32 = d_pcm_f32;
+    p.pcm_i16 = d_pcm_i16;
+    hipError_t e = launch_pv(p, ctx->stream);
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = es;
+    if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(e));
+    return MX_OK;
+  } catch (const std::bad_alloc &) {
+    return fail(MX_ERR_NOMEM, "out of host memory");
+  }
+}
+
+int mx_pv_render(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_marker *markers, int nmarkers,
+                 float *pcm_f32_out, int16_t *pcm_i16_out) {
+  if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
+  const int64_t m = mx_pv_render_length(a->n, sampleRate, markers, nmarkers);
+  if (m < 0) return (int)m;
+  if (m == 0 || (!pcm_f32_out && !pcm_i16_out)) return MX_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  float *d_f = nullptr;
+  int16_t *d_i = nullptr;
+  hipError_t e = hipSuccess;
+  if (pcm_f32_out) e = hipMalloc(&d_f, (size_t)m * sizeof(float));
+  if (e == hipSuccess && pcm_i16_out) e = hipMalloc(&d_i, (size_t)m * sizeof(int16_t));
+  if (e != hipSuccess) {
+    hipFree(d_f); hipFree(d_i);
+    return fail(MX_ERR_NOMEM, "device PCM buffers: %s", hipGetErrorString(e));
+  }
+  int rc = mx_pv_render_dev(ctx, a, sampleRate, markers, nmarkers, d_f, d_i);
+  if (rc == MX_OK) {
+    if (d_f) e = hipMemcpy(pcm_f32_out, d_f, (size_t)m * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && d_i) e = hipMemcpy(pcm_i16_out, d_i, (size_t)m * sizeof(int16_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
+  }
+  hipFree(d_f); hipFree(d_i);
+  return rc;
 }
 
 // ---- one rank of a multi-GPU phase-vocoder run (the overlap-add seams) ------------------------

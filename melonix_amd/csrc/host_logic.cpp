@@ -260,6 +260,37 @@ int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *g
 }
 
 // ---------------------------------------------------------------------------
+// Marker-driven phase-vocoder frame plan (build-defined)
+// ---------------------------------------------------------------------------
+int build_pv_plan(const mx_marker *markers, int nmarkers, int sampleRate, int64_t n, PvPlan &plan, std::string &err) {
+  plan = PvPlan{};
+  if (sampleRate <= 0) { err = "sampleRate must be positive"; return MX_ERR_INVALID; }
+  for (int m = 1; m < nmarkers; ++m)
+    if (markers[m].sample < markers[m - 1].sample) { err = "markers must be sorted by sample"; return MX_ERR_INVALID; }
+  const TimeMap tm(markers, nmarkers, sampleRate, n);
+  const double dur = tm.duration(), sr = (double)sampleRate;
+  int64_t n_out = dur > 0 ? (int64_t)std::ceil(dur * sr - 1e-12) : 0;  // the number of i with i/sr < duration()
+  while (n_out > 0 && (double)(n_out - 1) / sr >= dur) --n_out;
+  while ((double)n_out / sr < dur) ++n_out;
+  plan.n_out = n_out;
+  double t = 0.;
+  for (;;) {
+    const float pb = tm.time2pitchbend(t);
+    if (!(pb >= -48.f && pb <= 48.f)) { err = "pitch bend out of range [-48, 48] semitones"; return MX_ERR_INVALID; }
+    const double r = std::exp2((double)pb / 12.0);
+    plan.tf.push_back(t);
+    plan.rf.push_back(r);
+    plan.apos.push_back((int64_t)tm.time2sample(t));
+    plan.i0.push_back(std::min<int64_t>(n_out, (int64_t)std::ceil(t * sr)));
+    if (t >= dur) break;
+    t = t + 256.0 / (r * sr);
+    if (plan.tf.size() > ((size_t)1 << 31)) { err = "too many frames"; return MX_ERR_INVALID; }
+  }
+  plan.i0.push_back(n_out);
+  return MX_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Waveform pyramid query
 // ---------------------------------------------------------------------------
 namespace {

@@ -99,6 +99,17 @@ int64_t step_size(float rate, int32_t L);
 void minmax_from_range(const float *wav, int64_t n, const float *picks, const int64_t *counts, int nlevels,
                        int start, int end, float &mn, float &mx);
 
+// Frame plan of the marker-driven phase vocoder (build-defined; definition: oracle/pv_oracle.py marker_plan):
+// per frame the warped time t_f, the ratio r_f = 2^(time2PitchBend(t_f)/12), the analysis centre
+// a_f = time2Sample(t_f) and the first output sample i0_f = ceil(t_f*sr) (i0 has one more entry = n_out);
+// t_{f+1} = t_f + 256/(r_f*sr), frames until t_f >= duration() inclusive.  Returns MX_OK or MX_ERR_INVALID.
+struct PvPlan {
+  int64_t n_out = 0;
+  std::vector<int64_t> apos, i0;
+  std::vector<double> tf, rf;
+};
+int build_pv_plan(const mx_marker *markers, int nmarkers, int sampleRate, int64_t n, PvPlan &plan, std::string &err);
+
 int write_wav(const char *path, const int16_t *pcm, int64_t m, int sampleRate, bool strict);
 
 }  // namespace mx

@@ -88,6 +88,10 @@ struct PvArgs {
   const float *next_head;    // [N-Hs] the next rank's head seam, null on the last rank
   int64_t out_lo, out_hi;    // output samples [out_lo, out_hi) of the whole signal are resampled here
   int64_t s_origin;          // stretched sample index (incl. the N/2 offset) of s[0]
+  // marker-driven plan (null for a constant ratio): per frame warped time, ratio and first output sample
+  const double *tf, *rf;
+  const int64_t *i0;         // frames + 1 entries
+  int sample_rate;
 };
 hipError_t launch_pv(const PvArgs &a, hipStream_t s);
 hipError_t launch_pv_analyze(const PvArgs &a, hipStream_t s);

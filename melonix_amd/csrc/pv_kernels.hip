@@ -114,10 +114,12 @@ __device__ __forceinline__ bool pv_step(const PvArgs &a, int k, int64_t f, PvBin
   const size_t i = (size_t)f * kPvM + k;
   const uint32_t p = a.phase[i];
   const bool act = a.mags[i] >= kPvActiveRel * a.fmax[f];
-  const bool cont = f > 0 && act && st.act;
+  // (a marker-driven plan may stall or step backwards — h < 1: every bin restarts there)
+  const int64_t hh = f > 0 ? a.apos[f] - a.apos[f - 1] : 0;
+  const bool cont = f > 0 && act && st.act && hh >= 1;
   if (cont) {
     constexpr uint32_t unit = (uint32_t)(4294967296ull / kPvN);
-    const uint32_t h = (uint32_t)(a.apos[f] - a.apos[f - 1]);
+    const uint32_t h = (uint32_t)hh;
     const uint32_t expect = (((uint32_t)k * h) & (uint32_t)(kPvN - 1)) * unit;
     const int32_t d = (int32_t)(p - st.p - expect);
     const int64_t q = (int64_t)((double)d * ((double)kPvHs / (double)h));  // truncates toward zero
@@ -336,6 +338,26 @@ __global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
   }
 }
 
+// Marker-driven variant: the ratio is constant over a frame's hop, so frame f owns the output samples
+// [i0_f, i0_{f+1}) and reads the stretched signal at u = f*Hs + (i/sr - t_f) * r_f * sr.
+__global__ __launch_bounds__(256) void pv_resample_frames(const PvArgs a) {
+  const int64_t f = blockIdx.x;
+  const int64_t lo = a.i0[f], hi = a.i0[f + 1];
+  const double tf = a.tf[f], rs = a.rf[f] * (double)a.sample_rate, sr = (double)a.sample_rate;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const double pos = (double)(f * kPvHs) + ((double)i / sr - tf) * rs + (double)(kPvN / 2);
+    const double fl = floor(pos);
+    const int64_t m = (int64_t)fl - a.s_origin;
+    const float tt = (float)(pos - fl);
+    const float v = (1.0f - tt) * a.s[m] + tt * a.s[m + 1];
+    if (a.pcm_f32) a.pcm_f32[i] = v;
+    if (a.pcm_i16) {
+      const float c = v < -1.f ? -1.f : (1.f < v ? 1.f : v);
+      a.pcm_i16[i] = (int16_t)((double)c * 32767.);
+    }
+  }
+}
+
 }  // namespace
 
 int64_t pv_halo_floats(int64_t frames) { return pv_blocks(frames) * (int64_t)kPvHalo; }
@@ -366,7 +388,9 @@ hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
   const int64_t nb = pv_blocks(a.frames - a.first);
   hipLaunchKernelGGL(pv_fixup, dim3((kPvHalo + 255) / 256, (unsigned)(nb + 1)), dim3(256), 0, s, a);
-  if (a.out_hi > a.out_lo)
+  if (a.i0)  // marker-driven: one workgroup per frame
+    hipLaunchKernelGGL(pv_resample_frames, dim3((unsigned)(a.frames - a.first)), dim3(256), 0, s, a);
+  else if (a.out_hi > a.out_lo)
     hipLaunchKernelGGL(pv_resample, dim3((unsigned)((a.out_hi - a.out_lo + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }

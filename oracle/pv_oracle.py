@@ -73,17 +73,21 @@ def analysis(x, a, chunk=256):
 ACTIVE_REL = 1e-3
 
 
-def synthesis_phases(ph, a, mags):
-    """Integer phase propagation -> Phi (F, N/2) uint32."""
+def synthesis_phases(ph, a, mags, allow_stall=False):
+    """Integer phase propagation -> Phi (F, N/2) uint32.  allow_stall: frames whose analysis position did not
+    advance (h < 1) restart every bin (marker-driven variant); the constant-ratio plan never has them."""
     F = len(a)
     act = mags >= np.float32(ACTIVE_REL) * mags.max(axis=1, keepdims=True)
     k = np.arange(N // 2, dtype=np.int64)
     unit = 4294967296 // N
     h = np.diff(a)
-    assert (h >= 1).all(), "ratio too large: the analysis hop must stay >= 1 sample"
+    assert allow_stall or (h >= 1).all(), "ratio too large: the analysis hop must stay >= 1 sample"
     Phi = np.zeros((F, N // 2), dtype=np.uint32)
     Phi[0] = ph[0]
     for f in range(1, F):
+        if h[f - 1] < 1:
+            Phi[f] = ph[f]
+            continue
         expect = ((k * int(h[f - 1])) % N) * unit
         d = (ph[f].astype(np.int64) - ph[f - 1].astype(np.int64) - expect) & 0xFFFFFFFF
         d = np.where(d >= 2147483648, d - 4294967296, d)  # int32 reinterpretation
@@ -126,3 +130,71 @@ def pitch_shift(x, semitones):
     Phi = synthesis_phases(ph, a, mags)
     s = synthesis(mags, Phi)
     return resample(s, len(x), r)
+
+
+# ---- marker-driven variant ------------------------------------------------------------------------------
+# The same vocoder steered by the editor's markers the way App::exportWav is (app.cpp:1194-1207): the output runs
+# over warped time t in [0, duration()); at warped time t the source is read around time2Sample(t) and shifted by
+# 2^(time2PitchBend(t)/12) (app.cpp:296-301).  Per frame (the bend is taken constant over a frame's hop):
+#   t_0 = 0;  r_f = 2^(pb(t_f)/12) (the C library's binary64 exp2 of the binary32 bend / 12);  a_f = time2Sample(t_f);
+#   i0_f = ceil(t_f * sr)  (first output sample at or after t_f);  t_{f+1} = t_f + Hs / (r_f * sr)
+#   frames until t_f >= duration(), that frame included
+#   output sample i in [i0_f, i0_{f+1}):  u = f*Hs + (i/sr - t_f) * r_f * sr   (stretched position), lerp of s there
+# A bin also restarts whenever the analysis position does not advance (h_f < 1: a time warp that stalls or runs
+# backwards).  n_out = number of i with i/sr < duration().
+def _libm_exp2(x):
+    """exp2 of the C library (the product's host code calls std::exp2; numpy's own exp2 differs in the last bit)."""
+    import ctypes
+    import ctypes.util
+    global _LIBM
+    try:
+        _LIBM
+    except NameError:
+        _LIBM = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        _LIBM.exp2.restype = ctypes.c_double
+        _LIBM.exp2.argtypes = [ctypes.c_double]
+    return float(_LIBM.exp2(float(x)))
+
+
+def marker_plan(n, sr, markers):
+    from oracle import pyoracle as O
+    tm = O.TimeMap(list(markers), sr, n, memo=False)
+    dur = tm.duration()
+    n_out = int(np.ceil(dur * sr - 1e-12)) if dur > 0 else 0
+    while n_out > 0 and (n_out - 1) / sr >= dur:
+        n_out -= 1
+    while n_out / sr < dur:
+        n_out += 1
+    t, a, rf, tf, i0 = 0.0, [], [], [], []
+    while True:
+        pb = float(np.float32(tm.time2pitchbend(t)))
+        r = _libm_exp2(pb / 12.0)
+        tf.append(t)
+        rf.append(r)
+        a.append(int(tm.time2sample(t)))
+        i0.append(min(n_out, int(np.ceil(t * sr))))
+        if t >= dur:
+            break
+        t = t + HS / (r * sr)
+    i0.append(n_out)
+    return n_out, np.array(a, np.int64), np.array(tf), np.array(rf), np.array(i0, np.int64)
+
+
+def render(x, sr, markers):
+    """-> float64 PCM of n_out samples (warped duration)."""
+    x = np.asarray(x, dtype=np.float64)
+    n_out, a, tf, rf, i0 = marker_plan(len(x), sr, markers)
+    mags, ph = analysis(x, a)
+    Phi = synthesis_phases(ph, a, mags, allow_stall=True)
+    s = synthesis(mags, Phi)
+    out = np.zeros(n_out)
+    for f in range(len(a)):
+        lo, hi = int(i0[f]), int(i0[f + 1])
+        if hi <= lo:
+            continue
+        i = np.arange(lo, hi, dtype=np.float64)
+        u = f * HS + (i / sr - tf[f]) * rf[f] * sr + N // 2
+        m = np.floor(u).astype(np.int64)
+        w = u - m
+        out[lo:hi] = (1.0 - w) * s[m] + w * s[m + 1]
+    return out

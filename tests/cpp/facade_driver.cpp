@@ -141,6 +141,9 @@ int main(int argc, char **argv) {
     dump(out + "/refill.f32", rest);
     dump(out + "/refill_cursor.f64", std::vector<double>{cur});
     dump(out + "/pv.f32", rs.phaseVocoder(3.0));  // build-defined extra (no reference counterpart)
+    std::vector<Marker> ramp = {{1, 0, 0, -5.0}, {(int)wav.size() / 2, 0, 0.5, 7.0}, {(int)wav.size() - 1, 0, 0, 0.0}};
+    dump(out + "/pv_markers.f32", rs.renderPV(ramp));
+    check(rs.exportWavPV(out + "/export_pv.wav", ramp), "exportWavPV");
     std::vector<int32_t> g = rs.grainStarts();
     dump(out + "/grains.i32", g);
   }

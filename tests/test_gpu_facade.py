@@ -65,6 +65,11 @@ def test_facade_end_to_end(driver, oracle, tmp_path, N):
     from oracle import pv_oracle
     pvgot = np.fromfile(tmp_path / "pv.f32", np.float32)
     assert np.abs(pvgot - pv_oracle.pitch_shift(w.astype(np.float64), 3.0)).max() <= 2e-5
+    ramp = [(1, 0, 0, -5.0), (n // 2, 0, 0.5, 7.0), (n - 1, 0, 0, 0.0)]
+    pvm = np.fromfile(tmp_path / "pv_markers.f32", np.float32)
+    assert np.abs(pvm - pv_oracle.render(w.astype(np.float64), SR, ramp)).max() <= 5e-5
+    want16 = (np.clip(pvm, -1.0, 1.0).astype(np.float64) * 32767.0).astype(np.int16)
+    assert (tmp_path / "export_pv.wav").read_bytes() == oracle.wav_bytes(want16, SR)  # through saveWav, quirk and all
     # Resynth::refill == App::playback's refill loop at t = 2.5 s (oracle), bit for bit, and its exit cursor
     _, rest, cend = oracle.playback_fill(w, SR, mk, 2.5, 1024 + 1500)
     got = np.fromfile(tmp_path / "refill.f32", np.float32)

@@ -237,3 +237,37 @@ def test_gpu_two_processes_all_gather(gpu_ctx):
     f = np.concatenate([got[0][2], got[1][2]])
     assert np.array_equal(f.view(np.uint32), whole.view(np.uint32))
     assert np.array_equal(np.concatenate([got[0][3], got[1][3]]), whole16)
+
+
+MARKER_SETS = [
+    [],
+    [(1, 0, 0, 3.0), (143999, 0, 0, 3.0)],
+    [(1, 0, 0, -5.0), (72000, 0, 0.5, 7.0), (143999, 0, 0, 0.0)],
+    [(1000, 0, 0.0, 2.0), (40000, 0, -0.2, -3.0), (100000, 0, 0.3, 5.0), (143999, 0, 0, 0)],
+]
+
+
+@pytest.mark.parametrize("mk", MARKER_SETS)
+def test_marker_plan_equals_oracle(mxlib, pv, mk):
+    """build_pv_plan (host, C++) == oracle marker_plan, field by field: same time maps, same binary64 recurrence."""
+    n = 144000
+    n_out, apos, tf, rf, i0 = mxlib.pv_plan(n, SR, mk)
+    on, oa, otf, orf, oi0 = pv.marker_plan(n, SR, mk)
+    assert n_out == on and np.array_equal(apos, oa) and np.array_equal(i0, oi0)
+    assert np.array_equal(tf, otf) and np.array_equal(rf, orf)
+    assert i0[-1] == n_out and (np.diff(i0) >= 0).all() and tf[-1] >= (n_out - 1) / SR
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mk", MARKER_SETS)
+def test_gpu_marker_render_matches_oracle(gpu_ctx, pv, mk):
+    """The marker-driven render through the C-ABI vs the oracle on the same markers (time stretch either way,
+    bends that ramp): binary32 transforms vs binary64, integer phases on both sides."""
+    w = (accum_sweep(3 * SR) + _tone(2500.0, 3.0, 0.05)).astype(np.float32)
+    a = gpu_ctx.upload(w)
+    f32, i16 = gpu_ctx.pv_render(a, SR, mk)
+    ref = pv.render(w.astype(np.float64), SR, mk)
+    assert f32.shape == ref.shape
+    assert np.abs(f32 - ref).max() <= 5e-5
+    assert np.array_equal(i16, (np.clip(f32, -1.0, 1.0).astype(np.float64) * 32767.0).astype(np.int16))
+    a.free()
