@@ -230,7 +230,7 @@ def test_gpu_two_processes_all_gather(gpu_ctx):
             got[r] = (lo, hi, f32, i16)
         except _q.Empty:
             assert not [p.exitcode for p in procs if p.exitcode not in (None, 0)], "a rank died"
-            assert _t.time() - t0 < 240
+            assert _t.time() - t0 < 900  # (a fresh box pages torch in for a minute or two per process)
     for p in procs:
         p.join(timeout=60)
     assert got[0][0] == 0 and got[0][1] == got[1][0] and got[1][1] == len(w)
