@@ -548,6 +548,15 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   std::vector<int64_t> apos((size_t)Fl);
   for (int64_t j = 0; j < Fl; ++j)
     apos[(size_t)j] = plan ? plan->apos[(size_t)j] : (int64_t)std::floor((double)((F_lo - first + j) * Hs) / r);
+  std::vector<uint32_t> hop((size_t)Fl, 0u);
+  std::vector<double> hratio((size_t)Fl, 0.0);
+  for (int64_t j = 1; j < Fl; ++j) {
+    const int64_t h = apos[(size_t)j] - apos[(size_t)j - 1];
+    if (h >= 1 && h <= 0x7fffffffLL) {
+      hop[(size_t)j] = (uint32_t)h;
+      hratio[(size_t)j] = (double)Hs / (double)h;
+    }
+  }
   std::vector<float> hann((size_t)N), hann_sc((size_t)N);
   for (int j = 0; j < N; ++j) {
     hann[(size_t)j] = (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * j / N));
@@ -575,18 +584,18 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   p.s_origin = F_lo * Hs;
   const int64_t nchunks = (Fl - first + p.scan_chunk - 1) / p.scan_chunk;
   // one arena: apos, the two windows, mags, phase, phi, chunk sums, boundary halos, s (+1 for s[m+1]), split
-  // twiddles, frame peaks, restart flags of the chunks, this rank's totals, carry-in, the neighbours' seams
+  // twiddles, restart flags of the chunks, this rank's totals, carry-in, the neighbours' seams
   const size_t rowsz = (size_t)Fl * M;
   size_t off = 0;
   auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_apos = take((size_t)Fl * 8), o_h = take(N * 4), o_hs = take(N * 4), o_m = take(rowsz * 4),
                o_p = take(rowsz * 4), o_i = take(rowsz * 4), o_c = take((size_t)nchunks * M * 4),
                o_f = take((size_t)pv_halo_floats(Fl - first) * 4), o_s = take(((size_t)p.s_len + 1) * 4),
-               o_w = take((size_t)M * 8), o_x = take((size_t)Fl * 4), o_a = take((size_t)nchunks * M),
+               o_w = take((size_t)M * 8), o_a = take((size_t)nchunks * M),
                o_ts = take((size_t)M * 4), o_ta = take((size_t)M), o_ci = take((size_t)M * 4),
                o_pt = take((size_t)kPvSeam * 4), o_nh = take((size_t)kPvSeam * 4),
                o_tf = take(plan ? (size_t)Fl * 8 : 0), o_rf = take(plan ? (size_t)Fl * 8 : 0),
-               o_i0 = take(plan ? ((size_t)Fl + 1) * 8 : 0);
+               o_i0 = take(plan ? ((size_t)Fl + 1) * 8 : 0), o_hp = take((size_t)Fl * 4), o_hr = take((size_t)Fl * 8);
   if (ctx->pv_arena.cap < off) {
     if (ctx->pv_arena.p) hipFree(ctx->pv_arena.p);
     ctx->pv_arena = {};
@@ -604,7 +613,8 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   if (e == hipSuccess) e = hipMemcpyAsync(arena + o_w, wsplit.data(), (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream);
   // the last hop of s is beyond every frame, and s[s_len] backs the interpolation's m+1
   if (e == hipSuccess) e = hipMemsetAsync(arena + o_s + (size_t)(p.s_len - Hs) * 4, 0, (size_t)(Hs + 1) * 4, ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(arena + o_x, 0, (size_t)Fl * 4, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hp, hop.data(), (size_t)Fl * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hr, hratio.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
   if (plan) {
     if (e == hipSuccess) e = hipMemcpyAsync(arena + o_tf, plan->tf.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(arena + o_rf, plan->rf.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -613,9 +623,10 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host tables above die with this frame
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder setup: %s", hipGetErrorString(e));
-  p.fmax = reinterpret_cast<float *>(arena + o_x);
   p.chunk_any = reinterpret_cast<uint8_t *>(arena + o_a);
   p.apos = reinterpret_cast<const int64_t *>(arena + o_apos);
+  p.hop = reinterpret_cast<const uint32_t *>(arena + o_hp);
+  p.hratio = reinterpret_cast<const double *>(arena + o_hr);
   p.hann = reinterpret_cast<const float *>(arena + o_h);
   p.hann_scaled = reinterpret_cast<const float *>(arena + o_hs);
   p.mags = reinterpret_cast<float *>(arena + o_m);

@@ -60,15 +60,16 @@ struct PvArgs {
   int64_t n;
   double ratio;            // r = 2^(semitones/12)
   const int64_t *apos;     // analysis centres a_f = floor(f*Hs/r), frames entries
+  const uint32_t *hop;     // a_f - a_{f-1}; 0 for local row 0 of the whole signal and where a plan does not advance
+  const double *hratio;    // Hs / hop (binary64 quotient), 0 where hop is 0
   int64_t frames;
   const float *hann_scaled;  // periodic Hann * 1/(2N): the analysis window with the transform's folded scale
   const float *hann;         // periodic Hann (synthesis window)
   const float2 *wsplit;      // e^{+2 pi i c/N}, c = 0..N/2-1 (pre-split of the inverse transform)
   const float2 *tw2, *tw3, *ubase;  // Plan<4096,16> tables
   float *mags;        // [frames][N/2]
-  uint32_t *phase;    // [frames][N/2] analysis phases, turns * 2^32
+  uint32_t *phase;    // [frames][N/2] analysis phases: turns * 2^32 (even) | activity flag in bit 0
   uint32_t *phi;      // [frames][N/2] synthesis phases (output of the scan)
-  float *fmax;        // [frames] peak magnitude of the frame (zeroed before pv_analysis)
   uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2]
   uint8_t *chunk_any;    // same shape: the chunk contains a restart
   int scan_chunk;

@@ -9,7 +9,8 @@
 // Stages (all frame-parallel; the phase recurrence is an integer prefix sum over frames, so the parallel
 // scan gives exactly the serial result):
 //   pv_analysis   one workgroup walks consecutive frames: Hann-windowed frame at a_f -> the LDS-resident
-//                 real FFT of stft_core.h -> |X|/N and arg X as uint32 turns, rows [F][N/2]
+//                 real FFT of stft_core.h -> |X|/N and arg X as uint32 turns whose low bit is the
+//                 activity flag (|X| >= 1e-3 of the frame's peak), rows [F][N/2]
 //   pv_scan_*     per (frame, bin): wrapped deviation from the bin's nominal advance -> synthesis phase
 //                 advance (integer arithmetic); a bin accumulates only while it is active in this frame
 //                 and the previous one (|X| >= 1e-3 of the frame's peak), otherwise it restarts from its
@@ -33,17 +34,20 @@ namespace {
 
 using PV = Plan<4096, 16>;
 constexpr int kPvN = 4096, kPvM = kPvN / 2, kPvHs = 256;
+constexpr float kPvActiveRel = 1e-3f;  // a bin is active within 60 dB of its frame's peak
 static_assert(kPlan4096E == 16, "pv kernels use the 16-points-per-thread tables of N = 4096");
 
 __device__ __forceinline__ uint32_t to_turns(float re, float im) {
-  // arg in turns, rounded to 2^-32 (the float carries 24 bits of it); atan2f(0,0) = 0
+  // arg in turns, rounded to 2^-31 and stored as an even uint32 (the float carries 24 bits of it; the low bit of
+  // the word is free for the bin's activity flag); atan2f(0,0) = 0
   const float turns = atan2f(im, re) * 0.15915494309189535f;
-  return (uint32_t)(int64_t)llrintf(turns * 4294967296.0f);
+  return (uint32_t)((int64_t)llrintf(turns * 2147483648.0f) << 1);
 }
 
 __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   using P = PV;
   __shared__ __attribute__((aligned(16))) float2 lds[P::M];
+  __shared__ float red[2];
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;
   cpx u[P::R3];
@@ -77,24 +81,32 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       pass3<P, false>(t, v, tw3);
       post_cplx<P, false>(t, v, u, X);
     }
-    float *mrow = a.mags + (size_t)f * P::M;
-    uint32_t *prow = a.phase + (size_t)f * P::M;
+    float m[P::E];
     float mx = 0.f;
 #pragma unroll
     for (int o = 0; o < P::E; ++o) {
-      const int k = out_bin<P>(t, o);
-      const float m = fast_sqrt(cnorm2(X[o]));
-      mrow[k] = m;
-      prow[k] = to_turns(X[o].x, X[o].y);
-      mx = m > mx ? m : mx;
+      m[o] = fast_sqrt(cnorm2(X[o]));
+      mx = m[o] > mx ? m[o] : mx;
     }
-    // the frame's peak magnitude (non-negative floats order like their bit patterns); fmax is zeroed beforehand
+    // the frame's peak magnitude: wavefront, then the two wavefronts through LDS
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
       const float o = __shfl_xor(mx, d);
       mx = o > mx ? o : mx;
     }
-    if ((t & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(a.fmax) + f, __float_as_uint(mx));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();  // (red is rewritten only after the next frame's four barriers)
+    mx = red[0] > red[1] ? red[0] : red[1];
+    const float thr = kPvActiveRel * mx;
+    float *mrow = a.mags + (size_t)f * P::M;
+    uint32_t *prow = a.phase + (size_t)f * P::M;
+#pragma unroll
+    for (int o = 0; o < P::E; ++o) {
+      const int k = out_bin<P>(t, o);
+      mrow[k] = m[o];
+      // bit 0: the bin is active — the phase sweeps then need this one word per bin and frame, not the magnitude
+      prow[k] = to_turns(X[o].x, X[o].y) | (m[o] >= thr ? 1u : 0u);
+    }
   }
 }
 
@@ -105,59 +117,72 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
 //                                                             same two roundings on every IEEE machine
 // any other bin, and every bin of frame 0, restarts from its analysis phase.  Returns true for a restart; `val` is
 // the new phase (restart) or the advance.
-constexpr float kPvActiveRel = 1e-3f;
-struct PvBinState {
-  uint32_t p;  // analysis phase of the previous frame
-  bool act;    // the bin was active in the previous frame
-};
-__device__ __forceinline__ bool pv_step(const PvArgs &a, int k, int64_t f, PvBinState &st, uint32_t &val) {
-  const size_t i = (size_t)f * kPvM + k;
-  const uint32_t p = a.phase[i];
-  const bool act = a.mags[i] >= kPvActiveRel * a.fmax[f];
-  // (a marker-driven plan may stall or step backwards — h < 1: every bin restarts there)
-  const int64_t hh = f > 0 ? a.apos[f] - a.apos[f - 1] : 0;
-  const bool cont = f > 0 && act && st.act && hh >= 1;
+// Takes the row's word (phase | activity) so that a sweep can fetch four bins with one 16-byte load.
+__device__ __forceinline__ bool pv_step(const PvArgs &a, int k, int64_t f, uint32_t word, uint32_t &prev_p, bool &prev_act,
+                                        uint32_t &val) {
+  const uint32_t p = word & ~1u;
+  const bool act = (word & 1u) != 0;
+  // hop[f] = a_f - a_{f-1} and hratio[f] = Hs / hop[f] (binary64 quotient) come from the host; hop 0 marks frame 0 and
+  // the frames of a marker-driven plan that stall or step backwards: every bin restarts there
+  const uint32_t h = a.hop[f];
+  const bool cont = act && prev_act && h >= 1;
   if (cont) {
     constexpr uint32_t unit = (uint32_t)(4294967296ull / kPvN);
-    const uint32_t h = (uint32_t)hh;
     const uint32_t expect = (((uint32_t)k * h) & (uint32_t)(kPvN - 1)) * unit;
-    const int32_t d = (int32_t)(p - st.p - expect);
-    const int64_t q = (int64_t)((double)d * ((double)kPvHs / (double)h));  // truncates toward zero
+    const int32_t d = (int32_t)(p - prev_p - expect);
+    const int64_t q = (int64_t)((double)d * a.hratio[f]);  // truncates toward zero
     val = (((uint32_t)k * (uint32_t)kPvHs) & (uint32_t)(kPvN - 1)) * unit + (uint32_t)q;
   } else {
     val = p;
   }
-  st.p = p;
-  st.act = act;
+  prev_p = p;
+  prev_act = act;
   return !cont;
 }
-__device__ __forceinline__ PvBinState pv_state_before(const PvArgs &a, int k, int64_t f) {  // state after frame f-1
-  PvBinState st{0u, false};
-  if (f > 0) {
-    const size_t i = (size_t)(f - 1) * kPvM + k;
-    st.p = a.phase[i];
-    st.act = a.mags[i] >= kPvActiveRel * a.fmax[f - 1];
+
+// Segmented inclusive scan of those steps along the frame axis, in chunks of a.scan_chunk frames.  The operator on
+// (restart, value) pairs — (r1,v1)+(r2,v2) = (r1|r2, r2 ? v2 : v1+v2) — is associative, so chunk totals are combined
+// before the chunks are swept again.  A thread walks four adjacent bins (one 16-byte load per row: a workgroup reads
+// 4 KiB of every row it touches), so the previous frame's phase and activity are simply the previous iteration's.
+constexpr int kPvScanVec = 4, kPvScanBlocks = kPvM / (256 * kPvScanVec);
+struct PvScanState {
+  uint32_t p[kPvScanVec];
+  bool act[kPvScanVec];
+};
+__device__ __forceinline__ PvScanState pv_state_before(const PvArgs &a, int k0, int64_t f) {  // state after frame f-1
+  PvScanState st;
+  uint4 w = make_uint4(0u, 0u, 0u, 0u);
+  if (f > 0) w = *reinterpret_cast<const uint4 *>(a.phase + (size_t)(f - 1) * kPvM + k0);
+  const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int j = 0; j < kPvScanVec; ++j) {
+    st.p[j] = ww[j] & ~1u;
+    st.act[j] = f > 0 && (ww[j] & 1u) != 0;
   }
   return st;
 }
-
-// Segmented inclusive scan of those steps along the frame axis, per bin, in chunks of a.scan_chunk frames.  The
-// operator on (restart, value) pairs — (r1,v1)+(r2,v2) = (r1|r2, r2 ? v2 : v1+v2) — is associative, so chunk
-// totals are combined before the chunks are swept again; a thread walks one bin, so the previous frame's phase
-// and activity are simply the previous iteration's.
 __global__ __launch_bounds__(256) void pv_scan_sums(const PvArgs a) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int k0 = (blockIdx.x * 256 + threadIdx.x) * kPvScanVec;
   const int64_t c = blockIdx.y;
   const int64_t r0 = a.first + c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
-  PvBinState st = pv_state_before(a, k, r0);
-  uint32_t acc = 0, any = 0;
-  for (int64_t r = r0; r < r1; ++r) {
-    uint32_t v;
-    if (pv_step(a, k, r, st, v)) { acc = v; any = 1; }
-    else acc += v;
+  PvScanState st = pv_state_before(a, k0, r0);
+  uint32_t acc[kPvScanVec] = {0u, 0u, 0u, 0u}, any[kPvScanVec] = {0u, 0u, 0u, 0u};
+#pragma unroll 4
+  for (int64_t r = r0; r < r1; ++r) {  // (unrolled: the rows' loads do not depend on the running phase)
+    const uint4 w = *reinterpret_cast<const uint4 *>(a.phase + (size_t)r * kPvM + k0);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int j = 0; j < kPvScanVec; ++j) {
+      uint32_t v;
+      if (pv_step(a, k0 + j, r, ww[j], st.p[j], st.act[j], v)) { acc[j] = v; any[j] = 1; }
+      else acc[j] += v;
+    }
   }
-  a.chunk_sums[c * kPvM + k] = acc;
-  a.chunk_any[c * kPvM + k] = (uint8_t)any;
+#pragma unroll
+  for (int j = 0; j < kPvScanVec; ++j) {
+    a.chunk_sums[c * kPvM + k0 + j] = acc[j];
+    a.chunk_any[c * kPvM + k0 + j] = (uint8_t)any[j];
+  }
 }
 // This rank's total over its own frames (multi-GPU: what the other ranks need to know of it); leaves the chunk
 // totals as they are.
@@ -183,15 +208,23 @@ __global__ __launch_bounds__(256) void pv_scan_chunks(const PvArgs a, int64_t nc
   }
 }
 __global__ __launch_bounds__(256) void pv_scan_apply(const PvArgs a) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int k0 = (blockIdx.x * 256 + threadIdx.x) * kPvScanVec;
   const int64_t c = blockIdx.y;
   const int64_t r0 = a.first + c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
-  PvBinState st = pv_state_before(a, k, r0);
-  uint32_t acc = a.chunk_sums[c * kPvM + k];
+  PvScanState st = pv_state_before(a, k0, r0);
+  uint32_t acc[kPvScanVec];
+#pragma unroll
+  for (int j = 0; j < kPvScanVec; ++j) acc[j] = a.chunk_sums[c * kPvM + k0 + j];
+#pragma unroll 4
   for (int64_t r = r0; r < r1; ++r) {
-    uint32_t v;
-    acc = pv_step(a, k, r, st, v) ? v : acc + v;
-    a.phi[r * kPvM + k] = acc;
+    const uint4 w = *reinterpret_cast<const uint4 *>(a.phase + (size_t)r * kPvM + k0);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int j = 0; j < kPvScanVec; ++j) {
+      uint32_t v;
+      acc[j] = pv_step(a, k0 + j, r, ww[j], st.p[j], st.act[j], v) ? v : acc[j] + v;
+    }
+    *reinterpret_cast<uint4 *>(a.phi + (size_t)r * kPvM + k0) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
 
@@ -372,7 +405,7 @@ hipError_t launch_pv_analyze(const PvArgs &a0, hipStream_t s) {
   const unsigned fb = (unsigned)((a.frames + a.frames_per_block - 1) / a.frames_per_block);
   const int64_t nchunks = (a.frames - a.first + a.scan_chunk - 1) / a.scan_chunk;
   hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
-  hipLaunchKernelGGL(pv_scan_sums, dim3(kPvM / 256, (unsigned)nchunks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(pv_scan_sums, dim3(kPvScanBlocks, (unsigned)nchunks), dim3(256), 0, s, a);
   if (a.tot_sums) hipLaunchKernelGGL(pv_scan_totals, dim3(kPvM / 256), dim3(256), 0, s, a, nchunks);
   return hipGetLastError();
 }
@@ -380,7 +413,7 @@ hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
   const int64_t nchunks = (a.frames - a.first + a.scan_chunk - 1) / a.scan_chunk;
   hipLaunchKernelGGL(pv_scan_chunks, dim3(kPvM / 256), dim3(256), 0, s, a, nchunks);
-  hipLaunchKernelGGL(pv_scan_apply, dim3(kPvM / 256, (unsigned)nchunks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(pv_scan_apply, dim3(kPvScanBlocks, (unsigned)nchunks), dim3(256), 0, s, a);
   hipLaunchKernelGGL(pv_synthesis, dim3((unsigned)pv_blocks(a.frames - a.first)), dim3(PV::T), 0, s, a);
   return hipGetLastError();
 }

@@ -12,7 +12,8 @@ and this file is the only oracle it can have.  The definition (N = 4096, Hs = 25
   analysis centre   a_f = floor(f*Hs/r)                     (input advances Hs/r per frame: stretch by r)
   frame             x_f[j] = w[j] * x[a_f - N/2 + j],  w = periodic Hann, zeros outside the file
   spectrum          X_f[k] = sum_j x_f[j] e^{-2 pi i jk/N} / N,  k = 0..N/2-1    (Nyquist bin dropped)
-  phase in turns    P_f[k] = round(arg X_f[k] / 2pi * 2^32) mod 2^32          (uint32)
+  phase in turns    P_f[k] = 2 * round(arg X_f[k] / 2pi * 2^31) mod 2^32      (uint32, even: the product keeps the
+                    bin's activity flag in the spare low bit of the same word)
   hop               h_f = a_f - a_{f-1}
   deviation         d = int32( P_f - P_{f-1} - (k*h_f mod N) * 2^32/N )        (wraps to [-1/2, 1/2) turn)
   synthesis advance inc = (k*Hs mod N) * 2^32/N + trunc(float64(d) * (Hs / h_f))   (uint32; one binary64 product,
@@ -66,7 +67,7 @@ def analysis(x, a, chunk=256):
         X = np.fft.rfft(fr, axis=1)[:, : N // 2] / N
         mags[f0:f0 + chunk] = np.abs(X)
         turns = np.angle(X) / (2.0 * np.pi)
-        ph[f0:f0 + chunk] = (np.rint(turns * 4294967296.0).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+        ph[f0:f0 + chunk] = ((np.rint(turns * 2147483648.0).astype(np.int64) << 1) & 0xFFFFFFFF).astype(np.uint32)
     return mags, ph
 
 
