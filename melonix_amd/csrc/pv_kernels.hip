@@ -23,7 +23,11 @@
 //                 a workgroup boundary see two workgroups: the left one leaves its partial sums in s, the
 //                 right one in a halo buffer
 //   pv_fixup      adds the halo to s across each boundary (in frame order: deterministic, no atomics)
-//   pv_resample   linear interpolation at i*r -> f32 / int16 PCM
+//   pv_resample   linear interpolation at i*r -> f32 / int16 PCM (pv_resample_frames: the marker-driven variant,
+//                 where each frame carries its own warped time and ratio and owns a range of output samples)
+// One rank of a multi-GPU run executes the same kernels on its range of frames in three stages
+// (launch_pv_analyze / _synthesize / _finish): the phase carry into the rank and the two overlap-add seams come
+// from its neighbours between the stages (capi.cpp mx_pv_shard_*, melonix_amd/shard.py).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
