@@ -90,3 +90,18 @@ def test_stft_kernels_do_not_spill():
     bad = [(n, s) for n, s in zip(names, scratch) if "stft_kernel" in n and s != 0]
     assert not bad, bad
     assert max(vgprs) <= 256
+
+
+def test_pv_kernels_do_not_spill():
+    """The phase-vocoder kernels share the FFT passes; the synthesis kernel lives close to the 256-VGPR line
+    (its window and split twiddles stay in registers): keep it scratch-free."""
+    src = os.path.join(ROOT, "melonix_amd", "csrc", "pv_kernels.hip")
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-ffp-contract=off", "-c", "-x", "hip", src,
+                          "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    vgprs = [int(x) for x in re.findall(r"\bVGPRs: (\d+)", out.stderr)]
+    assert len(names) == len(scratch) == len(vgprs) and len(names) >= 7
+    assert not [(n, s) for n, s in zip(names, scratch) if s != 0]
+    assert max(vgprs) <= 256
