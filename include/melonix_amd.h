@@ -73,6 +73,10 @@ void mx_ctx_destroy(mx_ctx *ctx);
 int mx_ctx_set_stream(mx_ctx *ctx, void *hip_stream);
 int mx_ctx_use_own_stream(mx_ctx *ctx);
 int mx_ctx_synchronize(mx_ctx *ctx);
+/* The context keeps its work buffers between calls (device staging of the host-pointer entry points, the phase
+ * vocoder's arena — tens of GB for an hour of audio —, the host landing zone of mx_grains_dev); this releases them.
+ * mx_ctx_destroy does so too. */
+int mx_ctx_release_scratch(mx_ctx *ctx);
 /* Tuning knob: consecutive frames one workgroup walks (0 = per-N default). */
 int mx_ctx_set_frames_per_block(mx_ctx *ctx, int frames);
 /* Thread-local description of the last error returned on this thread. */

@@ -112,6 +112,10 @@ class Context:
     def use_own_stream(self):
         _capi.check(_capi.lib().mx_ctx_use_own_stream(self.handle))
 
+    def release_scratch(self):
+        """Give back the work buffers the context keeps between calls (staging, phase-vocoder arena)."""
+        _capi.check(_capi.lib().mx_ctx_release_scratch(self.handle))
+
     def set_frames_per_block(self, g: int):
         _capi.check(_capi.lib().mx_ctx_set_frames_per_block(self.handle, g))
 

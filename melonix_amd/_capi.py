@@ -52,6 +52,7 @@ SIGNATURES = {
     "mx_ctx_set_stream": (_i, [_vp, _vp]),
     "mx_ctx_use_own_stream": (_i, [_vp]),
     "mx_ctx_synchronize": (_i, [_vp]),
+    "mx_ctx_release_scratch": (_i, [_vp]),
     "mx_ctx_set_frames_per_block": (_i, [_vp, _i]),
     "mx_last_error": (C.c_char_p, []),
     "mx_version": (C.c_char_p, []),

@@ -303,6 +303,29 @@ int mx_ctx_synchronize(mx_ctx *ctx) {
   return MX_OK;
 }
 
+int mx_ctx_release_scratch(mx_ctx *ctx) {
+  if (!ctx) return fail(MX_ERR_INVALID, "null context");
+  HIP_TRY(hipSetDevice(ctx->device));
+  {
+    std::lock_guard<std::mutex> lk(ctx->stage_mu);
+    for (auto &st : ctx->stage) {
+      hipFree(st.p);
+      st = {};
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->pv_mu);
+    hipFree(ctx->pv_arena.p);
+    ctx->pv_arena = {};
+    ctx->pv_job_active = false;  // a staged phase-vocoder job lives in that arena
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->zc_mu);
+    ctx->zc_scratch = ZcBitmaps{};
+  }
+  return MX_OK;
+}
+
 int mx_ctx_set_frames_per_block(mx_ctx *ctx, int g) {  // tuning knob (bench sweeps)
   if (!ctx || g < 0) return fail(MX_ERR_INVALID, "bad argument");
   ctx->frames_per_block = g;

@@ -108,6 +108,9 @@ def test_gpu_properties(gpu_ctx):
         assert 0.30 < np.sqrt((mid.astype(np.float64) ** 2).mean()) < 0.37
         y2, _ = gpu_ctx.pv_pitch_shift(a, st)
         assert np.array_equal(y.view(np.uint32), y2.view(np.uint32))
+    gpu_ctx.release_scratch()  # the arena is rebuilt on demand: same result after giving it back
+    y3, _ = gpu_ctx.pv_pitch_shift(a, -7.0)
+    assert np.array_equal(y3.view(np.uint32), y2.view(np.uint32))
     a.free()
     z = gpu_ctx.upload(np.zeros(20000, np.float32))
     yz, iz = gpu_ctx.pv_pitch_shift(z, 3.0)
