@@ -92,7 +92,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--fft", type=int, default=4096)
     ap.add_argument("--hop", type=int, default=256)
-    ap.add_argument("--minutes", type=float, default=60.0, help="audio per GPU")
+    ap.add_argument("--minutes", type=float, default=60.0, help="audio per GPU (weak scaling, the default)")
+    ap.add_argument("--strong-total-minutes", type=float, default=0.0,
+                    help="strong scaling instead: this much audio in TOTAL, split evenly over the ranks "
+                         "(BASELINE configs[3]: 480 = 8 h)")
     ap.add_argument("--pitch-only", action="store_true", help="do not materialise magnitudes")
     ap.add_argument("--frames-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,7 +129,9 @@ def main() -> None:
     import melonix_amd as mx
 
     N, hop = args.fft, args.hop
-    n = int(round(args.minutes * 60 * SR))
+    strong = args.strong_total_minutes > 0
+    minutes = args.strong_total_minutes / world if strong else args.minutes
+    n = int(round(minutes * 60 * SR))
     n -= n % hop  # shards start on frame boundaries so local and global frame indexing coincide
     F = mx.frame_count(n, hop)
     pad = mx.MX_AUDIO_PAD
@@ -282,12 +287,13 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.minutes:g} min synthetic 48 kHz mono sine sweep per GPU, FFT={N} hop={hop}, "
+                "workload": f"{minutes:g} min synthetic 48 kHz mono sine sweep per GPU"
+                            f"{f' ({args.strong_total_minutes:g} min in total)' if strong else ''}, FFT={N} hop={hop}, "
                             f"STFT magnitudes{'' if not args.pitch_only else ' (not stored)'} + pitch pick "
                             f"(BASELINE.json configs[1]: STFT+pitch only{'; configs[3] sharding' if world > 1 else ''}"
                             f"; resynthesis = configs[2], outside the timed region, see resynth_supplementary)",
