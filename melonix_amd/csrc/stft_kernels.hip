@@ -29,19 +29,38 @@ struct Tune {
   //   2 = this thread's pass-3 twiddles in registers for the whole workgroup + the pass-2 table in LDS
   //       (no global twiddle loads at all);
   //   3 = only the pass-2 table in LDS (1.9 / 3.8 / 7.9 KiB), pass-3 twiddles from L2 — for the sliding
-  //       N = 16384 kernel, whose register image of the frame leaves no room for 30 more VGPRs;
+  //       N >= 16384 kernels, whose register image of the frame leaves no room for 30 more VGPRs;
   //   (1 = all in registers: spills; 0 = both from L2 every frame.)
   template <bool SLIDING>
-  static constexpr int twreg() { return (P::N == 16384 && SLIDING) ? 3 : 2; }
+  static constexpr int twreg() { return (P::N >= 16384 && SLIDING) ? 3 : 2; }
+  // hops the sliding kernel is instantiated for (the larger shifts D = hop/2T need more edge/prefetch registers
+  // and spill: measured with -Rpass-analysis, asserted scratch-free in tests/test_abi.py)
+  static constexpr bool slides(int hop) {
+    return P::N == 4096 ? (hop == 256 || hop == 512) : P::N == 16384 ? (hop == 512 || hop == 1024) : hop == 1024;
+  }
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
   static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
   // with DEFER: free the image right after the T2 read, so the next T1 scatter can start under pass 1 (+1%)
   static constexpr bool EARLYBAR = DEFER;
 };
 
+// Launches the sliding-window kernel for HOP if the plan can slide by it (Slide<P,HOP>::ok) and the call asks for it.
+template <class P, int HOP>
+bool try_slide(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
+  if constexpr (Slide<P, HOP>::ok && Tune<P>::slides(HOP)) {
+    if (b.hop != HOP) return false;
+    constexpr int TRS = Tune<P>::template twreg<true>();
+    hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, HOP, Tune<P>::WPE, Tune<P>::NOHOIST, true, TRS, Tune<P>::OUTSEP,
+                                    Tune<P>::DEFER, false, Tune<P>::EARLYBAR>),
+                       grid, block, 0, s, b);
+    return true;
+  } else {
+    return false;
+  }
+}
+
 template <class P>
 hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
-  constexpr int N = P::N;
   if (a.count <= 0) return hipSuccess;
   const int g = a.frames_per_block > 0 ? a.frames_per_block : 1;
   const int64_t blocks = (a.count + g - 1) / g;
@@ -51,14 +70,16 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
   const dim3 grid((unsigned)blocks), block(P::T);
   constexpr int W = Tune<P>::WPE;
   constexpr bool NH = Tune<P>::NOHOIST;
-  constexpr int TRS = Tune<P>::template twreg<true>(), TRD = Tune<P>::template twreg<false>();
+  constexpr int TRD = Tune<P>::template twreg<false>();
   constexpr bool OS = Tune<P>::OUTSEP, DF = Tune<P>::DEFER, EB = Tune<P>::EARLYBAR;
   switch (mode) {
     case kBulkAligned:
-      // the headline hops slide the windowed frame through registers (one HBM read per sample)
-      if (N == 4096 && a.hop == 256) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 4096 ? 256 : 0), W, NH, true, (N == 4096 ? TRS : TRD), OS, DF, false, EB>), grid, block, 0, s, b);
-      else if (N == 16384 && a.hop == 512) hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, (N == 16384 ? 512 : 0), W, NH, true, (N == 16384 ? TRS : TRD), OS, DF, false, EB>), grid, block, 0, s, b);
-      else hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b);
+      // hops that are a small multiple of 2T samples slide the windowed frame through registers (one HBM read
+      // per sample): 256/512 at N = 4096, 512/1024 at N = 16384, 1024 at N = 32768; any other hop loads every
+      // frame directly
+      if (!(try_slide<P, 256>(b, grid, block, s) || try_slide<P, 512>(b, grid, block, s) ||
+            try_slide<P, 1024>(b, grid, block, s)))
+        hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b);
       break;
     case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b); break;
     case kRanges:

@@ -145,5 +145,8 @@ extern "C" int emu_stft_slide(int N, int E, int hop, const float *wav, long n, l
   if (N == 4096 && E == 32 && hop == 256) return run_slide<Plan<4096, 32>, 256>(wav, n, first, count, mags);
   if (N == 4096 && E == 16 && hop == 256) return run_slide<Plan<4096, 16>, 256>(wav, n, first, count, mags);
   if (N == 16384 && E == 32 && hop == 512) return run_slide<Plan<16384, 32>, 512>(wav, n, first, count, mags);
+  if (N == 4096 && E == 16 && hop == 512) return run_slide<Plan<4096, 16>, 512>(wav, n, first, count, mags);
+  if (N == 16384 && E == 32 && hop == 1024) return run_slide<Plan<16384, 32>, 1024>(wav, n, first, count, mags);
+  if (N == 32768 && E == 32 && hop == 1024) return run_slide<Plan<32768, 32>, 1024>(wav, n, first, count, mags);
   return -1;
 }

@@ -43,8 +43,12 @@ def test_ranges_vs_oracle(gpu_ctx, oracle, N):
     a.free()
 
 
+SLIDING_HOPS = ((4096, 256), (4096, 512), (16384, 512), (16384, 1024), (32768, 1024))  # stft_kernels.hip Tune::slides
+
+
 @pytest.mark.parametrize("N,hop", [(4096, 256), (16384, 512), (32768, 375), (4096, 375), (4096, 128), (4096, 512),
-                                   (16384, 256), (32768, 512), (4096, 2), (4096, 4096), (4096, 6000)])
+                                   (16384, 256), (32768, 512), (4096, 2), (4096, 4096), (4096, 6000),
+                                   (16384, 1024), (32768, 1024), (4096, 1024)])
 def test_hop_vs_oracle(gpu_ctx, oracle, N, hop):
     w = noisy(accum_sweep(4 * SR))
     n = len(w)
@@ -72,7 +76,7 @@ def test_hop_vs_oracle(gpu_ctx, oracle, N, hop):
     gpu_ctx.set_frames_per_block(0)
     rr = np.stack([pick * hop, (pick + 1) * hop], axis=1).astype(np.int32)
     m2, p2 = gpu_ctx.stft_ranges(a, N, rr, band=band)
-    if (N, hop) in ((4096, 256), (16384, 512)):
+    if (N, hop) in SLIDING_HOPS:
         assert np.array_equal(m2, m1[pick])
         assert np.array_equal(p2, p1[pick])
     else:

@@ -39,7 +39,7 @@ def timed(fn, reps=5, warm=2):
     return a.elapsed_time(b) / reps
 
 
-for N, hop in ((4096, 256), (16384, 512), (32768, 375), (32768, 512), (4096, 375)):
+for N, hop in ((4096, 256), (4096, 512), (16384, 512), (16384, 1024), (32768, 1024), (32768, 375), (32768, 512), (4096, 375)):
     F = mx.frame_count(n, hop)
     if F * (N // 2) * 4 > 60e9:
         continue
