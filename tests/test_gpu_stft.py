@@ -24,6 +24,28 @@ def _check_pitch(pitch, ref_mags, band, tol_rows):
     return len(bad)
 
 
+@pytest.mark.parametrize("N,seed", [(4096, 1), (4096, 2), (16384, 3), (32768, 4)])
+def test_random_ranges_vs_oracle(gpu_ctx, oracle, N, seed):
+    """Randomised (start, end) pairs as a display would produce them and far beyond: columns of any width from 1
+    sample to several frames, starts before the file, ends past it, reversed pairs, odd alignments."""
+    rng = np.random.default_rng(seed)
+    w = noisy(accum_sweep(5 * SR), level=0.01)
+    n = len(w)
+    cnt = 160 if N == 4096 else 48
+    ends = rng.integers(-2 * N, n + 2 * N, cnt)
+    widths = np.concatenate([rng.integers(1, 600, cnt // 2), rng.integers(-50, 4 * N, cnt - cnt // 2)])
+    ranges = np.stack([ends - widths, ends], axis=1).astype(np.int32)
+    a = gpu_ctx.upload(w)
+    band = oracle.pitch_band(N, SR)
+    mags, pitch = gpu_ctx.stft_ranges(a, N, ranges, band=band)
+    ref = np.stack([oracle.spec_frame(w, N, int(s), int(e)) for s, e in ranges])
+    tol = mag_tol(ref)
+    err = np.abs(mags - ref)
+    assert (err <= tol).all(), float((err / tol).max())
+    _check_pitch(pitch, ref, band, tol)
+    a.free()
+
+
 @pytest.mark.parametrize("N", SIZES)
 def test_ranges_vs_oracle(gpu_ctx, oracle, N):
     w = noisy(accum_sweep(10 * SR))
