@@ -192,3 +192,32 @@ def test_sharded_render_equals_whole(gpu_ctx, oracle, mxlib, world):
     _, opcm = oracle.export_run(w, SR, mk)
     assert np.array_equal(f_all.view(np.uint32), opcm.view(np.uint32))
     a.free()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_markers_bit_exact(gpu_ctx, oracle, mxlib, seed):
+    """Random sorted markers (bends that ramp, time stretch either way) on a noisy signal: schedule fields, float
+    PCM and int16 PCM equal the oracle's bit for bit, through the device grain scan and the resynthesis kernels."""
+    rng = np.random.default_rng(seed)
+    w = noisy(accum_sweep(6 * SR), level=float(rng.choice([0.0, 0.01, 0.08])))
+    n = len(w)
+    k = int(rng.integers(0, 6))
+    samples = np.sort(rng.integers(1, n - 1, k))
+    mk = [(int(s_), 0.0, float(rng.uniform(-0.3, 0.5)), float(rng.uniform(-12, 12))) for s_ in samples]
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    rs, rl = oracle.grains(w)
+    assert np.array_equal(s, rs) and np.array_equal(l, rl)
+    try:
+        steps, total = mxlib.schedule_build(w, SR, s, l, mk)
+    except mxlib.MxError:
+        a.free()
+        return
+    osteps, opcm = oracle.export_run(w, SR, mk, memo=False)
+    assert total == len(opcm) and len(steps) == len(osteps)
+    for f in ("cursor", "grain_start", "grain_len", "rate", "next_first", "sz", "out_offset"):
+        assert np.array_equal(steps[f], osteps[f]), f
+    f32, i16 = gpu_ctx.resynth(a, steps, total)
+    assert np.array_equal(f32.view(np.uint32), opcm.view(np.uint32))
+    assert np.array_equal(i16, oracle.pcm_to_i16(opcm))
+    a.free()
