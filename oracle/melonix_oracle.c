@@ -10,6 +10,7 @@
 #define _GNU_SOURCE
 #include "melonix_oracle.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -150,22 +151,101 @@ int mxo_fft_c2c_f64(int N, const double *in, double *out) {
  * Spec::internalGetSpec — spec.cpp:44-66, SpectrSize (spec.cpp:8) -> N
  * ====================================================================== */
 
+/* ---- optional provider: a library that implements the FFTW3 API, loaded at run time --------------------
+ * The reference calls fftw_plan_dft_1d(N, in, out, FFTW_FORWARD, FFTW_MEASURE) + fftw_execute (spec.cpp:11-15,
+ * 60).  No FFTW header or library ships with the reference or the image, so nothing is linked: if the machine
+ * has libfftw3.so.3, or Intel MKL's FFTW3 interface (libmkl_rt.so exports the same entry points), it is
+ * dlopen'ed and the reference's very call sequence runs on it.  Used (a) to cross-check the built-in DFT
+ * against a production implementation of that API and (b) as the CPU baseline's FFT, which is then of the class
+ * the reference's FFTW path would have.  Plans are created under a lock (FFTW's planner is not thread-safe),
+ * executed concurrently on per-thread buffers. */
+typedef void *(*fftw_plan_fn)(int, void *, void *, int, unsigned);
+typedef void (*fftw_exec_fn)(void *);
+typedef void (*fftw_destroy_fn)(void *);
+static struct {
+  int tried, ok;
+  const char *name;
+  fftw_plan_fn plan;
+  fftw_exec_fn exec;
+  fftw_destroy_fn destroy;
+  pthread_mutex_t mu;
+} g_fftw = {0, 0, "none", NULL, NULL, NULL, PTHREAD_MUTEX_INITIALIZER};
+
+static int fftw_api_load(void) {
+  pthread_mutex_lock(&g_fftw.mu);
+  if (!g_fftw.tried) {
+    g_fftw.tried = 1;
+    /* one FFT per host thread of ours: MKL must not bring its own thread pool (no effect on a real FFTW) */
+    setenv("MKL_THREADING_LAYER", "SEQUENTIAL", 0);
+    setenv("MKL_NUM_THREADS", "1", 0);
+    const char *env = getenv("MXO_FFTW_LIB");
+    const char *cands[] = {env, "libfftw3.so.3", "libfftw3.so", "libmkl_rt.so", "/opt/conda/lib/libmkl_rt.so", NULL};
+    for (int i = 0; i < 5 && !g_fftw.ok; ++i) {
+      if (!cands[i] || !*cands[i]) continue;
+      void *h = dlopen(cands[i], RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      g_fftw.plan = (fftw_plan_fn)dlsym(h, "fftw_plan_dft_1d");
+      g_fftw.exec = (fftw_exec_fn)dlsym(h, "fftw_execute");
+      g_fftw.destroy = (fftw_destroy_fn)dlsym(h, "fftw_destroy_plan");
+      if (g_fftw.plan && g_fftw.exec && g_fftw.destroy) {
+        g_fftw.ok = 1;
+        g_fftw.name = strstr(cands[i], "mkl") ? "mkl-fftw3-interface" : "fftw3";
+        /* one FFT per host thread: keep the library from spawning its own */
+        void (*setn)(int) = (void (*)(int))dlsym(h, "MKL_Set_Num_Threads");
+        if (setn) setn(1);
+        /* first use from this one thread: a library that initialises itself lazily then does so before the
+         * worker threads arrive (MKL initialised from eight threads at once ran five times slower afterwards) */
+        double *tmp = (double *)calloc(4 * 64, sizeof(double));
+        if (tmp) {
+          void *pl = g_fftw.plan(64, tmp, tmp + 2 * 64, -1, 0u);
+          if (pl) { g_fftw.exec(pl); g_fftw.destroy(pl); }
+          free(tmp);
+        }
+      }
+    }
+  }
+  const int ok = g_fftw.ok;
+  pthread_mutex_unlock(&g_fftw.mu);
+  return ok;
+}
+const char *mxo_fftw_api_name(void) { return fftw_api_load() ? g_fftw.name : "none"; }
+
 typedef struct frame_ws {
   int N;
   const fft_plan *pl;
   double *in, *out, *scratch;
+  void *fftw_plan; /* non-NULL: execute through the FFTW-API library */
 } frame_ws;
 
-static int ws_init(frame_ws *ws, int N) {
+static int ws_init_p(frame_ws *ws, int N, int use_fftw_api) {
+  memset(ws, 0, sizeof *ws);
   if (!is_pow2(N)) return -1;
   ws->N = N;
   ws->pl = plan_for(N);
+  ws->fftw_plan = NULL;
   ws->in = (double *)calloc(2 * (size_t)N, sizeof(double));
   ws->out = (double *)calloc(2 * (size_t)N, sizeof(double));
   ws->scratch = (double *)calloc(2 * (size_t)N, sizeof(double));
-  return (ws->in && ws->out && ws->scratch) ? 0 : -1;
+  if (!(ws->in && ws->out && ws->scratch)) return -1;
+  if (use_fftw_api) {
+    if (!fftw_api_load()) return -2;
+    pthread_mutex_lock(&g_fftw.mu);
+    ws->fftw_plan = g_fftw.plan(N, ws->in, ws->out, -1 /* FFTW_FORWARD */, 0u /* FFTW_MEASURE, spec.cpp:15 */);
+    pthread_mutex_unlock(&g_fftw.mu);
+    if (!ws->fftw_plan) return -2;
+    memset(ws->in, 0, sizeof(double) * 2 * (size_t)N); /* FFTW_MEASURE may scribble on the buffers */
+  }
+  return 0;
 }
-static void ws_free(frame_ws *ws) { free(ws->in); free(ws->out); free(ws->scratch); }
+static int ws_init(frame_ws *ws, int N) { return ws_init_p(ws, N, 0); }
+static void ws_free(frame_ws *ws) {
+  if (ws->fftw_plan) {
+    pthread_mutex_lock(&g_fftw.mu);
+    g_fftw.destroy(ws->fftw_plan);
+    pthread_mutex_unlock(&g_fftw.mu);
+  }
+  free(ws->in); free(ws->out); free(ws->scratch);
+}
 
 static void spec_frame_ws(frame_ws *ws, const float *wav, int n, int start, int end, float *ret) {
   const int N = ws->N;
@@ -182,7 +262,8 @@ static void spec_frame_ws(frame_ws *ws, const float *wav, int n, int start, int 
     else
       ws->in[2 * p] = expf(-2.5e-4f * (start - i)) * wav[i]; /* float expr, spec.cpp:58 */
   }
-  fft_exec(ws->pl, ws->in, ws->out, ws->scratch); /* spec.cpp:60 */
+  if (ws->fftw_plan) g_fftw.exec(ws->fftw_plan); /* spec.cpp:60 on the FFTW-API library */
+  else fft_exec(ws->pl, ws->in, ws->out, ws->scratch); /* spec.cpp:60 */
   /* spec.cpp:61-65: bins 0..N/2-1, double sqrt, / N, narrowed to float */
   for (int k = 0; k < N / 2; ++k) {
     const double re = ws->out[2 * k], im = ws->out[2 * k + 1];
@@ -222,13 +303,13 @@ void mxo_pitch_band(int N, int sampleRate, int *kmin, int *kmax) {
 
 typedef struct hop_job {
   const float *wav; int n, N, hop; long first, count; int kmin, kmax;
-  float *mags; int32_t *pbin; float *pmag; int rc;
+  float *mags; int32_t *pbin; float *pmag; int rc; int use_fftw_api;
 } hop_job;
 
 static void *hop_worker(void *arg) {
   hop_job *jb = (hop_job *)arg;
   frame_ws ws;
-  if (ws_init(&ws, jb->N)) { jb->rc = -1; return NULL; }
+  if (ws_init_p(&ws, jb->N, jb->use_fftw_api)) { jb->rc = -1; return NULL; }
   float *row = (float *)malloc(sizeof(float) * (size_t)(jb->N / 2));
   for (long f = 0; f < jb->count; ++f) {
     const long h = jb->first + f;
@@ -251,7 +332,29 @@ static void *hop_worker(void *arg) {
 int mxo_stft_hop(const float *wav, int n, int N, int hop, long first_frame, long count,
                  int kmin, int kmax, float *mags, int32_t *pitch_bin, float *pitch_mag,
                  int nthreads) {
+  return mxo_stft_hop_p(wav, n, N, hop, first_frame, count, kmin, kmax, mags, pitch_bin, pitch_mag, nthreads, 0);
+}
+
+int mxo_spec_frame_fftw_api(const float *wav, int n, int N, int start, int end, float *out) {
+  frame_ws ws;
+  const int rc = ws_init_p(&ws, N, 1);
+  if (rc) { ws_free(&ws); return rc; }
+  spec_frame_ws(&ws, wav, n, start, end, out);
+  ws_free(&ws);
+  return 0;
+}
+
+int mxo_stft_hop_p(const float *wav, int n, int N, int hop, long first_frame, long count,
+                   int kmin, int kmax, float *mags, int32_t *pitch_bin, float *pitch_mag,
+                   int nthreads, int use_fftw_api) {
   if (!is_pow2(N) || hop <= 0 || count < 0) return -1;
+  if (use_fftw_api) {
+    if (!fftw_api_load()) return -2;
+    /* the first plan of this size is made (and run once) here, before the worker threads make theirs */
+    frame_ws warm;
+    if (ws_init_p(&warm, N, 1) == 0) g_fftw.exec(warm.fftw_plan);
+    ws_free(&warm);
+  }
   if (nthreads < 1) nthreads = 1;
   if (nthreads > count) nthreads = count > 0 ? (int)count : 1;
   plan_for(N); /* build the twiddle table before threads race for it */
@@ -263,7 +366,7 @@ int mxo_stft_hop(const float *wav, int n, int N, int hop, long first_frame, long
     hop_job *jb = &jobs[t];
     jb->wav = wav; jb->n = n; jb->N = N; jb->hop = hop;
     jb->first = first_frame + done; jb->count = share;
-    jb->kmin = kmin; jb->kmax = kmax;
+    jb->kmin = kmin; jb->kmax = kmax; jb->use_fftw_api = use_fftw_api;
     jb->mags = mags ? mags + (size_t)done * (size_t)(N / 2) : NULL;
     jb->pbin = pitch_bin ? pitch_bin + done : NULL;
     jb->pmag = pitch_mag ? pitch_mag + done : NULL;

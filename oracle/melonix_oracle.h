@@ -66,6 +66,16 @@ int mxo_stft_hop(const float *wav, int n, int N, int hop, long first_frame, long
                  int kmin, int kmax, float *mags, int32_t *pitch_bin, float *pitch_mag,
                  int nthreads);
 
+/* The same two functions with the DFT executed by a library that implements the FFTW3 API, dlopen'ed at run time
+ * (libfftw3.so.3 if present, else Intel MKL's FFTW3 interface; MXO_FFTW_LIB overrides): spec.cpp's own call
+ * sequence fftw_plan_dft_1d(N, in, out, FFTW_FORWARD, FFTW_MEASURE) / fftw_execute on a production implementation.
+ * Return -2 when no such library can be loaded.  mxo_fftw_api_name(): "fftw3", "mkl-fftw3-interface" or "none". */
+const char *mxo_fftw_api_name(void);
+int mxo_spec_frame_fftw_api(const float *wav, int n, int N, int start, int end, float *out);
+int mxo_stft_hop_p(const float *wav, int n, int N, int hop, long first_frame, long count,
+                   int kmin, int kmax, float *mags, int32_t *pitch_bin, float *pitch_mag,
+                   int nthreads, int use_fftw_api);
+
 /* Build-defined pitch pick: argmax over k in [kmin,kmax],
  * ties -> lowest k. */
 int mxo_pitch_pick(const float *mags, int nbins, int kmin, int kmax, int32_t *bin, float *mag);

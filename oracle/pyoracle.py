@@ -87,6 +87,10 @@ def lib():
         L.mxo_free.argtypes = [C.c_void_p]
         L.mxo_export_run.argtypes = [fp, C.c_long, C.c_int, C.POINTER(Marker), C.c_int, C.c_int, C.POINTER(Export)]
         L.mxo_export_free.argtypes = [C.POINTER(Export)]
+        L.mxo_fftw_api_name.restype = C.c_char_p
+        L.mxo_spec_frame_fftw_api.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.mxo_stft_hop_p.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, fp,
+                                     C.POINTER(C.c_int32), fp, C.c_int, C.c_int]
         L.mxo_playback_fill.argtypes = [fp, C.c_long, C.c_int, C.POINTER(Marker), C.c_int, C.c_int, C.c_double, C.c_long,
                                         C.POINTER(Export)]
         L.mxo_pcm_to_i16.argtypes = [fp, C.c_long, C.POINTER(C.c_int16)]
@@ -148,13 +152,29 @@ def spec_frame(wav, N, start, end):
     return out
 
 
+def fftw_api_name():
+    """'fftw3', 'mkl-fftw3-interface' or 'none': the FFTW-API library the oracle could dlopen on this machine."""
+    return lib().mxo_fftw_api_name().decode()
+
+
+def spec_frame_fftw_api(wav, N, start, end):
+    """spec.cpp:44-66 with the DFT run by the machine's FFTW-API library (None if there is none)."""
+    wav, p = _f32(wav)
+    out = np.empty(N // 2, dtype=np.float32)
+    rc = lib().mxo_spec_frame_fftw_api(p, len(wav), N, start, end, out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc == -2:
+        return None
+    assert rc == 0
+    return out
+
+
 def pitch_band(N, sr):
     a, b = C.c_int(), C.c_int()
     lib().mxo_pitch_band(N, sr, C.byref(a), C.byref(b))
     return a.value, b.value
 
 
-def stft_hop(wav, N, hop, first=0, count=None, band=None, want_mags=True, nthreads=1, sr=48000):
+def stft_hop(wav, N, hop, first=0, count=None, band=None, want_mags=True, nthreads=1, sr=48000, fftw_api=False):
     wav, p = _f32(wav)
     n = len(wav)
     if count is None:
@@ -163,9 +183,10 @@ def stft_hop(wav, N, hop, first=0, count=None, band=None, want_mags=True, nthrea
     mags = np.empty((count, N // 2), dtype=np.float32) if want_mags else None
     pb = np.empty(count, dtype=np.int32)
     pm = np.empty(count, dtype=np.float32)
-    rc = lib().mxo_stft_hop(p, n, N, hop, first, count, kmin, kmax,
-                            mags.ctypes.data_as(C.POINTER(C.c_float)) if want_mags else None,
-                            pb.ctypes.data_as(C.POINTER(C.c_int32)), pm.ctypes.data_as(C.POINTER(C.c_float)), nthreads)
+    rc = lib().mxo_stft_hop_p(p, n, N, hop, first, count, kmin, kmax,
+                              mags.ctypes.data_as(C.POINTER(C.c_float)) if want_mags else None,
+                              pb.ctypes.data_as(C.POINTER(C.c_int32)), pm.ctypes.data_as(C.POINTER(C.c_float)), nthreads,
+                              1 if fftw_api else 0)
     assert rc == 0
     return mags, pb, pm
 

@@ -163,3 +163,25 @@ def test_golden_fixture(oracle, sweep10):
         rr = rows[f"ranges_{N}"]
         got = np.stack([oracle.spec_frame(sweep10, N, int(s_), int(e_)) for s_, e_ in rr])
         assert np.array_equal(got, rows[f"mags_{N}"])
+
+
+@pytest.mark.parametrize("N", [4096, 16384, 32768])
+def test_dft_matches_fftw_api_library(oracle, N):
+    """spec.cpp's call sequence — fftw_plan_dft_1d(N, in, out, FFTW_FORWARD, FFTW_MEASURE), fftw_execute — run on a
+    production implementation of the FFTW3 API found on this machine (a real libfftw3, else Intel MKL's FFTW3
+    interface) gives the magnitudes of the built-in restatement to the last or next-to-last binary32 digit.  (The
+    reference pins no FFTW version and ships no vectors, so this still is not a pin by the reference itself.)"""
+    if oracle.fftw_api_name() == "none":
+        pytest.skip("no library implementing the FFTW3 API on this machine")
+    from conftest import accum_sweep, noisy
+    w = noisy(accum_sweep(10 * 48000))
+    n = len(w)
+    for s, e in [(48000, 48375), (0, 256), (-500, -100), (239744, 240000), (479900, 480300), (100000, 100001),
+                 (1000, 60000), (n - 375, n)]:
+        a = oracle.spec_frame(w, N, s, e)
+        b = oracle.spec_frame_fftw_api(w, N, s, e)
+        assert b is not None
+        assert np.abs(a - b).max() <= 2.0 * np.spacing(np.float32(max(a.max(), 1e-30)))
+    m1, b1, p1 = oracle.stft_hop(w[:200000], N, 512, nthreads=4)
+    m2, b2, p2 = oracle.stft_hop(w[:200000], N, 512, nthreads=4, fftw_api=True)
+    assert np.abs(m1 - m2).max() <= 2.0 * np.spacing(np.float32(m1.max())) and (b1 == b2).mean() > 0.999
