@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ======================================================================
  * Double-precision forward DFT — stands where FFTW stands
@@ -304,25 +305,40 @@ void mxo_pitch_band(int N, int sampleRate, int *kmin, int *kmax) {
 typedef struct hop_job {
   const float *wav; int n, N, hop; long first, count; int kmin, kmax;
   float *mags; int32_t *pbin; float *pmag; int rc; int use_fftw_api;
+  pthread_barrier_t *start; /* timed runs: every thread has its plan and buffers before any starts on its frames */
+  int pick;                 /* timed runs: pick the pitch although nothing is stored */
+  long sink;                /* ... and keep the pick observable */
+  double t_begin, t_end;    /* CLOCK_MONOTONIC seconds around this thread's frame loop */
 } hop_job;
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static void *hop_worker(void *arg) {
   hop_job *jb = (hop_job *)arg;
   frame_ws ws;
-  if (ws_init_p(&ws, jb->N, jb->use_fftw_api)) { jb->rc = -1; return NULL; }
+  const int bad = ws_init_p(&ws, jb->N, jb->use_fftw_api);
   float *row = (float *)malloc(sizeof(float) * (size_t)(jb->N / 2));
+  if (jb->start) pthread_barrier_wait(jb->start);
+  if (bad) { free(row); jb->rc = -1; return NULL; }
+  jb->t_begin = now_s();
   for (long f = 0; f < jb->count; ++f) {
     const long h = jb->first + f;
     const int start = (int)(h * jb->hop), end = (int)((h + 1) * jb->hop);
     float *dst = jb->mags ? jb->mags + (size_t)f * (size_t)(jb->N / 2) : row;
     spec_frame_ws(&ws, jb->wav, jb->n, start, end, dst);
-    if (jb->pbin || jb->pmag) {
+    if (jb->pbin || jb->pmag || jb->pick) {
       int32_t b; float m;
       mxo_pitch_pick(dst, jb->N / 2, jb->kmin, jb->kmax, &b, &m);
       if (jb->pbin) jb->pbin[f] = b;
       if (jb->pmag) jb->pmag[f] = m;
+      jb->sink += b;
     }
   }
+  jb->t_end = now_s();
   free(row);
   ws_free(&ws);
   jb->rc = 0;
@@ -344,9 +360,9 @@ int mxo_spec_frame_fftw_api(const float *wav, int n, int N, int start, int end, 
   return 0;
 }
 
-int mxo_stft_hop_p(const float *wav, int n, int N, int hop, long first_frame, long count,
-                   int kmin, int kmax, float *mags, int32_t *pitch_bin, float *pitch_mag,
-                   int nthreads, int use_fftw_api) {
+static int stft_hop_impl(const float *wav, int n, int N, int hop, long first_frame, long count,
+                         int kmin, int kmax, float *mags, int32_t *pitch_bin, float *pitch_mag,
+                         int nthreads, int use_fftw_api, double *loop_seconds) {
   if (!is_pow2(N) || hop <= 0 || count < 0) return -1;
   if (use_fftw_api) {
     if (!fftw_api_load()) return -2;
@@ -360,6 +376,9 @@ int mxo_stft_hop_p(const float *wav, int n, int N, int hop, long first_frame, lo
   plan_for(N); /* build the twiddle table before threads race for it */
   hop_job *jobs = (hop_job *)calloc((size_t)nthreads, sizeof(hop_job));
   pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+  pthread_barrier_t start;
+  const int timed = loop_seconds != NULL && nthreads > 1;
+  if (timed) pthread_barrier_init(&start, NULL, (unsigned)nthreads);
   long done = 0;
   for (int t = 0; t < nthreads; ++t) {
     const long share = (count - done) / (nthreads - t);
@@ -370,6 +389,8 @@ int mxo_stft_hop_p(const float *wav, int n, int N, int hop, long first_frame, lo
     jb->mags = mags ? mags + (size_t)done * (size_t)(N / 2) : NULL;
     jb->pbin = pitch_bin ? pitch_bin + done : NULL;
     jb->pmag = pitch_mag ? pitch_mag + done : NULL;
+    jb->start = timed ? &start : NULL;
+    jb->pick = loop_seconds != NULL;
     done += share;
     if (nthreads == 1) hop_worker(jb);
     else pthread_create(&th[t], NULL, hop_worker, jb);
@@ -379,9 +400,31 @@ int mxo_stft_hop_p(const float *wav, int n, int N, int hop, long first_frame, lo
     if (nthreads > 1) pthread_join(th[t], NULL);
     if (jobs[t].rc) rc = -1;
   }
+  if (loop_seconds && rc == 0) { /* first thread into its frames .. last thread out */
+    double b = jobs[0].t_begin, e = jobs[0].t_end;
+    for (int t = 1; t < nthreads; ++t) {
+      if (jobs[t].t_begin < b) b = jobs[t].t_begin;
+      if (jobs[t].t_end > e) e = jobs[t].t_end;
+    }
+    *loop_seconds = e - b;
+  }
+  if (timed) pthread_barrier_destroy(&start);
   free(jobs);
   free(th);
   return rc;
+}
+
+int mxo_stft_hop_p(const float *wav, int n, int N, int hop, long first_frame, long count,
+                   int kmin, int kmax, float *mags, int32_t *pitch_bin, float *pitch_mag,
+                   int nthreads, int use_fftw_api) {
+  return stft_hop_impl(wav, n, N, hop, first_frame, count, kmin, kmax, mags, pitch_bin, pitch_mag, nthreads,
+                       use_fftw_api, NULL);
+}
+
+int mxo_stft_hop_timed(const float *wav, int n, int N, int hop, long first_frame, long count,
+                       int kmin, int kmax, int nthreads, int use_fftw_api, double *loop_seconds) {
+  return stft_hop_impl(wav, n, N, hop, first_frame, count, kmin, kmax, NULL, NULL, NULL, nthreads, use_fftw_api,
+                       loop_seconds);
 }
 
 /* ======================================================================

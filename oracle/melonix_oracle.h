@@ -75,6 +75,12 @@ int mxo_spec_frame_fftw_api(const float *wav, int n, int N, int start, int end, 
 int mxo_stft_hop_p(const float *wav, int n, int N, int hop, long first_frame, long count,
                    int kmin, int kmax, float *mags, int32_t *pitch_bin, float *pitch_mag,
                    int nthreads, int use_fftw_api);
+/* Throughput probe for bench.py's cpu_baseline: the same frames, nothing stored; every thread makes its plan and
+ * buffers first (FFTW-API planning is serialised), then all start together; *loop_seconds = first thread into its
+ * frames .. last thread out (setup excluded, as the reference plans once per Spec, spec.cpp:11-15). */
+int mxo_stft_hop_timed(const float *wav, int n, int N, int hop, long first_frame, long count,
+                       int kmin, int kmax, int nthreads, int use_fftw_api, double *loop_seconds);
+
 
 /* Build-defined pitch pick: argmax over k in [kmin,kmax],
  * ties -> lowest k. */

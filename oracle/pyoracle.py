@@ -91,6 +91,8 @@ def lib():
         L.mxo_spec_frame_fftw_api.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
         L.mxo_stft_hop_p.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, fp,
                                      C.POINTER(C.c_int32), fp, C.c_int, C.c_int]
+        L.mxo_stft_hop_timed.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.POINTER(C.c_double)]
         L.mxo_playback_fill.argtypes = [fp, C.c_long, C.c_int, C.POINTER(Marker), C.c_int, C.c_int, C.c_double, C.c_long,
                                         C.POINTER(Export)]
         L.mxo_pcm_to_i16.argtypes = [fp, C.c_long, C.POINTER(C.c_int16)]
@@ -189,6 +191,20 @@ def stft_hop(wav, N, hop, first=0, count=None, band=None, want_mags=True, nthrea
                               1 if fftw_api else 0)
     assert rc == 0
     return mags, pb, pm
+
+
+def stft_hop_timed(wav, N, hop, first=0, count=None, band=None, nthreads=1, sr=48000, fftw_api=False):
+    """Seconds the threads spent on the frames themselves (plans and buffers made before the common start):
+    the throughput probe behind bench.py's cpu_baseline."""
+    wav, p = _f32(wav)
+    n = len(wav)
+    if count is None:
+        count = (n + hop - 1) // hop - first
+    kmin, kmax = band if band is not None else pitch_band(N, sr)
+    secs = C.c_double(0.0)
+    rc = lib().mxo_stft_hop_timed(p, n, N, hop, first, count, kmin, kmax, nthreads, 1 if fftw_api else 0, C.byref(secs))
+    assert rc == 0
+    return secs.value
 
 
 def pitch_pick(mags, kmin, kmax):

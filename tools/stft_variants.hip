@@ -228,6 +228,27 @@ int main(int argc, char **argv) {
   time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true>(a16, reps, ABLNAME " pitch-only");
   return 0;
 #endif
+#ifdef GSWEEP
+  for (int rep = 0; rep < 2; ++rep)
+  for (int g : {24, 32, 40, 48, 64, 80, 96, 128, 192}) {
+    a16.frames_per_block = g;
+    time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true, false, true>(a16, reps, "shipped E=16");
+  }
+  return 0;
+#endif
+#ifdef P32SWEEP
+  for (int g : {32, 64}) {
+    a32.frames_per_block = a16.frames_per_block = g;
+    time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true, false, true>(a16, reps, "shipped E=16");
+    time_variant<P32, kBulkAligned, 256, 2, true, true, 0, false, false>(a32, reps, "E=32 tw L2, out via image");
+    time_variant<P32, kBulkAligned, 256, 2, true, true, 3, false, false>(a32, reps, "E=32 tw2 lds, out via image");
+    time_variant<P32, kBulkAligned, 256, 2, true, true, 3, true, false>(a32, reps, "E=32 tw2 lds, outsep");
+    time_variant<P32, kBulkAligned, 256, 2, true, true, 3, true, true>(a32, reps, "E=32 tw2 lds, defer");
+    time_variant<P32, kBulkAligned, 256, 2, true, true, 3, true, true, false, true>(a32, reps, "E=32 tw2 lds, defer earlybar");
+    time_variant<P32, kBulkAligned, 256, 2, true, true, 2, true, true>(a32, reps, "E=32 tw2 lds tw3 reg, defer");
+  }
+  return 0;
+#endif
   for (int g : {8, 16, 32}) {
     a32.frames_per_block = a16.frames_per_block = g;
     time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true>(a16, reps, "shipped: tw2lds defer wpe3");
