@@ -41,21 +41,48 @@ constexpr int kPvN = 4096, kPvM = kPvN / 2, kPvHs = 256;
 constexpr float kPvActiveRel = 1e-3f;  // a bin is active within 60 dB of its frame's peak
 static_assert(kPlan4096E == 16, "pv kernels use the 16-points-per-thread tables of N = 4096");
 
+// arg(re + i im) in turns as an even uint32 (2^-31 turn steps; the float carries 24 bits of it, and the low bit of
+// the word is free for the bin's activity flag); arg(0, 0) = 0.  atan(q)/2pi on q = min/max in [0, 1] is an odd
+// polynomial (degree 17, |error| < 2e-8 turn incl. f32 rounding — the resolution of the float itself at 1/8 turn),
+// then the octant is undone; no division, no 64-bit conversion (the libm atan2f + llrintf this replaces was half
+// of the kernel's instructions).
 __device__ __forceinline__ uint32_t to_turns(float re, float im) {
-  // arg in turns, rounded to 2^-31 and stored as an even uint32 (the float carries 24 bits of it; the low bit of
-  // the word is free for the bin's activity flag); atan2f(0,0) = 0
-  const float turns = atan2f(im, re) * 0.15915494309189535f;
-  return (uint32_t)((int64_t)llrintf(turns * 2147483648.0f) << 1);
+  const float ax = __builtin_fabsf(re), ay = __builtin_fabsf(im);
+  const float hi = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 1e-30f), lo = __builtin_fminf(ax, ay);
+  const float q = lo * __builtin_amdgcn_rcpf(hi);
+  const float z = q * q;
+  float p = 3.955824650e-04f;
+  p = fma_(p, z, -2.311495831e-03f);
+  p = fma_(p, z, 6.365358364e-03f);
+  p = fma_(p, z, -1.154612750e-02f);
+  p = fma_(p, z, 1.672621258e-02f);
+  p = fma_(p, z, -2.254327014e-02f);
+  p = fma_(p, z, 3.180934861e-02f);
+  p = fma_(p, z, -5.305053294e-02f);
+  p = fma_(p, z, 1.591549218e-01f);
+  float r = p * q;                  // [0, 1/8]
+  r = ay > ax ? 0.25f - r : r;      // [0, 1/4]
+  r = re < 0.f ? 0.5f - r : r;      // [0, 1/2]
+  r = __builtin_copysignf(r, im);   // (-1/2, 1/2]
+  return (uint32_t)(int32_t)__builtin_rintf(r * 2147483648.0f) << 1;  // |r * 2^31| <= 2^30
 }
 
 __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   using P = PV;
-  __shared__ __attribute__((aligned(16))) float2 lds[P::M];
+  // the M-point image + the pass-2 twiddle table (2 KiB, shared by both waves); this thread's pass-3 twiddles stay
+  // in registers for the whole walk: no twiddle loads per frame (stft_kernel's TWREG = 2 arrangement)
+  constexpr int kTw2 = ((P::TW2 + 1) / 2) * 2;
+  __shared__ __attribute__((aligned(16))) float2 lds[P::M + kTw2];
   __shared__ float red[2];
+  float2 *const ltw2 = lds + P::M;
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;
   cpx u[P::R3];
   post_twiddles<P>(t_, a.ubase, u);
+  cpx w3r[P::R3 - 1];
+  fetch_tw3<P>(t_, a.tw3, w3r);
+  for (int i = t_; i < P::TW2; i += P::T) ltw2[i] = a.tw2[i];
+  __syncthreads();
   const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_block;
   const int64_t f1 = f0 + a.frames_per_block < a.frames ? f0 + a.frames_per_block : a.frames;
   for (int64_t f = f0; f < f1; ++f) {
@@ -63,26 +90,31 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     // frame-invariant table value and address out of the loop (256 VGPRs and spills instead of ~150)
     int t = t_, zoff = 0;
     asm volatile("" : "+v"(t), "+s"(zoff));
-    const float2 *tw2 = a.tw2 + zoff, *tw3 = a.tw3 + zoff;
     const float *x = a.audio + MX_AUDIO_PAD + (a.apos[f] - P::N / 2);
-    cpx Y[P::E], v[P::E];
-    load_frame<P, 1, false>(t, Y, x, a.hann_scaled + zoff);
+    cpx Y[P::E], v[P::E], xr[P::E];
+    load_raw<P, false>(t, xr, x);
+    // (this thread's 32 window weights are indexed by the un-laundered thread index on purpose: LICM keeps them in
+    // registers for the whole walk)
+    apply_window<P, 1, true>(t_, Y, xr, a.hann_scaled);
     pass1<P>(Y, v);
-    __syncthreads();  // every wave is past the previous frame's load_t2
+    __syncthreads();  // every wave is past the previous frame's load_t2 and row reads
     store_t1<P>(t, v, lds);
     __syncthreads();
-    load_t1<P>(t, v, lds);
+    cpx w2b[1][P::R2 - 1];
+#ifdef MX_LDS_ASM  // (device pass only: the batch is hand-issued ds_read_b64)
+    load_t1_tw2<P>(t, v, lds, ltw2, w2b);
+#endif
     __syncthreads();
-    pass2<P>(t, v, tw2);
+    pass2_reg<P>(v, w2b);
     store_t2<P>(t, v, lds);
     __syncthreads();
     load_t2<P>(t, v, lds);
     cpx X[P::E];
     if (wave0) {
-      pass3<P, true>(t, v, tw3);
+      pass3_reg<P, true>(t, v, w3r);
       post_cplx<P, true>(t, v, u, X);
     } else {
-      pass3<P, false>(t, v, tw3);
+      pass3_reg<P, false>(t, v, w3r);
       post_cplx<P, false>(t, v, u, X);
     }
     float m[P::E];
@@ -102,14 +134,34 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     __syncthreads();  // (red is rewritten only after the next frame's four barriers)
     mx = red[0] > red[1] ? red[0] : red[1];
     const float thr = kPvActiveRel * mx;
-    float *mrow = a.mags + (size_t)f * P::M;
-    uint32_t *prow = a.phase + (size_t)f * P::M;
+    // Both rows leave through the (now free) image: every lane scatters its 16 bins as dwords (consecutive lanes ->
+    // consecutive bins), then owns 4 consecutive bins of each row — 8 stores of 1 KiB per wavefront instruction
+    // instead of 32 dword stores.  Bit 0 of the phase word: the bin is active — the phase sweeps then need this one
+    // word per bin and frame, not the magnitude.
+    float *lm = reinterpret_cast<float *>(lds);
+    uint32_t *lp = reinterpret_cast<uint32_t *>(lds) + P::M;
 #pragma unroll
     for (int o = 0; o < P::E; ++o) {
       const int k = out_bin<P>(t, o);
-      mrow[k] = m[o];
-      // bit 0: the bin is active — the phase sweeps then need this one word per bin and frame, not the magnitude
-      prow[k] = to_turns(X[o].x, X[o].y) | (m[o] >= thr ? 1u : 0u);
+      lm[k] = m[o];
+      lp[k] = to_turns(X[o].x, X[o].y) | (m[o] >= thr ? 1u : 0u);
+    }
+    __syncthreads();
+    using f32x4 = float __attribute__((ext_vector_type(4)));
+    using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
+    f32x4 qm[P::M / 4 / P::T];
+    u32x4 qp[P::M / 4 / P::T];
+#pragma unroll
+    for (int i = 0; i < P::M / 4 / P::T; ++i) {
+      qm[i] = reinterpret_cast<const f32x4 *>(lm)[t + P::T * i];
+      qp[i] = reinterpret_cast<const u32x4 *>(lp)[t + P::T * i];
+    }
+    f32x4 *mrow = reinterpret_cast<f32x4 *>(a.mags + (size_t)f * P::M) + t;
+    u32x4 *prow = reinterpret_cast<u32x4 *>(a.phase + (size_t)f * P::M) + t;
+#pragma unroll
+    for (int i = 0; i < P::M / 4 / P::T; ++i) {
+      mrow[P::T * i] = qm[i];
+      prow[P::T * i] = qp[i];
     }
   }
 }
@@ -405,7 +457,7 @@ int64_t pv_halo_floats(int64_t frames) { return pv_blocks(frames) * (int64_t)kPv
 hipError_t launch_pv_analyze(const PvArgs &a0, hipStream_t s) {
   PvArgs a = a0;
   if (a.frames - a.first <= 0) return hipSuccess;
-  a.frames_per_block = 8;
+  a.frames_per_block = 8;  // (measured 8/16/32/64: 5.5/5.7/5.9/6.0 ms per 60 min)
   const unsigned fb = (unsigned)((a.frames + a.frames_per_block - 1) / a.frames_per_block);
   const int64_t nchunks = (a.frames - a.first + a.scan_chunk - 1) / a.scan_chunk;
   hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
