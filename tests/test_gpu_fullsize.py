@@ -77,6 +77,42 @@ def test_stft_full_size_properties(gpu_ctx, oracle, hour):
     a.free()
 
 
+@pytest.mark.parametrize("N2,HOP2", [(16384, 512), (32768, 375)])
+def test_stft_full_size_other_plans(gpu_ctx, oracle, hour, N2, HOP2):
+    """BASELINE configs[4] (N = 16384, hop 512: 337 500 frames, the sliding kernel) and the reference's own
+    SpectrSize at the default view's column width (N = 32768, 375-sample columns, spec.cpp:8 / SURVEY 8a-5: 460 800
+    frames, direct loads with in-kernel weights) over the whole hour, through the same size-independent properties."""
+    w = hour
+    n = len(w)
+    F = (n + HOP2 - 1) // HOP2
+    a = gpu_ctx.upload(w)
+    band = oracle.pitch_band(N2, SR)
+    _, pitch = gpu_ctx.stft_hop(a, N2, HOP2, band=band, want_mags=False)
+    assert len(pitch) == F
+    h = np.arange(F)
+    f_inst = 110.0 + (1760.0 - 110.0) * ((h + 1) * HOP2 / SR) / (n / SR)
+    expect = f_inst * N2 / SR
+    sel = (expect > band[0] + 8) & (expect < band[1] - 8) & (h > N2 // HOP2)
+    # the window is ~4000 samples long whatever N is: a bin is SR/N wide, the peak's own width ~N/4000 bins
+    assert np.abs(pitch["bin"][sel] - expect[sel]).max() <= 1.5 * N2 / 4096
+    assert (pitch["mag"][sel] > 0.05 * 4096 / N2).all()
+    rng = np.random.default_rng(N2)
+    pick = np.unique(np.concatenate([[0, 1, N2 // HOP2, F - 2, F - 1], rng.integers(0, F, 24)]))
+    rr = np.stack([pick * HOP2, (pick + 1) * HOP2], axis=1).astype(np.int32)
+    m_ranges, p_ranges = gpu_ctx.stft_ranges(a, N2, rr, band=band)
+    # the same frames inside a bulk run (sliding window at 16384/512, derived weights at 32768/375)
+    for i in (3, 9, 17):
+        f = int(pick[i])
+        lo = max(0, f - 40)
+        m_run, p_run = gpu_ctx.stft_hop(a, N2, HOP2, first=lo, count=64, band=band)
+        assert (np.abs(m_run[f - lo] - m_ranges[i]) <= mag_tol(m_ranges[i][None])[0] / 10).all()
+        assert p_run["bin"][f - lo] == p_ranges["bin"][i] == pitch["bin"][f]
+    for i in (0, 7, len(pick) - 1):
+        ref = oracle.spec_frame(w, N2, int(rr[i, 0]), int(rr[i, 1]))
+        assert (np.abs(m_ranges[i] - ref) <= mag_tol(ref[None])[0]).all()
+    a.free()
+
+
 def test_resynth_full_size_properties(gpu_ctx, mxlib, hour):
     w = hour
     n = len(w)
