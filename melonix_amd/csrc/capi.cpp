@@ -1102,8 +1102,19 @@ int mx_resynth_dev(mx_ctx *ctx, const mx_audio *a, const mx_step *d_steps, int64
   return MX_OK;
 }
 
-int mx_resynth(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nsteps, int64_t nsamples,
-               float *pcm_f32_out, int16_t *pcm_i16_out) {
+}  // extern "C"
+
+namespace {
+// The device half of mx_resynth: checks the schedule's invariants, uploads it, allocates the requested PCM buffers and
+// runs the kernel (asynchronously on the context's stream).  The caller downloads and frees.
+struct ResynthBuffers {
+  mx_step *d_steps = nullptr;
+  float *d_f = nullptr;
+  int16_t *d_i = nullptr;
+  ~ResynthBuffers() { hipFree(d_steps); hipFree(d_f); hipFree(d_i); }
+};
+int resynth_to_device(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nsteps, int64_t nsamples, bool want_f,
+                      bool want_i, ResynthBuffers &b) {
   if (!ctx || !a || nsteps < 0 || nsamples < 0 || (nsteps > 0 && !steps)) return fail(MX_ERR_INVALID, "bad argument");
   int64_t covered = 0;
   for (int64_t i = 0; i < nsteps; ++i) {
@@ -1116,55 +1127,109 @@ int mx_resynth(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nst
   if (covered > nsamples) return fail(MX_ERR_INVALID, "steps emit %lld samples, nsamples is %lld", (long long)covered,
                                       (long long)nsamples);
   HIP_TRY(hipSetDevice(ctx->device));
-  mx_step *d_steps = nullptr;
-  float *d_f = nullptr;
-  int16_t *d_i = nullptr;
   hipError_t e = hipSuccess;
-  if (nsteps) e = hipMalloc(&d_steps, (size_t)nsteps * sizeof(mx_step));
-  if (e == hipSuccess && pcm_f32_out && nsamples) e = hipMalloc(&d_f, (size_t)nsamples * sizeof(float));
-  if (e == hipSuccess && pcm_i16_out && nsamples) e = hipMalloc(&d_i, (size_t)nsamples * sizeof(int16_t));
-  int rc = MX_OK;
-  if (e != hipSuccess) rc = fail(MX_ERR_NOMEM, "device buffers: %s", hipGetErrorString(e));
-  if (rc == MX_OK && nsteps)
-    if ((e = hipMemcpyAsync(d_steps, steps, (size_t)nsteps * sizeof(mx_step), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-      rc = fail(MX_ERR_DEVICE, "schedule upload: %s", hipGetErrorString(e));
+  if (nsteps) e = hipMalloc(&b.d_steps, (size_t)nsteps * sizeof(mx_step));
+  if (e == hipSuccess && want_f && nsamples) e = hipMalloc(&b.d_f, (size_t)nsamples * sizeof(float));
+  if (e == hipSuccess && want_i && nsamples) e = hipMalloc(&b.d_i, (size_t)nsamples * sizeof(int16_t));
+  if (e != hipSuccess) return fail(MX_ERR_NOMEM, "device buffers: %s", hipGetErrorString(e));
+  if (nsteps)
+    if ((e = hipMemcpyAsync(b.d_steps, steps, (size_t)nsteps * sizeof(mx_step), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+      return fail(MX_ERR_DEVICE, "schedule upload: %s", hipGetErrorString(e));
+  // anything between the covered run and the tail is zero by definition
+  if (b.d_f) hipMemsetAsync(b.d_f + covered, 0, (size_t)(nsamples - covered) * sizeof(float), ctx->stream);
+  if (b.d_i) hipMemsetAsync(b.d_i + covered, 0, (size_t)(nsamples - covered) * sizeof(int16_t), ctx->stream);
+  return mx_resynth_dev(ctx, a, b.d_steps, nsteps, nsamples, b.d_f, b.d_i);
+}
+}  // namespace
+
+extern "C" {
+
+int mx_resynth(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nsteps, int64_t nsamples,
+               float *pcm_f32_out, int16_t *pcm_i16_out) {
+  ResynthBuffers b;
+  int rc = resynth_to_device(ctx, a, steps, nsteps, nsamples, pcm_f32_out != nullptr, pcm_i16_out != nullptr, b);
   if (rc == MX_OK) {
-    // anything between the covered run and the tail is zero by definition
-    if (d_f) hipMemsetAsync(d_f + covered, 0, (size_t)(nsamples - covered) * sizeof(float), ctx->stream);
-    if (d_i) hipMemsetAsync(d_i + covered, 0, (size_t)(nsamples - covered) * sizeof(int16_t), ctx->stream);
-    rc = mx_resynth_dev(ctx, a, d_steps, nsteps, nsamples, d_f, d_i);
-  }
-  if (rc == MX_OK) {
-    if (d_f) e = hipMemcpyAsync(pcm_f32_out, d_f, (size_t)nsamples * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && d_i)
-      e = hipMemcpyAsync(pcm_i16_out, d_i, (size_t)nsamples * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (b.d_f) e = hipMemcpyAsync(pcm_f32_out, b.d_f, (size_t)nsamples * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && b.d_i)
+      e = hipMemcpyAsync(pcm_i16_out, b.d_i, (size_t)nsamples * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
+  } else if (ctx) {
+    hipStreamSynchronize(ctx->stream);  // nothing of ours may still be in flight when the buffers go
   }
-  hipFree(d_steps); hipFree(d_f); hipFree(d_i);
   return rc;
 }
 
 int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate, const mx_marker *markers,
                   int nmarkers, const char *path, int strict_reference_header) {
   if (!ctx || !path || n < 0 || (n > 0 && !host_wav)) return fail(MX_ERR_INVALID, "bad argument");
+  const bool tr = getenv("MELONIX_TIMING") != nullptr;
+  using clk = std::chrono::steady_clock;
+  auto ms = [](clk::time_point x, clk::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+  const auto t0 = clk::now();
   mx_audio *a = nullptr;
   int rc = mx_audio_upload(ctx, host_wav, n, &a);
   if (rc) return rc;
+  const auto t1 = clk::now();
   int32_t *gs = nullptr, *gl = nullptr;
   int64_t ng = 0, nsteps = 0, nsamples = 0;
   mx_step *steps = nullptr;
-  int16_t *pcm = nullptr;
   rc = mx_grains_dev(ctx, a, &gs, &gl, &ng);
+  const auto t2 = clk::now();
   if (rc == MX_OK) rc = mx_schedule_build(host_wav, n, sampleRate, gs, gl, ng, markers, nmarkers, &steps, &nsteps, &nsamples);
+  const auto t3 = clk::now();
+  // The PCM never exists as one host buffer: it leaves the device in 16 MiB pieces through two pinned landing
+  // buffers, and each piece goes into the file while the next one is in flight.
+  clk::time_point t4 = t3;
   if (rc == MX_OK) {
-    pcm = (int16_t *)malloc(sizeof(int16_t) * (size_t)std::max<int64_t>(nsamples, 1));
-    if (!pcm) rc = fail(MX_ERR_NOMEM, "out of host memory");
+    ResynthBuffers b;
+    rc = resynth_to_device(ctx, a, steps, nsteps, nsamples, false, true, b);
+    t4 = clk::now();
+    WavStream ws;
+    if (rc == MX_OK && wav_begin(ws, path, nsamples, sampleRate, strict_reference_header != 0) != MX_OK)
+      rc = fail(MX_ERR_IO, "cannot write %s", path);
+    if (rc == MX_OK) {
+      constexpr int64_t kPiece = 8 << 20;  // samples
+      int16_t *land[2] = {nullptr, nullptr};
+      hipEvent_t ev[2] = {nullptr, nullptr};
+      hipError_t e = hipSuccess;
+      const int64_t pieces = (nsamples + kPiece - 1) / kPiece;
+      for (int i = 0; i < 2 && e == hipSuccess && i < pieces; ++i) {
+        e = hipHostMalloc((void **)&land[i], (size_t)std::min<int64_t>(kPiece, nsamples) * sizeof(int16_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+      }
+      auto piece_len = [&](int64_t k) { return std::min<int64_t>(kPiece, nsamples - k * kPiece); };
+      for (int64_t k = 0; k <= pieces && e == hipSuccess; ++k) {
+        if (k < pieces) {
+          e = hipMemcpyAsync(land[k & 1], b.d_i + k * kPiece, (size_t)piece_len(k) * sizeof(int16_t), hipMemcpyDeviceToHost,
+                             ctx->stream);
+          if (e == hipSuccess) e = hipEventRecord(ev[k & 1], ctx->stream);
+        }
+        if (k > 0 && e == hipSuccess) {
+          e = hipEventSynchronize(ev[(k - 1) & 1]);
+          if (e == hipSuccess) wav_append(ws, land[(k - 1) & 1], piece_len(k - 1));
+        }
+      }
+      if (e != hipSuccess) {
+        hipStreamSynchronize(ctx->stream);
+        rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
+      }
+      for (int i = 0; i < 2; ++i) {
+        if (ev[i]) hipEventDestroy(ev[i]);
+        if (land[i]) hipHostFree(land[i]);
+      }
+      if (wav_end(ws) != MX_OK && rc == MX_OK) rc = fail(MX_ERR_IO, "cannot write %s", path);
+    } else if (ctx) {
+      hipStreamSynchronize(ctx->stream);
+    }
   }
-  if (rc == MX_OK) rc = mx_resynth(ctx, a, steps, nsteps, nsamples, nullptr, pcm);
-  if (rc == MX_OK) rc = mx_save_wav(path, pcm, nsamples, sampleRate, strict_reference_header);
-  free(pcm); mx_free(steps); mx_free(gs); mx_free(gl);
+  const auto t5 = clk::now();
+  mx_free(steps); mx_free(gs); mx_free(gl);
   mx_audio_free(ctx, a);
+  if (tr)
+    fprintf(stderr, "mx_export_wav: upload %.2f ms, grains %.2f, schedule %.2f, resynth launch %.2f, D2H + file %.2f, free %.2f\n",
+            ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, clk::now()));
   return rc;
 }
 

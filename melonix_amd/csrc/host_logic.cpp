@@ -345,8 +345,9 @@ void put_le(unsigned char *b, uint64_t v, int bytes) {
 }
 }  // namespace
 
-int write_wav(const char *path, const int16_t *pcm, int64_t m, int sampleRate, bool strict) {
-  if (!path || m < 0 || (m > 0 && !pcm)) return MX_ERR_INVALID;
+int wav_begin(WavStream &w, const char *path, int64_t m, int sampleRate, bool strict) {
+  w = WavStream{};
+  if (!path || m < 0) return MX_ERR_INVALID;
   unsigned char hdr[48];
   std::memcpy(hdr, "RIFF", 4);
   const uint64_t fileLength = 44 + 2 * (uint64_t)m;
@@ -361,26 +362,46 @@ int write_wav(const char *path, const int16_t *pcm, int64_t m, int sampleRate, b
   put_le(hdr + 34, 16, 2);
   std::memcpy(hdr + 36, "data", 4);
   size_t hdr_len = 44;
-  int64_t skip = 0;  // PCM samples replaced by header bytes
   if (strict) {
     // save-wav.cpp:43: writeWord(f, size_t(fileLength - dataChunkPos + 8)) with the
     // default size = sizeof(size_t) = 8 -> eight bytes at offset 40.
     put_le(hdr + 40, fileLength - 36 + 8, 8);
     hdr_len = 48;
-    skip = 2;
+    w.skip = 2;  // PCM samples replaced by header bytes
   } else {
     put_le(hdr + 40, 2 * (uint64_t)m, 4);
   }
-  FILE *f = std::fopen(path, "wb");
-  if (!f) return MX_ERR_IO;
-  bool ok = std::fwrite(hdr, 1, hdr_len, f) == hdr_len;
-  if (ok && m > skip) {
+  w.f = std::fopen(path, "wb");
+  if (!w.f) return MX_ERR_IO;
+  w.ok = std::fwrite(hdr, 1, hdr_len, w.f) == hdr_len;
+  return w.ok ? MX_OK : MX_ERR_IO;
+}
+
+void wav_append(WavStream &w, const int16_t *pcm, int64_t count) {
+  if (!w.f || count <= 0) return;
+  const int64_t drop = std::min<int64_t>(count, std::max<int64_t>(0, w.skip - w.seen));
+  w.seen += count;
+  if (w.ok && count > drop) {
     // int16 little-endian == the in-memory layout on the (little-endian) hosts this runs on
-    const size_t cnt = (size_t)(m - skip);
-    ok = std::fwrite(pcm + skip, sizeof(int16_t), cnt, f) == cnt;
+    const size_t cnt = (size_t)(count - drop);
+    w.ok = std::fwrite(pcm + drop, sizeof(int16_t), cnt, w.f) == cnt;
   }
-  ok = (std::fclose(f) == 0) && ok;
-  return ok ? MX_OK : MX_ERR_IO;
+}
+
+int wav_end(WavStream &w) {
+  if (!w.f) return MX_ERR_IO;
+  w.ok = (std::fclose(w.f) == 0) && w.ok;
+  w.f = nullptr;
+  return w.ok ? MX_OK : MX_ERR_IO;
+}
+
+int write_wav(const char *path, const int16_t *pcm, int64_t m, int sampleRate, bool strict) {
+  if (!path || m < 0 || (m > 0 && !pcm)) return MX_ERR_INVALID;
+  WavStream w;
+  const int rc = wav_begin(w, path, m, sampleRate, strict);
+  if (rc != MX_OK) return rc;
+  wav_append(w, pcm, m);
+  return wav_end(w);
 }
 
 }  // namespace mx

@@ -8,6 +8,7 @@
 // save-wav.cpp:17-48 (RIFF writer).
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <functional>
 #include <memory>
 #include <string>
@@ -111,5 +112,15 @@ struct PvPlan {
 int build_pv_plan(const mx_marker *markers, int nmarkers, int sampleRate, int64_t n, PvPlan &plan, std::string &err);
 
 int write_wav(const char *path, const int16_t *pcm, int64_t m, int sampleRate, bool strict);
+// The same file written in pieces (mx_export_wav streams the PCM off the device): begin writes the header for m
+// samples, append takes consecutive runs of them (the first two are the bytes save-wav.cpp:43 overwrites in strict mode).
+struct WavStream {
+  FILE *f = nullptr;
+  int64_t skip = 0, seen = 0;
+  bool ok = false;
+};
+int wav_begin(WavStream &w, const char *path, int64_t m, int sampleRate, bool strict);
+void wav_append(WavStream &w, const int16_t *pcm, int64_t count);
+int wav_end(WavStream &w);
 
 }  // namespace mx
