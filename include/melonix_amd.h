@@ -203,6 +203,12 @@ int mx_resynth(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nst
 int mx_resynth_dev(mx_ctx *ctx, const mx_audio *a, const mx_step *d_steps, int64_t nsteps,
                    int64_t nsamples, float *d_pcm_f32, int16_t *d_pcm_i16);
 
+/* The tail of App::exportWav (app.cpp:1209-1214) for a schedule that is already built and audio that is already
+ * on the device: resynthesis to int16 and saveWav, with the PCM streamed device -> pinned pieces -> file (it never
+ * exists as one host buffer).  File bytes = mx_resynth's int16 output through mx_save_wav. */
+int mx_resynth_to_wav(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nsteps,
+                      int64_t nsamples, const char *path, int sampleRate, int strict_reference_header);
+
 /* Whole App::exportWav (app.cpp:1194-1215): grains -> schedule -> GPU resynth
  * -> int16 -> saveWav.  strict_reference_header!=0 reproduces save-wav.cpp:43. */
 int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate,

@@ -261,6 +261,12 @@ class Context:
             off += 2 * int(counts[l])
         return out
 
+    def resynth_to_wav(self, audio: Audio, steps, nsamples: int, sr: int, path: str, strict: bool = True):
+        """Resynthesis of a built schedule straight into a WAV file (PCM streamed off the device in pieces)."""
+        steps = np.ascontiguousarray(steps)
+        _capi.check(_capi.lib().mx_resynth_to_wav(self.handle, audio.handle, _ptr(steps) if len(steps) else None,
+                                                  len(steps), nsamples, str(path).encode(), sr, 1 if strict else 0))
+
     def export_wav(self, wav, sr: int, markers, path: str, strict: bool = True):
         wav = np.ascontiguousarray(wav, dtype=np.float32)
         m = _capi.markers_array(markers)

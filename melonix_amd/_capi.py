@@ -86,6 +86,7 @@ SIGNATURES = {
     "mx_free": (None, [_vp]),
     "mx_resynth": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mx_resynth_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "mx_resynth_to_wav": (_i, [_vp, _vp, _vp, _i64, _i64, C.c_char_p, _i, _i]),
     "mx_export_wav": (_i, [_vp, _vp, _i64, _i, _vp, _i, C.c_char_p, _i]),
     "mx_pv_pitch_shift": (_i, [_vp, _vp, _d, _vp, _vp]),
     "mx_pv_pitch_shift_dev": (_i, [_vp, _vp, _d, _vp, _vp]),

@@ -101,10 +101,23 @@ bool Resynth::exportWavPV(const std::string &fileName, const std::vector<Marker>
 }
 
 bool Resynth::exportWav(const std::string &fileName, const std::vector<Marker> &markers) const {
-  std::vector<int16_t> pcm16;
-  if (!run(markers, nullptr, &pcm16)) return false;
-  saveWav(fileName, pcm16, sampleRate);  // app.cpp:1214
-  return true;
+  if (!ok()) return false;
+  // schedule on the host, then resynthesis + int16 + saveWav (app.cpp:1209-1214) with the PCM streamed from the device
+  // into the file in pieces; same bytes as render16() + saveWav()
+  mx_step *steps = nullptr;
+  int64_t nsteps = 0, nsamples = 0;
+  const mx_marker *mk = reinterpret_cast<const mx_marker *>(markers.data());
+  if (mx_schedule_build(host.data(), (int64_t)host.size(), sampleRate, starts.data(), lens.data(), (int64_t)starts.size(),
+                        mk, (int)markers.size(), &steps, &nsteps, &nsamples) != MX_OK)
+    return false;
+#ifdef MELONIX_CORRECT_WAV_HEADER
+  const int strict = 0;
+#else
+  const int strict = 1;
+#endif
+  const int rc = mx_resynth_to_wav(ctx, audio, steps, nsteps, nsamples, fileName.c_str(), sampleRate, strict);
+  mx_free(steps);
+  return rc == MX_OK;
 }
 
 }  // namespace melonix

@@ -1161,6 +1161,52 @@ int mx_resynth(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nst
   return rc;
 }
 
+int mx_resynth_to_wav(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nsteps, int64_t nsamples,
+                      const char *path, int sampleRate, int strict_reference_header) {
+  if (!ctx || !a || !path) return fail(MX_ERR_INVALID, "bad argument");
+  // The PCM never exists as one host buffer: it leaves the device in 16 MiB pieces through two pinned landing
+  // buffers, and each piece goes into the file while the next one is in flight.
+  ResynthBuffers b;
+  int rc = resynth_to_device(ctx, a, steps, nsteps, nsamples, false, true, b);
+  WavStream ws;
+  if (rc == MX_OK && wav_begin(ws, path, nsamples, sampleRate, strict_reference_header != 0) != MX_OK)
+    rc = fail(MX_ERR_IO, "cannot write %s", path);
+  if (rc != MX_OK) {
+    hipStreamSynchronize(ctx->stream);  // nothing of ours may still be in flight when the buffers go
+    return rc;
+  }
+  constexpr int64_t kPiece = 8 << 20;  // samples
+  int16_t *land[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  const int64_t pieces = (nsamples + kPiece - 1) / kPiece;
+  for (int i = 0; i < 2 && e == hipSuccess && i < pieces; ++i) {
+    e = hipHostMalloc((void **)&land[i], (size_t)std::min<int64_t>(kPiece, nsamples) * sizeof(int16_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+  }
+  auto piece_len = [&](int64_t k) { return std::min<int64_t>(kPiece, nsamples - k * kPiece); };
+  for (int64_t k = 0; k <= pieces && e == hipSuccess; ++k) {
+    if (k < pieces) {
+      e = hipMemcpyAsync(land[k & 1], b.d_i + k * kPiece, (size_t)piece_len(k) * sizeof(int16_t), hipMemcpyDeviceToHost,
+                         ctx->stream);
+      if (e == hipSuccess) e = hipEventRecord(ev[k & 1], ctx->stream);
+    }
+    if (k > 0 && e == hipSuccess) {
+      e = hipEventSynchronize(ev[(k - 1) & 1]);
+      if (e == hipSuccess) wav_append(ws, land[(k - 1) & 1], piece_len(k - 1));
+    }
+  }
+  const hipError_t es = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = es;
+  if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
+  for (int i = 0; i < 2; ++i) {
+    if (ev[i]) hipEventDestroy(ev[i]);
+    if (land[i]) hipHostFree(land[i]);
+  }
+  if (wav_end(ws) != MX_OK && rc == MX_OK) rc = fail(MX_ERR_IO, "cannot write %s", path);
+  return rc;
+}
+
 int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate, const mx_marker *markers,
                   int nmarkers, const char *path, int strict_reference_header) {
   if (!ctx || !path || n < 0 || (n > 0 && !host_wav)) return fail(MX_ERR_INVALID, "bad argument");
@@ -1179,57 +1225,14 @@ int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate,
   const auto t2 = clk::now();
   if (rc == MX_OK) rc = mx_schedule_build(host_wav, n, sampleRate, gs, gl, ng, markers, nmarkers, &steps, &nsteps, &nsamples);
   const auto t3 = clk::now();
-  // The PCM never exists as one host buffer: it leaves the device in 16 MiB pieces through two pinned landing
-  // buffers, and each piece goes into the file while the next one is in flight.
-  clk::time_point t4 = t3;
-  if (rc == MX_OK) {
-    ResynthBuffers b;
-    rc = resynth_to_device(ctx, a, steps, nsteps, nsamples, false, true, b);
-    t4 = clk::now();
-    WavStream ws;
-    if (rc == MX_OK && wav_begin(ws, path, nsamples, sampleRate, strict_reference_header != 0) != MX_OK)
-      rc = fail(MX_ERR_IO, "cannot write %s", path);
-    if (rc == MX_OK) {
-      constexpr int64_t kPiece = 8 << 20;  // samples
-      int16_t *land[2] = {nullptr, nullptr};
-      hipEvent_t ev[2] = {nullptr, nullptr};
-      hipError_t e = hipSuccess;
-      const int64_t pieces = (nsamples + kPiece - 1) / kPiece;
-      for (int i = 0; i < 2 && e == hipSuccess && i < pieces; ++i) {
-        e = hipHostMalloc((void **)&land[i], (size_t)std::min<int64_t>(kPiece, nsamples) * sizeof(int16_t), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
-      }
-      auto piece_len = [&](int64_t k) { return std::min<int64_t>(kPiece, nsamples - k * kPiece); };
-      for (int64_t k = 0; k <= pieces && e == hipSuccess; ++k) {
-        if (k < pieces) {
-          e = hipMemcpyAsync(land[k & 1], b.d_i + k * kPiece, (size_t)piece_len(k) * sizeof(int16_t), hipMemcpyDeviceToHost,
-                             ctx->stream);
-          if (e == hipSuccess) e = hipEventRecord(ev[k & 1], ctx->stream);
-        }
-        if (k > 0 && e == hipSuccess) {
-          e = hipEventSynchronize(ev[(k - 1) & 1]);
-          if (e == hipSuccess) wav_append(ws, land[(k - 1) & 1], piece_len(k - 1));
-        }
-      }
-      if (e != hipSuccess) {
-        hipStreamSynchronize(ctx->stream);
-        rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
-      }
-      for (int i = 0; i < 2; ++i) {
-        if (ev[i]) hipEventDestroy(ev[i]);
-        if (land[i]) hipHostFree(land[i]);
-      }
-      if (wav_end(ws) != MX_OK && rc == MX_OK) rc = fail(MX_ERR_IO, "cannot write %s", path);
-    } else if (ctx) {
-      hipStreamSynchronize(ctx->stream);
-    }
-  }
-  const auto t5 = clk::now();
+  if (rc == MX_OK) rc = mx_resynth_to_wav(ctx, a, steps, nsteps, nsamples, path, sampleRate, strict_reference_header);
+  const auto t4 = clk::now();
+  const auto t5 = t4;
   mx_free(steps); mx_free(gs); mx_free(gl);
   mx_audio_free(ctx, a);
   if (tr)
-    fprintf(stderr, "mx_export_wav: upload %.2f ms, grains %.2f, schedule %.2f, resynth launch %.2f, D2H + file %.2f, free %.2f\n",
-            ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, clk::now()));
+    fprintf(stderr, "mx_export_wav: upload %.2f ms, grains %.2f, schedule %.2f, resynth + D2H + file %.2f, free %.2f\n",
+            ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t5, clk::now()));
   return rc;
 }
 

@@ -68,6 +68,42 @@ def test_export_known_answers_bit_exact(gpu_ctx, oracle, mxlib, pb, steps, sampl
     a.free()
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_resynth_to_wav_streams_the_same_bytes(gpu_ctx, oracle, mxlib, tmp_path, strict):
+    """mx_resynth_to_wav (PCM streamed device -> pinned pieces -> file) writes exactly mx_resynth's int16 output through
+    saveWav: a render longer than two 8 Mi-sample pieces, a piece boundary inside, and the 0-/1-/2-sample files whose
+    first samples the reference's header write lands on (save-wav.cpp:43)."""
+    w = oracle.sweep(7 * 60 * SR)  # 20.2 M samples -> three pieces
+    n = len(w)
+    mk = [(1, 0, 0, -2.0), (n - 1, 0, 0, 4.0)]
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    st, total = mxlib.schedule_build(w, SR, s, l, mk)
+    assert total > 2 * (8 << 20)
+    _, i16 = gpu_ctx.resynth(a, st, total, want_f32=False)
+    path = tmp_path / "stream.wav"
+    gpu_ctx.resynth_to_wav(a, st, total, SR, path, strict=strict)
+    ref = tmp_path / "ref.wav"
+    mxlib.save_wav(ref, i16, SR, strict=strict)
+    assert path.read_bytes() == ref.read_bytes()
+    if strict:
+        assert path.read_bytes() == oracle.wav_bytes(i16, SR)
+    # degenerate schedules: nothing but the zero tail
+    for m in (0, 1, 2, 3):
+        st0 = st[:0]
+        gpu_ctx.resynth_to_wav(a, st0, m, SR, path, strict=strict)
+        mxlib.save_wav(ref, np.zeros(m, np.int16), SR, strict=strict)
+        assert path.read_bytes() == ref.read_bytes()
+    # errors: unwritable path, inconsistent schedule
+    with pytest.raises(mxlib.MxError):
+        gpu_ctx.resynth_to_wav(a, st, total, SR, tmp_path / "no_such_dir" / "x.wav")
+    bad = st.copy()
+    bad["out_offset"][3] += 1
+    with pytest.raises(mxlib.MxError):
+        gpu_ctx.resynth_to_wav(a, bad, total, SR, path)
+    a.free()
+
+
 def test_resynth_warp_markers_bit_exact(gpu_ctx, oracle, mxlib):
     w = noisy(accum_sweep(10 * SR), level=0.05)
     n = len(w)
