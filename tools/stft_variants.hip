@@ -228,6 +228,18 @@ int main(int argc, char **argv) {
   time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true>(a16, reps, ABLNAME " pitch-only");
   return 0;
 #endif
+#ifdef OCC4
+  for (int g : {16, 32}) {
+    a16.frames_per_block = g;
+    time_variant<P16, kBulkAligned, 256, 3, true, true, 2, true, true, false, true>(a16, reps, "shipped (3 waves/SIMD)");
+    time_variant<P16, kBulkAligned, 256, 4, true, true, 3, false, false>(a16, reps, "wpe4 tw2 lds tw3 L2, out via image");
+    time_variant<P16, kBulkAligned, 256, 4, true, true, 3, true, false>(a16, reps, "wpe4 tw2 lds tw3 L2, outsep");
+    time_variant<P16, kBulkAligned, 256, 4, true, true, 3, true, true, false, true>(a16, reps, "wpe4 tw2 lds tw3 L2, defer earlybar");
+    time_variant<P16, kBulkAligned, 256, 4, true, true, 2, false, false>(a16, reps, "wpe4 tw3 reg, out via image");
+    time_variant<P16, kBulkAligned, 256, 3, true, true, 3, false, false>(a16, reps, "wpe3 tw3 L2, out via image");
+  }
+  return 0;
+#endif
 #ifdef GSWEEP
   for (int rep = 0; rep < 2; ++rep)
   for (int g : {24, 32, 40, 48, 64, 80, 96, 128, 192}) {
