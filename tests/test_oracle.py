@@ -89,6 +89,24 @@ def test_fft_vs_independent_f64(oracle, N):
     assert np.max(np.abs(got - ref)) <= 1e-12 * np.sqrt(N) * np.max(np.abs(ref))
 
 
+@pytest.mark.parametrize("N", [4096, 16384, 32768])
+def test_fft_error_against_extended_precision(oracle, N):
+    """The restatement's own rounding error, measured against an 80-bit (x87 long double) transform of the same input
+    (scipy's pocketfft, a third implementation): it stays at the binary64 level any FFTW build works at, five orders
+    of magnitude below the binary32 magnitudes spec.cpp:63 rounds to — which FFTW build the reference links against
+    cannot move a result bit except at a rounding tie."""
+    sfft = pytest.importorskip("scipy.fft")
+    if np.finfo(np.longdouble).eps >= np.finfo(np.float64).eps:
+        pytest.skip("long double is binary64 on this platform")
+    rng = np.random.default_rng(7 * N)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    ref = sfft.fft(x.astype(np.clongdouble))
+    err_oracle = float(np.max(np.abs(oracle.fft(x) - ref)) / np.max(np.abs(ref)))
+    err_numpy = float(np.max(np.abs(np.fft.fft(x) - ref)) / np.max(np.abs(ref)))
+    assert err_oracle <= 4e-15 and err_oracle <= 8 * err_numpy
+    assert err_oracle < 1e-7 * float(np.finfo(np.float32).eps)  # far below one binary32 ulp of any bin
+
+
 def test_fft_analytic_pairs(oracle):
     N = 4096
     d = np.zeros(N, complex); d[3] = 1.0
