@@ -250,16 +250,18 @@ int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_ma
  * the two small exchanges between the stages with its own collective (melonix_amd/shard.py: RCCL / gloo
  * all-gathers): the per-rank phase totals after stage 1, the seams after stage 2.
  *   mx_pv_shard_frames      the rank's frame range and the output samples [out_lo, out_hi) it will deliver
- *   mx_pv_shard_analyze     stage 1; tot_sums_out[2048] / tot_any_out[2048]: this rank's (phase, restart) totals
- *   mx_pv_shard_synthesize  stage 2; carry_in[2048]: the totals of all lower ranks folded left to right with
- *                           (r1,v1)+(r2,v2) = (r1|r2, r2 ? v2 : v1+v2 mod 2^32) (NULL on rank 0);
+ *   mx_pv_shard_analyze     stage 1; tot_sums_out[2048] / tot_org_out[2048]: this rank's frames as one map of the
+ *                           phase row: bin k ends at value[org[k]] + sums[k] (mod 2^32), or at sums[k] where
+ *                           org[k] = 0xFFFF (the bin restarted inside the rank)
+ *   mx_pv_shard_synthesize  stage 2; carry_in[2048]: the phase row the rank starts from = the maps of all lower
+ *                           ranks applied in order to a zero row (NULL on rank 0);
  *                           head_out / tail_out[3840]: raw partial sums either side of the rank's frames
  *   mx_pv_shard_finish      stage 3; prev_tail = rank-1's tail_out (NULL on rank 0), next_head = rank+1's head_out
  *                           (NULL on the last rank); out_hi-out_lo samples each (host, either may be NULL) */
 int mx_pv_shard_frames(int64_t n, double semitones, int rank, int world, int64_t *frame_lo, int64_t *frame_hi,
                        int64_t *out_lo, int64_t *out_hi);
 int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world,
-                        uint32_t *tot_sums_out, uint8_t *tot_any_out);
+                        uint32_t *tot_sums_out, uint16_t *tot_org_out);
 int mx_pv_shard_synthesize(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out);
 int mx_pv_shard_finish(mx_ctx *ctx, const float *prev_tail, const float *next_head, float *pcm_f32_out,
                        int16_t *pcm_i16_out);

@@ -225,12 +225,12 @@ class Context:
 
     # ---- one rank of a multi-GPU phase-vocoder run (melonix_amd.shard.pv_pitch_shift_rank drives these) ----
     def pv_shard_analyze(self, audio: Audio, semitones: float, rank: int, world: int):
-        """Stage 1 -> (tot_sums uint32[2048], tot_any uint8[2048]): this rank's phase totals."""
+        """Stage 1 -> (tot_sums uint32[2048], tot_org uint16[2048]): this rank's frames as one map of the phase row."""
         sums = np.empty(2048, dtype=np.uint32)
-        anyf = np.empty(2048, dtype=np.uint8)
+        org = np.empty(2048, dtype=np.uint16)
         _capi.check(_capi.lib().mx_pv_shard_analyze(self.handle, audio.handle, float(semitones), rank, world,
-                                                    _ptr(sums), _ptr(anyf)))
-        return sums, anyf
+                                                    _ptr(sums), _ptr(org)))
+        return sums, org
 
     def pv_shard_synthesize(self, carry_in):
         """Stage 2 -> (head, tail) float32[3840] raw seams; carry_in: uint32[2048] or None on rank 0."""

@@ -600,9 +600,8 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   p.tw2 = t.tw2;
   p.tw3 = t.tw3;
   p.ubase = t.ubase;
-  // chunks of the frame axis for the scan: about a thousand of them (the sweep over the chunk totals is serial per
-  // bin), at least 64 frames each
-  p.scan_chunk = (int)std::max<int64_t>(64, (Fl - first + 1023) / 1024);
+  // chunks of the frame axis for the scan: about 768 of them (the pass over the chunk maps is serial), at least 64 frames each
+  p.scan_chunk = (int)std::max<int64_t>(64, (Fl - first + 767) / 768);  // (three row-walking workgroups per CU)
   p.s_len = (Fl - first) * Hs + N;
   p.s_origin = F_lo * Hs;
   const int64_t nchunks = (Fl - first + p.scan_chunk - 1) / p.scan_chunk;
@@ -614,8 +613,8 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   const size_t o_apos = take((size_t)Fl * 8), o_h = take(N * 4), o_hs = take(N * 4), o_m = take(rowsz * 4),
                o_p = take(rowsz * 4), o_i = take(rowsz * 4), o_c = take((size_t)nchunks * M * 4),
                o_f = take((size_t)pv_halo_floats(Fl - first) * 4), o_s = take(((size_t)p.s_len + 1) * 4),
-               o_w = take((size_t)M * 8), o_a = take((size_t)nchunks * M),
-               o_ts = take((size_t)M * 4), o_ta = take((size_t)M), o_ci = take((size_t)M * 4),
+               o_w = take((size_t)M * 8), o_a = take((size_t)nchunks * M * 2), o_ow = take(rowsz * 2),
+               o_ts = take((size_t)M * 4), o_ta = take((size_t)M * 2), o_ci = take((size_t)M * 4),
                o_pt = take((size_t)kPvSeam * 4), o_nh = take((size_t)kPvSeam * 4),
                o_tf = take(plan ? (size_t)Fl * 8 : 0), o_rf = take(plan ? (size_t)Fl * 8 : 0),
                o_i0 = take(plan ? ((size_t)Fl + 1) * 8 : 0), o_hp = take((size_t)Fl * 4), o_hr = take((size_t)Fl * 8);
@@ -646,7 +645,8 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host tables above die with this frame
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder setup: %s", hipGetErrorString(e));
-  p.chunk_any = reinterpret_cast<uint8_t *>(arena + o_a);
+  p.chunk_org = reinterpret_cast<uint16_t *>(arena + o_a);
+  p.owner = reinterpret_cast<uint16_t *>(arena + o_ow);
   p.apos = reinterpret_cast<const int64_t *>(arena + o_apos);
   p.hop = reinterpret_cast<const uint32_t *>(arena + o_hp);
   p.hratio = reinterpret_cast<const double *>(arena + o_hr);
@@ -666,7 +666,7 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   }
   if (want_totals) {
     p.tot_sums = reinterpret_cast<uint32_t *>(arena + o_ts);
-    p.tot_any = reinterpret_cast<uint8_t *>(arena + o_ta);
+    p.tot_org = reinterpret_cast<uint16_t *>(arena + o_ta);
   }
   // slots the staged (multi-GPU) entry points fill from host data
   ctx->pv_slot_carry = arena + o_ci;
@@ -815,8 +815,8 @@ int mx_pv_shard_frames(int64_t n, double semitones, int rank, int world, int64_t
 }
 
 int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world, uint32_t *tot_sums_out,
-                        uint8_t *tot_any_out) {
-  if (!ctx || !a || !tot_sums_out || !tot_any_out) return fail(MX_ERR_INVALID, "bad argument");
+                        uint16_t *tot_org_out) {
+  if (!ctx || !a || !tot_sums_out || !tot_org_out) return fail(MX_ERR_INVALID, "bad argument");
   int64_t lo, hi, olo, ohi;
   int rc = mx_pv_shard_frames(a->n, semitones, rank, world, &lo, &hi, &olo, &ohi);
   if (rc) return rc;
@@ -830,13 +830,26 @@ int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int ra
   ctx->pv_job_last = rank == world - 1;
   hipError_t e = launch_pv_analyze(p, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(tot_sums_out, p.tot_sums, kPvM * 4, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(tot_any_out, p.tot_any, kPvM, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(tot_org_out, p.tot_org, kPvM * 2, hipMemcpyDeviceToHost, ctx->stream);
   const hipError_t es = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess) e = es;
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (analysis): %s", hipGetErrorString(e));
   ctx->pv_job_active = true;
   return MX_OK;
 }
+
+#ifdef MX_PV_DEBUG
+// (debug builds only) one row of the staged job's intermediates: 0 mags, 1 phase words, 2 owners, 3 phi
+int mx_debug_pv_row(mx_ctx *ctx, int kind, int64_t row, void *out) {
+  if (!ctx || !ctx->pv_job_active || !out) return fail(MX_ERR_INVALID, "no staged job");
+  const PvArgs &p = ctx->pv_job;
+  if (row < 0 || row >= p.frames) return fail(MX_ERR_INVALID, "row out of range");
+  const void *src = kind == 0 ? (const void *)(p.mags + row * kPvM) : kind == 1 ? (const void *)(p.phase + row * kPvM)
+                   : kind == 2 ? (const void *)(p.owner + row * kPvM) : (const void *)(p.phi + row * kPvM);
+  hipStreamSynchronize(ctx->stream);
+  return hipMemcpy(out, src, (size_t)kPvM * (kind == 2 ? 2 : 4), hipMemcpyDeviceToHost) == hipSuccess ? MX_OK : MX_ERR_DEVICE;
+}
+#endif
 
 int mx_pv_shard_synthesize(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out) {
   if (!ctx || !head_out || !tail_out) return fail(MX_ERR_INVALID, "bad argument");

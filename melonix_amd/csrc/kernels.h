@@ -70,8 +70,9 @@ struct PvArgs {
   float *mags;        // [frames][N/2]
   uint32_t *phase;    // [frames][N/2] analysis phases: turns * 2^32 (even) | activity flag in bit 0
   uint32_t *phi;      // [frames][N/2] synthesis phases (output of the scan)
-  uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2]
-  uint8_t *chunk_any;    // same shape: the chunk contains a restart
+  uint16_t *owner;    // [frames][N/2] the peak each bin is locked to (0xFFFF: none)
+  uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2] a chunk's composed map: delta (or restart value) ...
+  uint16_t *chunk_org;   // ... and source bin at the chunk's start (0xFFFF: restart); then the chunk-start phases
   int scan_chunk;
   float *halo;        // pv_halo_floats(frames): partial sums right of each synthesis-workgroup boundary
   float *s;           // stretched signal, s_len = frames*Hs + N, index 0 = stretched time -N/2
@@ -83,8 +84,8 @@ struct PvArgs {
   int64_t first;             // local frames [first, frames) are this rank's; first = 1: row 0 is the frame before them
   int global_first;          // this rank holds the signal's frame 0
   const uint32_t *carry_in;  // [N/2] synthesis phase at the end of the previous rank's last frame (null: zero)
-  uint32_t *tot_sums;        // [N/2] out: this rank's total (restart, phase) over its frames (null: not wanted)
-  uint8_t *tot_any;
+  uint32_t *tot_sums;        // [N/2] out: this rank's total map over its frames (null: not wanted): delta / value ...
+  uint16_t *tot_org;         // ... and source bin at the rank's start (0xFFFF: restart)
   const float *prev_tail;    // [N-Hs] the previous rank's tail seam (raw sums), null on the first rank
   const float *next_head;    // [N-Hs] the next rank's head seam, null on the last rank
   int64_t out_lo, out_hi;    // output samples [out_lo, out_hi) of the whole signal are resampled here

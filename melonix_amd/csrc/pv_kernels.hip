@@ -39,6 +39,9 @@ namespace {
 using PV = Plan<4096, 16>;
 constexpr int kPvN = 4096, kPvM = kPvN / 2, kPvHs = 256;
 constexpr float kPvActiveRel = 1e-3f;  // a bin is active within 60 dB of its frame's peak
+constexpr int kPvReach = 32;            // a peak owns bins at most this far away
+constexpr float kPvPeakMargin = 0.9990234375f;  // 1 - 2^-10: near-ties are peaks on both sides, not left to rounding
+constexpr uint16_t kPvNoBin = 0xFFFF;   // owner / origin: none
 static_assert(kPlan4096E == 16, "pv kernels use the 16-points-per-thread tables of N = 4096");
 
 // arg(re + i im) in turns as an even uint32 (2^-31 turn steps; the float carries 24 bits of it, and the low bit of
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   constexpr int kTw2 = ((P::TW2 + 1) / 2) * 2;
   __shared__ __attribute__((aligned(16))) float2 lds[P::M + kTw2];
   __shared__ float red[2];
+  __shared__ uint32_t pkbits[P::M / 32];
   float2 *const ltw2 = lds + P::M;
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       lm[k] = m[o];
       lp[k] = to_turns(X[o].x, X[o].y) | (m[o] >= thr ? 1u : 0u);
     }
+    if (t < P::M / 32) pkbits[t] = 0u;  // (last read before the previous frame's closing barrier)
     __syncthreads();
     using f32x4 = float __attribute__((ext_vector_type(4)));
     using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
@@ -163,124 +168,211 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       mrow[P::T * i] = qm[i];
       prow[P::T * i] = qp[i];
     }
-  }
-}
-
-// One step of a bin's phase bookkeeping.  A bin that is active (|X| >= 1e-3 * frame peak) in this frame and the
-// previous one advances its synthesis phase by
-//   d   = int32(P_f - P_{f-1} - (k*h mod N) * 2^32/N)        deviation from the nominal advance over h samples
-//   inc = (k*Hs mod N) * 2^32/N + trunc(double(d) * (Hs/h))  one binary64 product of a binary64 quotient: the
-//                                                             same two roundings on every IEEE machine
-// any other bin, and every bin of frame 0, restarts from its analysis phase.  Returns true for a restart; `val` is
-// the new phase (restart) or the advance.
-// Takes the row's word (phase | activity) so that a sweep can fetch four bins with one 16-byte load.
-__device__ __forceinline__ bool pv_step(const PvArgs &a, int k, int64_t f, uint32_t word, uint32_t &prev_p, bool &prev_act,
-                                        uint32_t &val) {
-  const uint32_t p = word & ~1u;
-  const bool act = (word & 1u) != 0;
-  // hop[f] = a_f - a_{f-1} and hratio[f] = Hs / hop[f] (binary64 quotient) come from the host; hop 0 marks frame 0 and
-  // the frames of a marker-driven plan that stall or step backwards: every bin restarts there
-  const uint32_t h = a.hop[f];
-  const bool cont = act && prev_act && h >= 1;
-  if (cont) {
-    constexpr uint32_t unit = (uint32_t)(4294967296ull / kPvN);
-    const uint32_t expect = (((uint32_t)k * h) & (uint32_t)(kPvN - 1)) * unit;
-    const int32_t d = (int32_t)(p - prev_p - expect);
-    const int64_t q = (int64_t)((double)d * a.hratio[f]);  // truncates toward zero
-    val = (((uint32_t)k * (uint32_t)kPvHs) & (uint32_t)(kPvN - 1)) * unit + (uint32_t)q;
-  } else {
-    val = p;
-  }
-  prev_p = p;
-  prev_act = act;
-  return !cont;
-}
-
-// Segmented inclusive scan of those steps along the frame axis, in chunks of a.scan_chunk frames.  The operator on
-// (restart, value) pairs — (r1,v1)+(r2,v2) = (r1|r2, r2 ? v2 : v1+v2) — is associative, so chunk totals are combined
-// before the chunks are swept again.  A thread walks four adjacent bins (one 16-byte load per row: a workgroup reads
-// 4 KiB of every row it touches), so the previous frame's phase and activity are simply the previous iteration's.
-constexpr int kPvScanVec = 4, kPvScanBlocks = kPvM / (256 * kPvScanVec);
-struct PvScanState {
-  uint32_t p[kPvScanVec];
-  bool act[kPvScanVec];
-};
-__device__ __forceinline__ PvScanState pv_state_before(const PvArgs &a, int k0, int64_t f) {  // state after frame f-1
-  PvScanState st;
-  uint4 w = make_uint4(0u, 0u, 0u, 0u);
-  if (f > 0) w = *reinterpret_cast<const uint4 *>(a.phase + (size_t)(f - 1) * kPvM + k0);
-  const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    // Peaks of the row (active, not below rho times any of its four neighbours) as a 2048-bit map in LDS,
+    // then every bin's owner: the nearest peak at most kPvReach bins away, the lower one on a tie (phase locking).
 #pragma unroll
-  for (int j = 0; j < kPvScanVec; ++j) {
-    st.p[j] = ww[j] & ~1u;
-    st.act[j] = f > 0 && (ww[j] & 1u) != 0;
-  }
-  return st;
-}
-__global__ __launch_bounds__(256) void pv_scan_sums(const PvArgs a) {
-  const int k0 = (blockIdx.x * 256 + threadIdx.x) * kPvScanVec;
-  const int64_t c = blockIdx.y;
-  const int64_t r0 = a.first + c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
-  PvScanState st = pv_state_before(a, k0, r0);
-  uint32_t acc[kPvScanVec] = {0u, 0u, 0u, 0u}, any[kPvScanVec] = {0u, 0u, 0u, 0u};
-#pragma unroll 4
-  for (int64_t r = r0; r < r1; ++r) {  // (unrolled: the rows' loads do not depend on the running phase)
-    const uint4 w = *reinterpret_cast<const uint4 *>(a.phase + (size_t)r * kPvM + k0);
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    for (int i = 0; i < P::M / 4 / P::T; ++i) {
+      const int j = t + P::T * i;  // bins 4j .. 4j+3
+      const float2 lo = j > 0 ? reinterpret_cast<const float2 *>(lm)[2 * j - 1] : make_float2(-1.f, -1.f);
+      const float2 hi = j < P::M / 4 - 1 ? reinterpret_cast<const float2 *>(lm)[2 * j + 2] : make_float2(-1.f, -1.f);
+      const float v[8] = {lo.x, lo.y, qm[i].x, qm[i].y, qm[i].z, qm[i].w, hi.x, hi.y};
+      const uint32_t w[4] = {qp[i].x, qp[i].y, qp[i].z, qp[i].w};
+      uint32_t nib = 0;
 #pragma unroll
-    for (int j = 0; j < kPvScanVec; ++j) {
-      uint32_t v;
-      if (pv_step(a, k0 + j, r, ww[j], st.p[j], st.act[j], v)) { acc[j] = v; any[j] = 1; }
-      else acc[j] += v;
+      for (int b = 0; b < 4; ++b) {
+        const float c = v[b + 2];
+        const bool pk = (w[b] & 1u) && c >= kPvPeakMargin * v[b + 1] && c >= kPvPeakMargin * v[b] &&
+                        c >= kPvPeakMargin * v[b + 3] && c >= kPvPeakMargin * v[b + 4];
+        nib |= pk ? (1u << b) : 0u;
+      }
+      if (nib) atomicOr(&pkbits[j >> 3], nib << (4 * (j & 7)));
+    }
+    __syncthreads();
+    using u16x4 = uint16_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < P::M / 4 / P::T; ++i) {
+      const int j = t + P::T * i;
+      const int wi = j >> 3;
+      const uint32_t w0 = wi > 0 ? pkbits[wi - 1] : 0u, w1 = pkbits[wi], w2 = wi < P::M / 32 - 1 ? pkbits[wi + 1] : 0u;
+      const uint64_t below = ((uint64_t)w1 << 32) | w0, above = ((uint64_t)w2 << 32) | w1;
+      uint16_t o[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int k = 4 * j + b, bit = k & 31;
+        const uint64_t lm_ = below & (~0ull >> (31 - bit));  // peaks at or below k (bit 32 + `bit` is k itself)
+        const uint64_t rm_ = above & (~0ull << bit);         // peaks at or above k
+        const int dl = lm_ ? (32 + bit) - (63 - __builtin_clzll(lm_)) : 1 << 20;
+        const int dr = rm_ ? __builtin_ctzll(rm_) - bit : 1 << 20;
+        const int dmin = dl <= dr ? dl : dr;
+        o[b] = dmin <= kPvReach ? (uint16_t)(dl <= dr ? k - dl : k + dr) : kPvNoBin;
+      }
+      const u16x4 ov = {o[0], o[1], o[2], o[3]};
+      reinterpret_cast<u16x4 *>(a.owner + (size_t)f * P::M)[j] = ov;
     }
   }
-#pragma unroll
-  for (int j = 0; j < kPvScanVec; ++j) {
-    a.chunk_sums[c * kPvM + k0 + j] = acc[j];
-    a.chunk_any[c * kPvM + k0 + j] = (uint8_t)any[j];
-  }
 }
-// This rank's total over its own frames (multi-GPU: what the other ranks need to know of it); leaves the chunk
-// totals as they are.
-__global__ __launch_bounds__(256) void pv_scan_totals(const PvArgs a, int64_t nchunks) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  uint32_t acc = 0, any = 0;
-  for (int64_t c = 0; c < nchunks; ++c) {
-    const uint32_t v = a.chunk_sums[c * kPvM + k];
-    if (a.chunk_any[c * kPvM + k]) { acc = v; any = 1; }
-    else acc += v;
-  }
-  a.tot_sums[k] = acc;
-  a.tot_any[k] = (uint8_t)any;
+
+// Phase bookkeeping with identity phase locking (oracle/pv_oracle.py is the definition).  In frame f bin k with owner
+// peak p continues from what bin p held in frame f-1:
+//   Phi_f[k] = Phi_{f-1}[p] + inc_f[p] + (P_f[k] - P_f[p])      if p carried signal in both frames and h_f >= 1
+//   Phi_f[k] = P_f[k]                                            otherwise (restart)
+//   inc_f[p] = (p*Hs mod N) * 2^32/N + trunc(double(d) * (Hs/h)),  d = int32(P_f[p] - P_{f-1}[p] - (p*h mod N) * 2^32/N)
+// (one binary64 product of a binary64 quotient: the same two roundings on every IEEE machine; uint32 wrap = mod 1 turn).
+// So a frame is a map k -> (source bin, delta) | restart(value), and maps compose associatively: the frame axis is cut
+// into chunks, every chunk's composed map comes out of one sweep, the chunk-start phases out of a short serial pass over
+// the chunk maps, and a second sweep writes the rows.  Bins exchange values across the whole row, so a workgroup walks
+// whole rows: three analysis-phase rows rotate through LDS (previous, current, the one being filled) next to the
+// double-buffered state, one barrier per row.
+__device__ __forceinline__ uint32_t pv_inc(int k, uint32_t h, double hratio, uint32_t p, uint32_t prev_p) {
+  constexpr uint32_t unit = (uint32_t)(4294967296ull / kPvN);
+  const uint32_t expect = (((uint32_t)k * h) & (uint32_t)(kPvN - 1)) * unit;
+  const int32_t d = (int32_t)(p - prev_p - expect);
+  const int64_t q = (int64_t)((double)d * hratio);  // truncates toward zero
+  return (((uint32_t)k * (uint32_t)kPvHs) & (uint32_t)(kPvN - 1)) * unit + (uint32_t)q;
 }
-__global__ __launch_bounds__(256) void pv_scan_chunks(const PvArgs a, int64_t nchunks) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  uint32_t carry = a.carry_in ? a.carry_in[k] : 0u;  // the phase at the end of the previous rank's last frame
-  for (int64_t c = 0; c < nchunks; ++c) {  // carry into chunk c = phase at the end of chunk c-1
-    const uint32_t v = a.chunk_sums[c * kPvM + k];
-    const bool any = a.chunk_any[c * kPvM + k] != 0;
-    a.chunk_sums[c * kPvM + k] = carry;
-    carry = any ? v : carry + v;
-  }
-}
-__global__ __launch_bounds__(256) void pv_scan_apply(const PvArgs a) {
-  const int k0 = (blockIdx.x * 256 + threadIdx.x) * kPvScanVec;
-  const int64_t c = blockIdx.y;
+
+constexpr int kLockT = 512, kLockV = kPvM / kLockT;  // threads per row-walking workgroup, bins per thread
+static_assert(kLockV == 4, "a thread moves its bins as one 16-byte word");
+__host__ __device__ inline int64_t pv_chunks(const PvArgs &a) { return (a.frames - a.first + a.scan_chunk - 1) / a.scan_chunk; }
+
+// APPLY = false: the chunk's composed map -> chunk_org / chunk_sums.  APPLY = true: chunk_sums holds the phases at the
+// chunk's start (pv_lock_chunks); the rows of Phi are written.
+template <bool APPLY>
+__global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
+  using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
+  using u16x4 = uint16_t __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) uint32_t P[3][kPvM];
+  __shared__ __attribute__((aligned(16))) uint32_t D[2][kPvM];
+  __shared__ __attribute__((aligned(16))) uint16_t O[APPLY ? 1 : 2][APPLY ? 4 : kPvM];
+  const int t = threadIdx.x, k0 = t * kLockV;
+  const int64_t c = blockIdx.x;
   const int64_t r0 = a.first + c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
-  PvScanState st = pv_state_before(a, k0, r0);
-  uint32_t acc[kPvScanVec];
-#pragma unroll
-  for (int j = 0; j < kPvScanVec; ++j) acc[j] = a.chunk_sums[c * kPvM + k0 + j];
-#pragma unroll 4
+  u32x4 st;
+  if constexpr (APPLY) st = *reinterpret_cast<const u32x4 *>(a.chunk_sums + c * kPvM + k0);
+  else st = u32x4{0u, 0u, 0u, 0u};
+  *reinterpret_cast<u32x4 *>(&D[0][k0]) = st;
+  if constexpr (!APPLY) {
+    const u16x4 id = {(uint16_t)k0, (uint16_t)(k0 + 1), (uint16_t)(k0 + 2), (uint16_t)(k0 + 3)};
+    *reinterpret_cast<u16x4 *>(&O[0][k0]) = id;
+  }
+  u32x4 prevrow = u32x4{0u, 0u, 0u, 0u};
+  if (r0 > 0) prevrow = *reinterpret_cast<const u32x4 *>(a.phase + (size_t)(r0 - 1) * kPvM + k0);
+  *reinterpret_cast<u32x4 *>(&P[(r0 + 2) % 3][k0]) = prevrow;  // row r0 - 1 sits in slot (r0 - 1) mod 3
+  u32x4 wn = *reinterpret_cast<const u32x4 *>(a.phase + (size_t)r0 * kPvM + k0);
+  u16x4 on = *reinterpret_cast<const u16x4 *>(a.owner + (size_t)r0 * kPvM + k0);
+  int cur = 0;
+  u16x4 org_out = u16x4{kPvNoBin, kPvNoBin, kPvNoBin, kPvNoBin};
   for (int64_t r = r0; r < r1; ++r) {
-    const uint4 w = *reinterpret_cast<const uint4 *>(a.phase + (size_t)r * kPvM + k0);
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int j = 0; j < kPvScanVec; ++j) {
-      uint32_t v;
-      acc[j] = pv_step(a, k0 + j, r, ww[j], st.p[j], st.act[j], v) ? v : acc[j] + v;
+    const int pc = (int)(r % 3), pp = (int)((r + 2) % 3);
+    const u32x4 w = wn;
+    const u16x4 ow = on;
+    *reinterpret_cast<u32x4 *>(&P[pc][k0]) = w;
+    __syncthreads();  // row r and the state after row r-1 are complete; slot (r+1) mod 3 is no longer read
+    if (r + 1 < r1) {
+      wn = *reinterpret_cast<const u32x4 *>(a.phase + (size_t)(r + 1) * kPvM + k0);
+      on = *reinterpret_cast<const u16x4 *>(a.owner + (size_t)(r + 1) * kPvM + k0);
     }
-    *reinterpret_cast<uint4 *>(a.phi + (size_t)r * kPvM + k0) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+    const uint32_t h = a.hop[r];
+    const double hr = a.hratio[r];
+    const uint32_t wk[4] = {w.x, w.y, w.z, w.w};
+    const uint16_t ok[4] = {ow.x, ow.y, ow.z, ow.w};
+    uint32_t nd[4];
+    uint16_t no[4];
+#pragma unroll
+    for (int j = 0; j < kLockV; ++j) {
+      const uint32_t pk = wk[j] & ~1u;
+      nd[j] = pk;
+      no[j] = kPvNoBin;
+      const int p = ok[j];
+      if (h >= 1 && p != kPvNoBin) {
+        const uint32_t wp = P[pc][p], wq = P[pp][p];
+        if ((wp & wq & 1u) != 0u) {
+          const uint32_t pp_ = wp & ~1u;
+          nd[j] = D[cur][p] + pv_inc(p, h, hr, pp_, wq & ~1u) + (pk - pp_);
+          if constexpr (!APPLY) no[j] = O[cur][p];
+        }
+      }
+    }
+    const u32x4 ndv = {nd[0], nd[1], nd[2], nd[3]};
+    *reinterpret_cast<u32x4 *>(&D[cur ^ 1][k0]) = ndv;
+    if constexpr (!APPLY) {
+      org_out = u16x4{no[0], no[1], no[2], no[3]};
+      *reinterpret_cast<u16x4 *>(&O[cur ^ 1][k0]) = org_out;
+    } else {
+      __builtin_nontemporal_store(ndv, reinterpret_cast<u32x4 *>(a.phi + (size_t)r * kPvM + k0));
+    }
+    st = ndv;
+    cur ^= 1;
+  }
+  if constexpr (!APPLY) {
+    *reinterpret_cast<u32x4 *>(a.chunk_sums + c * kPvM + k0) = st;
+    *reinterpret_cast<u16x4 *>(a.chunk_org + c * kPvM + k0) = org_out;
+  }
+}
+
+// The serial pass over the chunk maps (one workgroup, two bins per thread, one barrier per chunk).
+// MAP = false: phases at every chunk's start, from carry_in (the phase row at the end of the previous rank's last
+// frame; irrelevant for the rank that holds frame 0, which restarts every bin) — they replace the chunk's delta row.
+// MAP = true: this rank's total map (tot_org, tot_sums), what the other ranks need to know of it; the chunk maps stay.
+constexpr int kChunkT = 1024, kChunkV = kPvM / kChunkT;
+template <bool MAP>
+__global__ __launch_bounds__(kChunkT) void pv_lock_chunks(const PvArgs a, int64_t nchunks) {
+  __shared__ uint32_t D[2][kPvM];
+  __shared__ uint16_t O[MAP ? 2 : 1][MAP ? kPvM : 2];
+  const int t = threadIdx.x;
+  uint32_t sd[kChunkV];
+  uint16_t so[kChunkV];
+#pragma unroll
+  for (int j = 0; j < kChunkV; ++j) {
+    const int k = t + kChunkT * j;
+    sd[j] = MAP ? 0u : (a.carry_in ? a.carry_in[k] : 0u);
+    so[j] = (uint16_t)k;
+    D[0][k] = sd[j];
+    if constexpr (MAP) O[0][k] = so[j];
+  }
+  int cur = 0;
+  uint32_t nd[kChunkV];
+  uint16_t no[kChunkV];
+#pragma unroll
+  for (int j = 0; j < kChunkV; ++j) {
+    nd[j] = nchunks > 0 ? a.chunk_sums[t + kChunkT * j] : 0u;
+    no[j] = nchunks > 0 ? a.chunk_org[t + kChunkT * j] : kPvNoBin;
+  }
+  for (int64_t c = 0; c < nchunks; ++c) {
+    __syncthreads();
+    uint32_t cd[kChunkV];
+    uint16_t co[kChunkV];
+#pragma unroll
+    for (int j = 0; j < kChunkV; ++j) { cd[j] = nd[j]; co[j] = no[j]; }
+    if (c + 1 < nchunks) {
+#pragma unroll
+      for (int j = 0; j < kChunkV; ++j) {
+        nd[j] = a.chunk_sums[(c + 1) * kPvM + t + kChunkT * j];
+        no[j] = a.chunk_org[(c + 1) * kPvM + t + kChunkT * j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kChunkV; ++j) {
+      const int k = t + kChunkT * j;
+      if constexpr (!MAP) a.chunk_sums[c * kPvM + k] = sd[j];  // the phases this chunk starts from
+      if (co[j] == kPvNoBin) {
+        sd[j] = cd[j];
+        so[j] = kPvNoBin;
+      } else {
+        sd[j] = D[cur][co[j]] + cd[j];
+        if constexpr (MAP) so[j] = O[cur][co[j]];
+      }
+      D[cur ^ 1][k] = sd[j];
+      if constexpr (MAP) O[cur ^ 1][k] = so[j];
+    }
+    cur ^= 1;
+  }
+  if constexpr (MAP) {
+#pragma unroll
+    for (int j = 0; j < kChunkV; ++j) {
+      a.tot_sums[t + kChunkT * j] = sd[j];
+      a.tot_org[t + kChunkT * j] = so[j];
+    }
   }
 }
 
@@ -290,7 +382,9 @@ __device__ __forceinline__ cpx pv_coef(const float *mrow, const uint32_t *prow, 
   const float m = mrow[k];
   const float turns = (float)(int32_t)prow[k] * 2.3283064365386963e-10f;  // [-1/2, 1/2)
   // v_sin_f32 / v_cos_f32 take their argument in turns
-  return mk(m * __builtin_amdgcn_cosf(turns), m * __builtin_amdgcn_sinf(turns));
+  // (bin 0 contributes its real part only — y is the real part of the one-sided sum — and a locked DC bin no longer
+  // has a real coefficient by construction)
+  return mk(m * __builtin_amdgcn_cosf(turns), k == 0 ? 0.f : m * __builtin_amdgcn_sinf(turns));
 }
 
 // y[j] = sum_{k<N} Yhat[k] e^{+2 pi i jk/N} (Hermitian extension, real).  Packed z[m] = y[2m] + i y[2m+1] is
@@ -459,17 +553,17 @@ hipError_t launch_pv_analyze(const PvArgs &a0, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
   a.frames_per_block = 8;  // (measured 8/16/32/64: 5.5/5.7/5.9/6.0 ms per 60 min)
   const unsigned fb = (unsigned)((a.frames + a.frames_per_block - 1) / a.frames_per_block);
-  const int64_t nchunks = (a.frames - a.first + a.scan_chunk - 1) / a.scan_chunk;
+  const int64_t nchunks = pv_chunks(a);
   hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
-  hipLaunchKernelGGL(pv_scan_sums, dim3(kPvScanBlocks, (unsigned)nchunks), dim3(256), 0, s, a);
-  if (a.tot_sums) hipLaunchKernelGGL(pv_scan_totals, dim3(kPvM / 256), dim3(256), 0, s, a, nchunks);
+  hipLaunchKernelGGL(pv_lock_walk<false>, dim3((unsigned)nchunks), dim3(kLockT), 0, s, a);
+  if (a.tot_sums) hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(1), dim3(kChunkT), 0, s, a, nchunks);
   return hipGetLastError();
 }
 hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
-  const int64_t nchunks = (a.frames - a.first + a.scan_chunk - 1) / a.scan_chunk;
-  hipLaunchKernelGGL(pv_scan_chunks, dim3(kPvM / 256), dim3(256), 0, s, a, nchunks);
-  hipLaunchKernelGGL(pv_scan_apply, dim3(kPvScanBlocks, (unsigned)nchunks), dim3(256), 0, s, a);
+  const int64_t nchunks = pv_chunks(a);
+  hipLaunchKernelGGL(pv_lock_chunks<false>, dim3(1), dim3(kChunkT), 0, s, a, nchunks);
+  hipLaunchKernelGGL(pv_lock_walk<true>, dim3((unsigned)nchunks), dim3(kLockT), 0, s, a);
   hipLaunchKernelGGL(pv_synthesis, dim3((unsigned)pv_blocks(a.frames - a.first)), dim3(PV::T), 0, s, a);
   return hipGetLastError();
 }

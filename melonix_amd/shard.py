@@ -113,22 +113,25 @@ def gather_pcm(dist, local, shards):
 
 
 # ---- phase vocoder across ranks (the overlap-add seams) ------------------------------------------
-def pv_fold_carry(tot_sums, tot_any, rank: int):
-    """Synthesis phase at the end of rank-1's last frame from the per-rank totals (arrays [world][2048]): the ranks
-    below `rank` folded left to right with (r1,v1)+(r2,v2) = (r1|r2, r2 ? v2 : v1+v2 mod 2^32)."""
+def pv_fold_carry(tot_sums, tot_org, rank: int):
+    """The phase row at the end of rank-1's last frame from the per-rank maps (arrays [world][2048]): the maps of the
+    ranks below `rank` applied in order to a zero row — bin k of a rank ends at row[org[k]] + sums[k] mod 2^32, or at
+    sums[k] where org[k] = 0xFFFF (the bin restarted inside that rank; the rank holding frame 0 restarts every bin)."""
     import numpy as np
 
     carry = np.zeros(np.asarray(tot_sums).shape[1], dtype=np.uint32)
     for r in range(rank):
         s_r = np.asarray(tot_sums[r], dtype=np.uint32)
-        carry = np.where(np.asarray(tot_any[r]) != 0, s_r, carry + s_r).astype(np.uint32)  # uint32 wraps = mod 1 turn
+        o_r = np.asarray(tot_org[r], dtype=np.uint16)
+        src = np.where(o_r == 0xFFFF, 0, o_r).astype(np.int64)
+        carry = np.where(o_r == 0xFFFF, s_r, carry[src] + s_r).astype(np.uint32)  # uint32 wraps = mod 1 turn
     return carry
 
 
 def pv_pitch_shift_rank(ctx, audio, semitones: float, dist, rank: int, world: int, want_i16: bool = True):
     """One rank's part of a multi-GPU phase-vocoder pitch shift.  `audio` is the WHOLE signal on this rank's GPU.
     Two small all-gathers (any torch.distributed backend; payloads are host tensors moved to `device` when the
-    backend needs device memory): 10 KiB of phase totals per rank, then the two 15 KiB seams per rank.
+    backend needs device memory): 12 KiB of phase maps per rank, then the two 15 KiB seams per rank.
     -> (out_lo, out_hi, f32, int16 | None): the rank's slice of the output."""
     import numpy as np
     import torch
@@ -143,11 +146,11 @@ def pv_pitch_shift_rank(ctx, audio, semitones: float, dist, rank: int, world: in
         dist.all_gather_into_tensor(out, mine)
         return out.cpu().numpy().reshape(world, -1)
 
-    sums, anyf = ctx.pv_shard_analyze(audio, semitones, rank, world)
-    tot = all_gather_bytes(np.concatenate([sums.view(np.uint8), anyf]))
+    sums, org = ctx.pv_shard_analyze(audio, semitones, rank, world)
+    tot = all_gather_bytes(np.concatenate([sums.view(np.uint8), org.view(np.uint8)]))
     all_sums = np.ascontiguousarray(tot[:, : 4 * 2048]).view(np.uint32).reshape(world, 2048)
-    all_any = tot[:, 4 * 2048:]
-    carry = pv_fold_carry(all_sums, all_any, rank) if rank > 0 else None
+    all_org = np.ascontiguousarray(tot[:, 4 * 2048:]).view(np.uint16).reshape(world, 2048)
+    carry = pv_fold_carry(all_sums, all_org, rank) if rank > 0 else None
     head, tail = ctx.pv_shard_synthesize(carry)
     seams = all_gather_bytes(np.concatenate([head, tail])).view(np.float32).reshape(world, 2, 3840)
     prev_tail = seams[rank - 1, 1] if rank > 0 else None

