@@ -613,7 +613,7 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   const size_t o_apos = take((size_t)Fl * 8), o_h = take(N * 4), o_hs = take(N * 4), o_m = take(rowsz * 4),
                o_p = take(rowsz * 4), o_i = take(rowsz * 4), o_c = take((size_t)nchunks * M * 4),
                o_f = take((size_t)pv_halo_floats(Fl - first) * 4), o_s = take(((size_t)p.s_len + 1) * 4),
-               o_w = take((size_t)M * 8), o_a = take((size_t)nchunks * M * 2), o_ow = take(rowsz * 2),
+               o_w = take((size_t)M * 8), o_a = take((size_t)nchunks * M * 2), o_ow = take((size_t)Fl * (M / 32) * 4),
                o_ts = take((size_t)M * 4), o_ta = take((size_t)M * 2), o_ci = take((size_t)M * 4),
                o_pt = take((size_t)kPvSeam * 4), o_nh = take((size_t)kPvSeam * 4),
                o_tf = take(plan ? (size_t)Fl * 8 : 0), o_rf = take(plan ? (size_t)Fl * 8 : 0),
@@ -646,7 +646,7 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host tables above die with this frame
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder setup: %s", hipGetErrorString(e));
   p.chunk_org = reinterpret_cast<uint16_t *>(arena + o_a);
-  p.owner = reinterpret_cast<uint16_t *>(arena + o_ow);
+  p.pkmap = reinterpret_cast<uint32_t *>(arena + o_ow);
   p.apos = reinterpret_cast<const int64_t *>(arena + o_apos);
   p.hop = reinterpret_cast<const uint32_t *>(arena + o_hp);
   p.hratio = reinterpret_cast<const double *>(arena + o_hr);
@@ -845,7 +845,7 @@ int mx_debug_pv_row(mx_ctx *ctx, int kind, int64_t row, void *out) {
   const PvArgs &p = ctx->pv_job;
   if (row < 0 || row >= p.frames) return fail(MX_ERR_INVALID, "row out of range");
   const void *src = kind == 0 ? (const void *)(p.mags + row * kPvM) : kind == 1 ? (const void *)(p.phase + row * kPvM)
-                   : kind == 2 ? (const void *)(p.owner + row * kPvM) : (const void *)(p.phi + row * kPvM);
+                   : kind == 2 ? (const void *)(p.pkmap + row * (kPvM / 32)) : (const void *)(p.phi + row * kPvM);
   hipStreamSynchronize(ctx->stream);
   return hipMemcpy(out, src, (size_t)kPvM * (kind == 2 ? 2 : 4), hipMemcpyDeviceToHost) == hipSuccess ? MX_OK : MX_ERR_DEVICE;
 }

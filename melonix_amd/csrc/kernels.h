@@ -70,7 +70,7 @@ struct PvArgs {
   float *mags;        // [frames][N/2]
   uint32_t *phase;    // [frames][N/2] analysis phases: turns * 2^32 (even) | activity flag in bit 0
   uint32_t *phi;      // [frames][N/2] synthesis phases (output of the scan)
-  uint16_t *owner;    // [frames][N/2] the peak each bin is locked to (0xFFFF: none)
+  uint32_t *pkmap;    // [frames][N/64] bit k: bin k is a spectral peak of the frame
   uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2] a chunk's composed map: delta (or restart value) ...
   uint16_t *chunk_org;   // ... and source bin at the chunk's start (0xFFFF: restart); then the chunk-start phases
   int scan_chunk;

@@ -10,12 +10,15 @@
 // scan gives exactly the serial result):
 //   pv_analysis   one workgroup walks consecutive frames: Hann-windowed frame at a_f -> the LDS-resident
 //                 real FFT of stft_core.h -> |X|/N and arg X as uint32 turns whose low bit is the
-//                 activity flag (|X| >= 1e-3 of the frame's peak), rows [F][N/2]
-//   pv_scan_*     per (frame, bin): wrapped deviation from the bin's nominal advance -> synthesis phase
-//                 advance (integer arithmetic); a bin accumulates only while it is active in this frame
-//                 and the previous one (|X| >= 1e-3 of the frame's peak), otherwise it restarts from its
-//                 analysis phase.  Chunked SEGMENTED inclusive scan of those steps along the frame axis
-//                 (uint32 wrap = mod 1 turn); the steps are recomputed in both sweeps, never stored
+//                 activity flag (|X| >= 1e-3 of the frame's peak), rows [F][N/2]; the frame's spectral peaks as
+//                 a 2048-bit map, [F][N/64]
+//   pv_lock_*     identity phase locking: a peak continues from what its bin held in the previous frame plus its
+//                 measured advance (integer arithmetic), every other bin takes its owner peak's synthesis phase plus
+//                 the analysis phase difference; a bin whose peak carried no signal in the previous frame restarts
+//                 from its analysis phase.  A frame is therefore a map bin -> (source bin, delta) | restart, maps
+//                 compose associatively, and the frame axis is scanned in chunks: composed chunk maps, a serial
+//                 pass over them, then the rows of Phi (uint32 wrap = mod 1 turn).  The maps are recomputed in
+//                 both sweeps from the phase rows and the peak maps, never stored
 //   pv_synthesis  a workgroup walks >= 32 consecutive frames: |X| e^{i Phi} -> inverse real FFT (the same
 //                 three passes run on the conjugated, pre-split spectrum) -> Hann window -> overlap-add in
 //                 an LDS ring of N samples; after each frame the oldest hop is complete and leaves as one
@@ -101,7 +104,8 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     // registers for the whole walk)
     apply_window<P, 1, true>(t_, Y, xr, a.hann_scaled);
     pass1<P>(Y, v);
-    __syncthreads();  // every wave is past the previous frame's load_t2 and row reads
+    __syncthreads();  // every wave is past the previous frame's load_t2, row reads and peak-map updates
+    if (f > f0 && t < P::M / 32) a.pkmap[(size_t)(f - 1) * (P::M / 32) + t] = pkbits[t];  // 256 B per frame
     store_t1<P>(t, v, lds);
     __syncthreads();
     cpx w2b[1][P::R2 - 1];
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       lm[k] = m[o];
       lp[k] = to_turns(X[o].x, X[o].y) | (m[o] >= thr ? 1u : 0u);
     }
-    if (t < P::M / 32) pkbits[t] = 0u;  // (last read before the previous frame's closing barrier)
+    if (t < P::M / 32) pkbits[t] = 0u;  // (the previous frame's map left after this frame's first barrier)
     __syncthreads();
     using f32x4 = float __attribute__((ext_vector_type(4)));
     using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
@@ -168,8 +172,8 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       mrow[P::T * i] = qm[i];
       prow[P::T * i] = qp[i];
     }
-    // Peaks of the row (active, not below rho times any of its four neighbours) as a 2048-bit map in LDS,
-    // then every bin's owner: the nearest peak at most kPvReach bins away, the lower one on a tie (phase locking).
+    // Peaks of the row (active, not below rho times any of its four neighbours) as a 2048-bit map: what the phase
+    // sweeps need to know of the magnitudes (they find every bin's owner peak in it).
 #pragma unroll
     for (int i = 0; i < P::M / 4 / P::T; ++i) {
       const int j = t + P::T * i;  // bins 4j .. 4j+3
@@ -187,29 +191,10 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       }
       if (nib) atomicOr(&pkbits[j >> 3], nib << (4 * (j & 7)));
     }
-    __syncthreads();
-    using u16x4 = uint16_t __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int i = 0; i < P::M / 4 / P::T; ++i) {
-      const int j = t + P::T * i;
-      const int wi = j >> 3;
-      const uint32_t w0 = wi > 0 ? pkbits[wi - 1] : 0u, w1 = pkbits[wi], w2 = wi < P::M / 32 - 1 ? pkbits[wi + 1] : 0u;
-      const uint64_t below = ((uint64_t)w1 << 32) | w0, above = ((uint64_t)w2 << 32) | w1;
-      uint16_t o[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int k = 4 * j + b, bit = k & 31;
-        const uint64_t lm_ = below & (~0ull >> (31 - bit));  // peaks at or below k (bit 32 + `bit` is k itself)
-        const uint64_t rm_ = above & (~0ull << bit);         // peaks at or above k
-        const int dl = lm_ ? (32 + bit) - (63 - __builtin_clzll(lm_)) : 1 << 20;
-        const int dr = rm_ ? __builtin_ctzll(rm_) - bit : 1 << 20;
-        const int dmin = dl <= dr ? dl : dr;
-        o[b] = dmin <= kPvReach ? (uint16_t)(dl <= dr ? k - dl : k + dr) : kPvNoBin;
-      }
-      const u16x4 ov = {o[0], o[1], o[2], o[3]};
-      reinterpret_cast<u16x4 *>(a.owner + (size_t)f * P::M)[j] = ov;
-    }
   }
+  // the last frame's peak map (every other frame's leaves after the next frame's first barrier, below)
+  __syncthreads();
+  if (f0 < f1 && t_ < P::M / 32) a.pkmap[(size_t)(f1 - 1) * (P::M / 32) + t_] = pkbits[t_];
 }
 
 // Phase bookkeeping with identity phase locking (oracle/pv_oracle.py is the definition).  In frame f bin k with owner
@@ -258,24 +243,42 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
   u32x4 prevrow = u32x4{0u, 0u, 0u, 0u};
   if (r0 > 0) prevrow = *reinterpret_cast<const u32x4 *>(a.phase + (size_t)(r0 - 1) * kPvM + k0);
   *reinterpret_cast<u32x4 *>(&P[(r0 + 2) % 3][k0]) = prevrow;  // row r0 - 1 sits in slot (r0 - 1) mod 3
+  __shared__ uint32_t pkw[2][kPvM / 32 + 2];  // the row's peak map, a zero word either side
+  if (t < 2) pkw[t][0] = pkw[t][kPvM / 32 + 1] = 0u;
   u32x4 wn = *reinterpret_cast<const u32x4 *>(a.phase + (size_t)r0 * kPvM + k0);
-  u16x4 on = *reinterpret_cast<const u16x4 *>(a.owner + (size_t)r0 * kPvM + k0);
+  uint32_t bn = t < kPvM / 32 ? a.pkmap[(size_t)r0 * (kPvM / 32) + t] : 0u;
   int cur = 0;
   u16x4 org_out = u16x4{kPvNoBin, kPvNoBin, kPvNoBin, kPvNoBin};
   for (int64_t r = r0; r < r1; ++r) {
     const int pc = (int)(r % 3), pp = (int)((r + 2) % 3);
     const u32x4 w = wn;
-    const u16x4 ow = on;
     *reinterpret_cast<u32x4 *>(&P[pc][k0]) = w;
+    if (t < kPvM / 32) pkw[r & 1][t + 1] = bn;
     __syncthreads();  // row r and the state after row r-1 are complete; slot (r+1) mod 3 is no longer read
     if (r + 1 < r1) {
       wn = *reinterpret_cast<const u32x4 *>(a.phase + (size_t)(r + 1) * kPvM + k0);
-      on = *reinterpret_cast<const u16x4 *>(a.owner + (size_t)(r + 1) * kPvM + k0);
+      if (t < kPvM / 32) bn = a.pkmap[(size_t)(r + 1) * (kPvM / 32) + t];
     }
     const uint32_t h = a.hop[r];
     const double hr = a.hratio[r];
     const uint32_t wk[4] = {w.x, w.y, w.z, w.w};
-    const uint16_t ok[4] = {ow.x, ow.y, ow.z, ow.w};
+    // owners of this thread's four bins: the nearest peak at most kPvReach bins away, the lower one on a tie
+    uint16_t ok[4];
+    {
+      const int wi = t >> 3;  // bins 4t .. 4t+3 sit in word wi of the map
+      const uint32_t w0 = pkw[r & 1][wi], w1 = pkw[r & 1][wi + 1], w2 = pkw[r & 1][wi + 2];
+      const uint64_t below = ((uint64_t)w1 << 32) | w0, above = ((uint64_t)w2 << 32) | w1;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int k = k0 + b, bit = k & 31;
+        const uint64_t lm_ = below & (~0ull >> (31 - bit));  // peaks at or below k (bit 32 + `bit` is k itself)
+        const uint64_t rm_ = above & (~0ull << bit);         // peaks at or above k
+        const int dl = lm_ ? (32 + bit) - (63 - __builtin_clzll(lm_)) : 1 << 20;
+        const int dr = rm_ ? __builtin_ctzll(rm_) - bit : 1 << 20;
+        const int dmin = dl <= dr ? dl : dr;
+        ok[b] = dmin <= kPvReach ? (uint16_t)(dl <= dr ? k - dl : k + dr) : kPvNoBin;
+      }
+    }
     uint32_t nd[4];
     uint16_t no[4];
 #pragma unroll
