@@ -92,17 +92,19 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   __syncthreads();
   const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_block;
   const int64_t f1 = f0 + a.frames_per_block < a.frames ? f0 + a.frames_per_block : a.frames;
+  // the samples of frame f + 1 are requested while frame f is in its last pass (their latency, left at the top of the
+  // loop, was a third of the kernel)
+  cpx xr[P::E];
+  if (f0 < f1) load_raw<P, false>(t_, xr, a.audio + MX_AUDIO_PAD + (a.apos[f0] - P::N / 2));
   for (int64_t f = f0; f < f1; ++f) {
     // as in stft_kernel: re-materialise the thread index and a zero table offset per frame, or LICM hoists every
     // frame-invariant table value and address out of the loop (256 VGPRs and spills instead of ~150)
     int t = t_, zoff = 0;
     asm volatile("" : "+v"(t), "+s"(zoff));
-    const float *x = a.audio + MX_AUDIO_PAD + (a.apos[f] - P::N / 2);
-    cpx Y[P::E], v[P::E], xr[P::E];
-    load_raw<P, false>(t, xr, x);
-    // (this thread's 32 window weights are indexed by the un-laundered thread index on purpose: LICM keeps them in
-    // registers for the whole walk)
-    apply_window<P, 1, true>(t_, Y, xr, a.hann_scaled);
+    cpx Y[P::E], v[P::E];
+    // (the window weights are reloaded per frame — L2 hits issued behind the already-landed samples: kept in
+    // registers for the whole walk they cost the third wave per SIMD once the sample prefetch holds 32 registers)
+    apply_window<P, 1, true>(t, Y, xr, a.hann_scaled + zoff);
     pass1<P>(Y, v);
     __syncthreads();  // every wave is past the previous frame's load_t2, row reads and peak-map updates
     if (f > f0 && t < P::M / 32) a.pkmap[(size_t)(f - 1) * (P::M / 32) + t] = pkbits[t];  // 256 B per frame
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     store_t2<P>(t, v, lds);
     __syncthreads();
     load_t2<P>(t, v, lds);
+    if (f + 1 < f1) load_raw<P, false>(t, xr, a.audio + MX_AUDIO_PAD + (a.apos[f + 1] - P::N / 2));
     cpx X[P::E];
     if (wave0) {
       pass3_reg<P, true>(t, v, w3r);
@@ -380,19 +383,18 @@ __global__ __launch_bounds__(kChunkT) void pv_lock_chunks(const PvArgs a, int64_
 }
 
 // One synthesis coefficient Yhat[k] = |X[k]|/N * e^{2 pi i Phi/2^32}; the Nyquist bin (k = M) is zero.
-__device__ __forceinline__ cpx pv_coef(const float *mrow, const uint32_t *prow, int k) {
-  if (k >= kPvM) return mk(0.f, 0.f);
-  const float m = mrow[k];
-  const float turns = (float)(int32_t)prow[k] * 2.3283064365386963e-10f;  // [-1/2, 1/2)
+__device__ __forceinline__ cpx pv_coef(float m, uint32_t phi, bool dc) {
+  const float turns = (float)(int32_t)phi * 2.3283064365386963e-10f;  // [-1/2, 1/2)
   // v_sin_f32 / v_cos_f32 take their argument in turns
   // (bin 0 contributes its real part only — y is the real part of the one-sided sum — and a locked DC bin no longer
   // has a real coefficient by construction)
-  return mk(m * __builtin_amdgcn_cosf(turns), k == 0 ? 0.f : m * __builtin_amdgcn_sinf(turns));
+  return mk(m * __builtin_amdgcn_cosf(turns), dc ? 0.f : m * __builtin_amdgcn_sinf(turns));
 }
 
 // y[j] = sum_{k<N} Yhat[k] e^{+2 pi i jk/N} (Hermitian extension, real).  Packed z[m] = y[2m] + i y[2m+1] is
 // 2*conj(DFT_M(conj Z')) with Z'[c] = (A+B)/2 + i e^{+2 pi i c/N} (A-B)/2, A = Yhat[c], B = conj(Yhat[M-c]):
 // the forward passes of stft_core.h run on G[c] = conj((A+B) + i w_c (A-B)) and the frame is conj of the result.
+__device__ constexpr float kW32[16][2] = {{1.000000000f, 0.000000000f}, {0.980785280f, 0.195090322f}, {0.923879533f, 0.382683432f}, {0.831469612f, 0.555570233f}, {0.707106781f, 0.707106781f}, {0.555570233f, 0.831469612f}, {0.382683432f, 0.923879533f}, {0.195090322f, 0.980785280f}, {0.000000000f, 1.000000000f}, {-0.195090322f, 0.980785280f}, {-0.382683432f, 0.923879533f}, {-0.555570233f, 0.831469612f}, {-0.707106781f, 0.707106781f}, {-0.831469612f, 0.555570233f}, {-0.923879533f, 0.382683432f}, {-0.980785280f, 0.195090322f}};  // e^{2 pi i e/32}
 constexpr int kPvBlockFrames = 32;       // frames per synthesis workgroup (the last one takes the remainder too)
 constexpr int kPvHalo = kPvN - kPvHs;    // samples either side of a workgroup boundary that two workgroups feed
 constexpr float kPvNorm = 1.0f / (3.0f * kPvN / (8.0f * kPvHs));
@@ -401,7 +403,7 @@ __host__ __device__ constexpr int64_t pv_blocks(int64_t frames) {
   return frames / kPvBlockFrames > 0 ? frames / kPvBlockFrames : 1;
 }
 
-__global__ __launch_bounds__(PV::T) void pv_synthesis(const PvArgs a) {
+__global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) void pv_synthesis(const PvArgs a) {
   using P = PV;
   __shared__ __attribute__((aligned(16))) float2 lds[P::M];
   __shared__ __attribute__((aligned(16))) float ring[P::N];  // overlap-add accumulator, stretched time mod N
@@ -413,6 +415,26 @@ __global__ __launch_bounds__(PV::T) void pv_synthesis(const PvArgs a) {
   const int64_t f0 = a.first + blk * kPvBlockFrames;  // local frame indices; s[0] belongs to local frame a.first
   const int64_t f1 = blk == nb - 1 ? a.frames : f0 + kPvBlockFrames;
   float2 *ring2 = reinterpret_cast<float2 *>(ring);
+  // This thread's 2 x 16 bins of a frame: c = t + T e and its mirror M - c (bin M, thread 0's mirror of c = 0, is the
+  // dropped Nyquist bin: the load is clamped and the coefficient zeroed).  The rows of frame f + 1 are requested while
+  // frame f is in its last pass — left at the top of the loop their latency is the kernel (3.5 of 7.0 ms).
+  float rm[2 * P::E];
+  uint32_t rp[2 * P::E];
+  auto fetch_rows = [&](int64_t fr, int tt) {
+    const float *mrow = a.mags + (size_t)fr * P::M;
+    const uint32_t *prow = a.phi + (size_t)fr * P::M;
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      const int c = tt + P::T * e;
+      const int cm = (P::M - c) & (P::M - 1);  // (c = 0 -> 0: clamped)
+      rm[2 * e] = mrow[c];
+      rp[2 * e] = prow[c];
+      rm[2 * e + 1] = mrow[cm];
+      rp[2 * e + 1] = prow[cm];
+    }
+  };
+  if (f0 < f1) fetch_rows(f0, t_);
+  const cpx wbase = a.wsplit[t_];  // e^{+2 pi i t/N}
   for (int64_t f = f0; f < f1; ++f) {
     // LICM may keep this thread's window and split twiddles in registers for the whole walk (twice as fast as
     // reloading them per frame), but not the pass twiddles as well: those would push the kernel past 256 VGPRs
@@ -420,19 +442,19 @@ __global__ __launch_bounds__(PV::T) void pv_synthesis(const PvArgs a) {
     int zoff = 0;
     asm volatile("" : "+s"(zoff));
     const float2 *tw2 = a.tw2 + zoff, *tw3 = a.tw3 + zoff;
-    const float2 *wsp = a.wsplit;  // e^{+2 pi i c/N}, c < M
     const float2 *w2 = reinterpret_cast<const float2 *>(a.hann);
     const int kp = k0p<P>(t), kq = k0q<P>(t);
-    const float *mrow = a.mags + (size_t)f * P::M;
-    const uint32_t *prow = a.phi + (size_t)f * P::M;
     cpx Y[P::E], v[P::E];
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       const int c = t + P::T * e;
-      const cpx A = pv_coef(mrow, prow, c);
-      const cpx B = cconj(pv_coef(mrow, prow, P::M - c));
+      const cpx A = pv_coef(rm[2 * e], rp[2 * e], c == 0);
+      cpx B = cconj(pv_coef(rm[2 * e + 1], rp[2 * e + 1], false));
+      if (c == 0) B = mk(0.f, 0.f);
       const cpx Sm = cadd(A, B), Dm = csub(A, B);
-      const cpx wd = cmul(wsp[c], Dm);             // w_c (A-B)
+      // w_c = e^{2 pi i c/N} = e^{2 pi i t/N} * e^{2 pi i e/32}: one hoisted value and a constant, not 16 table entries
+      // held in registers for the whole walk (they are what the row prefetch needed the room of)
+      const cpx wd = cmul(cmul(wbase, mk(kW32[e][0], kW32[e][1])), Dm);  // w_c (A-B)
       Y[e] = mk(Sm.x - wd.y, -(Sm.y + wd.x));      // conj((A+B) + i*wd)
     }
     pass1<P>(Y, v);
@@ -445,8 +467,13 @@ __global__ __launch_bounds__(PV::T) void pv_synthesis(const PvArgs a) {
     store_t2<P>(t, v, lds);
     __syncthreads();
     load_t2<P>(t, v, lds);
-    if (wave0) pass3<P, true>(t, v, tw3);
-    else pass3<P, false>(t, v, tw3);
+    cpx w3[P::R3 - 1];
+    int tl = t_;
+    asm volatile("" : "+v"(tl));  // (or the 64 row offsets are kept in registers for the whole walk)
+    fetch_tw3<P>(tl, tw3, w3);  // (ahead of the row requests: loads return in order)
+    if (f + 1 < f1) fetch_rows(f + 1, tl);
+    if (wave0) pass3_reg<P, true>(t, v, w3);
+    else pass3_reg<P, false>(t, v, w3);
     // v[r] = D[k0p + NS3 r], v[q_index(r)] = D[k0q + NS3 r]; sample pair m: y[2m] = Re D[m], y[2m+1] = -Im D[m].
     // Pair m of frame f sits at stretched sample f*Hs + 2m: ring slot (g*Hs/2 + m) mod M, g = f - f0.  Every slot
     // is touched by exactly one thread per frame.
