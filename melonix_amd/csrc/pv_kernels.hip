@@ -252,8 +252,11 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
   uint32_t bn = t < kPvM / 32 ? a.pkmap[(size_t)r0 * (kPvM / 32) + t] : 0u;
   int cur = 0;
   u16x4 org_out = u16x4{kPvNoBin, kPvNoBin, kPvNoBin, kPvNoBin};
+  int pc = (int)(r0 % 3);
+  uint32_t hn = a.hop[r0];
+  double hrn = a.hratio[r0];
   for (int64_t r = r0; r < r1; ++r) {
-    const int pc = (int)(r % 3), pp = (int)((r + 2) % 3);
+    const int pp = pc == 0 ? 2 : pc - 1;  // row r - 1 sits in slot (r - 1) mod 3
     const u32x4 w = wn;
     *reinterpret_cast<u32x4 *>(&P[pc][k0]) = w;
     if (t < kPvM / 32) pkw[r & 1][t + 1] = bn;
@@ -262,8 +265,12 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
       wn = *reinterpret_cast<const u32x4 *>(a.phase + (size_t)(r + 1) * kPvM + k0);
       if (t < kPvM / 32) bn = a.pkmap[(size_t)(r + 1) * (kPvM / 32) + t];
     }
-    const uint32_t h = a.hop[r];
-    const double hr = a.hratio[r];
+    const uint32_t h = hn;
+    const double hr = hrn;
+    if (r + 1 < r1) {  // (scalar loads: a row ahead as well)
+      hn = a.hop[r + 1];
+      hrn = a.hratio[r + 1];
+    }
     const uint32_t wk[4] = {w.x, w.y, w.z, w.w};
     // owners of this thread's four bins: the nearest peak at most kPvReach bins away, the lower one on a tie
     uint16_t ok[4];
@@ -284,20 +291,30 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
     }
     uint32_t nd[4];
     uint16_t no[4];
+    // neighbouring bins mostly share their owner: its phase step and state are fetched once per run of equal owners
+    int p_prev = -1;
+    bool cont = false;
+    uint32_t base = 0u;       // D[cur][p] + inc_f[p] - P_f[p]
+    uint16_t base_org = kPvNoBin;
 #pragma unroll
     for (int j = 0; j < kLockV; ++j) {
       const uint32_t pk = wk[j] & ~1u;
-      nd[j] = pk;
-      no[j] = kPvNoBin;
       const int p = ok[j];
-      if (h >= 1 && p != kPvNoBin) {
-        const uint32_t wp = P[pc][p], wq = P[pp][p];
-        if ((wp & wq & 1u) != 0u) {
-          const uint32_t pp_ = wp & ~1u;
-          nd[j] = D[cur][p] + pv_inc(p, h, hr, pp_, wq & ~1u) + (pk - pp_);
-          if constexpr (!APPLY) no[j] = O[cur][p];
+      if (p != p_prev) {
+        p_prev = p;
+        cont = false;
+        if (h >= 1 && p != kPvNoBin) {
+          const uint32_t wp = P[pc][p], wq = P[pp][p];
+          if ((wp & wq & 1u) != 0u) {
+            const uint32_t pp_ = wp & ~1u;
+            cont = true;
+            base = D[cur][p] + pv_inc(p, h, hr, pp_, wq & ~1u) - pp_;
+            if constexpr (!APPLY) base_org = O[cur][p];
+          }
         }
       }
+      nd[j] = cont ? base + pk : pk;
+      no[j] = cont ? base_org : kPvNoBin;
     }
     const u32x4 ndv = {nd[0], nd[1], nd[2], nd[3]};
     *reinterpret_cast<u32x4 *>(&D[cur ^ 1][k0]) = ndv;
@@ -309,6 +326,7 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
     }
     st = ndv;
     cur ^= 1;
+    pc = pc == 2 ? 0 : pc + 1;
   }
   if constexpr (!APPLY) {
     *reinterpret_cast<u32x4 *>(a.chunk_sums + c * kPvM + k0) = st;
