@@ -324,7 +324,7 @@ def main() -> None:
             fpv = int(np.ceil(n * 2.0 ** (3 / 12) / 256)) + 1
             pv = {"pitch_shift_semitones": 3, "frames": fpv, "call_ms": dt * 1e3, "frames_per_s": fpv / dt,
                   "output_rms": float(out16.float().pow(2).mean().sqrt().item() / 32767.0),
-                  "note": "build-defined (no reference counterpart); N=4096, synthesis hop 256"}
+                  "note": "build-defined (no reference counterpart); N=4096, synthesis hop 256, identity phase locking"}
             del out16
         except Exception as exc:  # never let a supplementary figure take the headline line down
             pv = {"error": str(exc)}
