@@ -1,3 +1,6 @@
+"""tools/pv_diag2.py — debugging aid (GPU box): dumps the staged phase-vocoder job's intermediate rows (magnitudes, phase words,
+peak maps, synthesis phases) through mx_debug_pv_row — which only exists in a library built with -DMX_PV_DEBUG
+(melonix_amd.build.build(force=True, extra_defines=["-DMX_PV_DEBUG"])) — and compares them with oracle/pv_oracle.py frame by frame."""
 import os, sys, ctypes as C
 import numpy as np
 import torch
