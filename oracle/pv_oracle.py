@@ -91,14 +91,18 @@ LOCK_REACH = 32  # bins
 PEAK_MARGIN = 1.0 - 2.0 ** -10
 
 
-def owners(m, act):
-    """Owner peak of every bin of one frame (int64; -1 = none)."""
-    M = len(m)
+def peaks(m, act):
+    """Peak mask of one frame."""
     e = np.concatenate([np.full(2, -1.0), np.asarray(m, dtype=np.float64), np.full(2, -1.0)])
     c = e[2:-2]
     rho = PEAK_MARGIN
-    pk = act & (c >= rho * e[1:-3]) & (c >= rho * e[0:-4]) & (c >= rho * e[3:-1]) & (c >= rho * e[4:])
-    idx = np.flatnonzero(pk)
+    return act & (c >= rho * e[1:-3]) & (c >= rho * e[0:-4]) & (c >= rho * e[3:-1]) & (c >= rho * e[4:])
+
+
+def owners(m, act):
+    """Owner peak of every bin of one frame (int64; -1 = none)."""
+    M = len(m)
+    idx = np.flatnonzero(peaks(m, act))
     own = np.full(M, -1, dtype=np.int64)
     if len(idx):
         k = np.arange(M)

@@ -23,15 +23,16 @@ sums, org = ctx.pv_shard_analyze(a, st, 0, 1)
 L = _capi.lib()
 L.mx_debug_pv_row.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
 def row(kind, f):
-    out = np.empty(2048, dtype=[np.float32, np.uint32, np.uint16, np.uint32][kind])
+    out = np.empty(64 if kind == 2 else 2048, dtype=[np.float32, np.uint32, np.uint32, np.uint32][kind])
     assert L.mx_debug_pv_row(ctx.handle, kind, f, out.ctypes.data) == 0
     return out
 for f in range(0, 12):
-    gm, gp, go = row(0, f), row(1, f), row(2, f)
-    oo = pv.owners(mags[f], act[f]); oo16 = np.where(oo < 0, 0xFFFF, oo).astype(np.uint16)
+    gm, gp, gmap = row(0, f), row(1, f), row(2, f)
+    gpk = ((gmap[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(bool).reshape(-1)
+    opk = pv.peaks(mags[f], act[f])
     gact = (gp & 1).astype(bool)
-    nd = np.flatnonzero(go != oo16)
-    print(f"frame {f}: act diff {np.count_nonzero(gact != act[f])}, owner diff {len(nd)} first {nd[:8]} gpu {go[nd[:8]]} orc {oo16[nd[:8]]}; mag relerr {np.abs(gm-mags[f]).max()/mags[f].max():.1e}")
+    nd = np.flatnonzero(gpk != opk)
+    print(f"frame {f}: act diff {np.count_nonzero(gact != act[f])}, peak diff {len(nd)} at {nd[:8]}; mag relerr {np.abs(gm-mags[f]).max()/mags[f].max():.1e}")
 head, tail = ctx.pv_shard_synthesize(None)
 for f in range(0, 40):
     gphi = row(3, f)
