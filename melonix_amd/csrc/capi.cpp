@@ -568,16 +568,18 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   const double r = std::pow(2.0, semitones / 12.0);
   const int64_t first = F_lo > 0 ? 1 : 0;
   const int64_t Fl = F_hi - F_lo + first;  // local rows
-  std::vector<int64_t> apos((size_t)Fl);
-  for (int64_t j = 0; j < Fl; ++j)
-    apos[(size_t)j] = plan ? plan->apos[(size_t)j] : (int64_t)std::floor((double)((F_lo - first + j) * Hs) / r);
-  std::vector<uint32_t> hop((size_t)Fl, 0u);
-  std::vector<double> hratio((size_t)Fl, 0.0);
-  for (int64_t j = 1; j < Fl; ++j) {
-    const int64_t h = apos[(size_t)j] - apos[(size_t)j - 1];
-    if (h >= 1 && h <= 0x7fffffffLL) {
-      hop[(size_t)j] = (uint32_t)h;
-      hratio[(size_t)j] = (double)Hs / (double)h;
+  // the constant-ratio plan (analysis positions, hops, Hs/hop) is written on the device; a marker plan comes from the host
+  std::vector<uint32_t> hop;
+  std::vector<double> hratio;
+  if (plan) {
+    hop.assign((size_t)Fl, 0u);
+    hratio.assign((size_t)Fl, 0.0);
+    for (int64_t j = 1; j < Fl; ++j) {
+      const int64_t h = plan->apos[(size_t)j] - plan->apos[(size_t)j - 1];
+      if (h >= 1 && h <= 0x7fffffffLL) {
+        hop[(size_t)j] = (uint32_t)h;
+        hratio[(size_t)j] = (double)Hs / (double)h;
+      }
     }
   }
   std::vector<float> hann((size_t)N), hann_sc((size_t)N);
@@ -629,14 +631,18 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
     ctx->pv_arena.cap = off;
   }
   char *arena = static_cast<char *>(ctx->pv_arena.p);
-  hipError_t e = hipMemcpyAsync(arena + o_apos, apos.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e = plan ? hipMemcpyAsync(arena + o_apos, plan->apos.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream)
+                      : launch_pv_plan_const(reinterpret_cast<int64_t *>(arena + o_apos), reinterpret_cast<uint32_t *>(arena + o_hp),
+                                             reinterpret_cast<double *>(arena + o_hr), Fl, F_lo - first, r, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(arena + o_h, hann.data(), N * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hs, hann_sc.data(), N * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(arena + o_w, wsplit.data(), (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream);
   // the last hop of s is beyond every frame, and s[s_len] backs the interpolation's m+1
   if (e == hipSuccess) e = hipMemsetAsync(arena + o_s + (size_t)(p.s_len - Hs) * 4, 0, (size_t)(Hs + 1) * 4, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hp, hop.data(), (size_t)Fl * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hr, hratio.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (plan) {
+    if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hp, hop.data(), (size_t)Fl * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hr, hratio.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
+  }
   if (plan) {
     if (e == hipSuccess) e = hipMemcpyAsync(arena + o_tf, plan->tf.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(arena + o_rf, plan->rf.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);

@@ -100,6 +100,9 @@ hipError_t launch_pv_analyze(const PvArgs &a, hipStream_t s);
 hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s);
 hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s);
 int64_t pv_halo_floats(int64_t frames);
+// constant-ratio analysis plan written on the device: rows of apos / hop / hratio for global frames fbase, fbase+1, ...
+hipError_t launch_pv_plan_const(int64_t *apos, uint32_t *hop, double *hratio, int64_t rows, int64_t fbase, double r,
+                                hipStream_t s);
 
 // spec-cache.cpp:77-96 colormap: nbins_total magnitudes -> 3*nbins_total bytes (both device).
 hipError_t launch_colormap(const float *mags, uint8_t *rgb, int64_t nbins_total, float k, hipStream_t s);

@@ -593,6 +593,36 @@ __global__ __launch_bounds__(256) void pv_resample_frames(const PvArgs a) {
 
 int64_t pv_halo_floats(int64_t frames) { return pv_blocks(frames) * (int64_t)kPvHalo; }
 
+namespace {
+// The constant-ratio plan, on the device (binary64 division and floor are exact IEEE operations here as on the host:
+// a_f = floor(double(f*Hs) / r), h_f = a_f - a_{f-1}, Hs / h_f).  Row j is global frame fbase + j; row 0 gets hop 0.
+__global__ __launch_bounds__(256) void pv_plan_const(int64_t *apos, uint32_t *hop, double *hratio, int64_t rows,
+                                                     int64_t fbase, double r) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= rows) return;
+  const int64_t aj = (int64_t)floor((double)((fbase + j) * kPvHs) / r);
+  apos[j] = aj;
+  uint32_t h = 0u;
+  double q = 0.0;
+  if (j > 0) {
+    const int64_t d = aj - (int64_t)floor((double)((fbase + j - 1) * kPvHs) / r);
+    if (d >= 1 && d <= 0x7fffffffLL) {
+      h = (uint32_t)d;
+      q = (double)kPvHs / (double)d;
+    }
+  }
+  hop[j] = h;
+  hratio[j] = q;
+}
+}  // namespace
+
+hipError_t launch_pv_plan_const(int64_t *apos, uint32_t *hop, double *hratio, int64_t rows, int64_t fbase, double r,
+                                hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pv_plan_const, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, apos, hop, hratio, rows, fbase, r);
+  return hipGetLastError();
+}
+
 // Stage 1: analysis rows and this rank's phase totals.  Stage 2: carries (from carry_in), synthesis phases, synthesis
 // with the overlap-add ring (afterwards halo[0 .. N-Hs) is this rank's head seam and s[(frames-first)*Hs ..) its
 // tail seam, both raw).  Stage 3: boundary fix-up (with the neighbours' seams) and resampling.
