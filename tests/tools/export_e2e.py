@@ -1,11 +1,11 @@
-"""tools/export_e2e.py — BASELINE configs[2] end to end on the GPU box: mx_export_wav of the 60-minute sweep at +3 st
+"""tests/tools/export_e2e.py — BASELINE configs[2] end to end on the GPU box: mx_export_wav of the 60-minute sweep at +3 st
 (host f32 in -> upload, grain scan, schedule, gather-lerp + int16 kernel, D2H, WAV file on /tmp), with
 MELONIX_TIMING=1 stage traces, next to the CPU oracle's export of the first minutes (App::exportWav's loop)."""
 import os, sys, time
 import numpy as np
 import torch  # before the library: one HIP runtime per process
 torch.cuda.init()
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 import melonix_amd as mx
 from oracle import pyoracle as O

@@ -1,9 +1,9 @@
-"""tools/pv_check.py — quick look at the phase-vocoder path vs its oracle (GPU box)."""
+"""tests/tools/pv_check.py — quick look at the phase-vocoder path vs its oracle (GPU box)."""
 import os, sys, time
 import numpy as np
 import torch  # before the library: one HIP runtime per process
 torch.cuda.init()
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import melonix_amd as mx
 from oracle import pv_oracle as pv

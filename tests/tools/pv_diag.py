@@ -1,9 +1,9 @@
-"""tools/pv_diag.py — where along the output the GPU phase vocoder and its oracle differ (GPU box)."""
+"""tests/tools/pv_diag.py — where along the output the GPU phase vocoder and its oracle differ (GPU box)."""
 import os, sys
 import numpy as np
 import torch
 torch.cuda.init()
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import melonix_amd as mx
 from oracle import pv_oracle as pv

@@ -1,11 +1,11 @@
-"""tools/pv_diag2.py — debugging aid (GPU box): dumps the staged phase-vocoder job's intermediate rows (magnitudes, phase words,
+"""tests/tools/pv_diag2.py — debugging aid (GPU box): dumps the staged phase-vocoder job's intermediate rows (magnitudes, phase words,
 peak maps, synthesis phases) through mx_debug_pv_row — which only exists in a library built with -DMX_PV_DEBUG
 (melonix_amd.build.build(force=True, extra_defines=["-DMX_PV_DEBUG"])) — and compares them with oracle/pv_oracle.py frame by frame."""
 import os, sys, ctypes as C
 import numpy as np
 import torch
 torch.cuda.init()
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import melonix_amd as mx
 from melonix_amd import _capi
