@@ -35,6 +35,7 @@
 
 #include "kernels.h"
 #include "stft_core.h"
+#include "stft_kernel_impl.h"  // wave_reduce_u32
 
 namespace mx {
 namespace {
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     store_t2<P>(t, v, lds);
     __syncthreads();
     load_t2<P>(t, v, lds);
+    __syncthreads();  // every wave has its T2 read: the image is free for the two rows (below)
     if (f + 1 < f1) load_raw<P, false>(t, xr, a.audio + MX_AUDIO_PAD + (a.apos[f + 1] - P::N / 2));
     cpx X[P::E];
     if (wave0) {
@@ -135,30 +137,25 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       m[o] = fast_sqrt(cnorm2(X[o]));
       mx = m[o] > mx ? m[o] : mx;
     }
-    // the frame's peak magnitude: wavefront, then the two wavefronts through LDS
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const float o = __shfl_xor(mx, d);
-      mx = o > mx ? o : mx;
-    }
-    if ((t & 63) == 0) red[t >> 6] = mx;
-    __syncthreads();  // (red is rewritten only after the next frame's four barriers)
-    mx = red[0] > red[1] ? red[0] : red[1];
-    const float thr = kPvActiveRel * mx;
+    // the frame's peak magnitude: wavefront maximum through the DPP crossbar (non-negative floats order like their bit
+    // patterns), the two wavefronts through LDS behind the same barrier as the rows
+    const uint32_t wmax = wave_reduce_u32<true>(__float_as_uint(mx));
+    if ((t & 63) == 0) red[t >> 6] = __uint_as_float(wmax);
     // Both rows leave through the (now free) image: every lane scatters its 16 bins as dwords (consecutive lanes ->
     // consecutive bins), then owns 4 consecutive bins of each row — 8 stores of 1 KiB per wavefront instruction
-    // instead of 32 dword stores.  Bit 0 of the phase word: the bin is active — the phase sweeps then need this one
-    // word per bin and frame, not the magnitude.
+    // instead of 32 dword stores.  Bit 0 of the phase word: the bin is active (within 60 dB of the frame's peak) — the
+    // phase sweeps then need this one word per bin and frame, not the magnitude; it is set on the way out.
     float *lm = reinterpret_cast<float *>(lds);
     uint32_t *lp = reinterpret_cast<uint32_t *>(lds) + P::M;
 #pragma unroll
     for (int o = 0; o < P::E; ++o) {
       const int k = out_bin<P>(t, o);
       lm[k] = m[o];
-      lp[k] = to_turns(X[o].x, X[o].y) | (m[o] >= thr ? 1u : 0u);
+      lp[k] = to_turns(X[o].x, X[o].y);
     }
     if (t < P::M / 32) pkbits[t] = 0u;  // (the previous frame's map left after this frame's first barrier)
-    __syncthreads();
+    __syncthreads();  // (red is rewritten only after the next frame's barriers)
+    const float thr = kPvActiveRel * (red[0] > red[1] ? red[0] : red[1]);
     using f32x4 = float __attribute__((ext_vector_type(4)));
     using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
     f32x4 qm[P::M / 4 / P::T];
@@ -167,6 +164,10 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     for (int i = 0; i < P::M / 4 / P::T; ++i) {
       qm[i] = reinterpret_cast<const f32x4 *>(lm)[t + P::T * i];
       qp[i] = reinterpret_cast<const u32x4 *>(lp)[t + P::T * i];
+      qp[i].x |= qm[i].x >= thr ? 1u : 0u;
+      qp[i].y |= qm[i].y >= thr ? 1u : 0u;
+      qp[i].z |= qm[i].z >= thr ? 1u : 0u;
+      qp[i].w |= qm[i].w >= thr ? 1u : 0u;
     }
     f32x4 *mrow = reinterpret_cast<f32x4 *>(a.mags + (size_t)f * P::M) + t;
     u32x4 *prow = reinterpret_cast<u32x4 *>(a.phase + (size_t)f * P::M) + t;
