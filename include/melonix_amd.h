@@ -218,7 +218,8 @@ int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate,
 /* ---- phase-vocoder pitch shift (BUILD-DEFINED) ------------------------------------
  * The reference has no phase vocoder (its pitch shift is the granular resampler above); BASELINE.json's
  * north_star names one, so the build defines it: N = 4096, synthesis hop 256, periodic Hann analysis and
- * synthesis windows, time-stretch by r = 2^(semitones/12) with integer phase propagation, overlap-add,
+ * synthesis windows, time-stretch by r = 2^(semitones/12) with integer phase propagation and identity phase
+ * locking (spectral peaks carry the phase, every other bin rides on its nearest peak), overlap-add,
  * linear resampling by r back to the input length (definition: oracle/pv_oracle.py).  Constant shift over
  * the whole file; output has mx_audio_length(a) samples.  int16 = (int16)(clamp(v,-1,1) * 32767.).
  * Parity is unpinned by construction: the only oracle is the build's own CPU restatement. */

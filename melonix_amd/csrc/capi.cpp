@@ -608,7 +608,7 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   p.s_origin = F_lo * Hs;
   const int64_t nchunks = (Fl - first + p.scan_chunk - 1) / p.scan_chunk;
   // one arena: apos, the two windows, mags, phase, phi, chunk sums, boundary halos, s (+1 for s[m+1]), split
-  // twiddles, restart flags of the chunks, this rank's totals, carry-in, the neighbours' seams
+  // twiddles, source bins of the chunk maps, peak maps, this rank's total map, carry-in, the neighbours' seams
   const size_t rowsz = (size_t)Fl * M;
   size_t off = 0;
   auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
