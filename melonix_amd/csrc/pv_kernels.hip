@@ -91,7 +91,15 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   fetch_tw3<P>(t_, a.tw3, w3r);
   for (int i = t_; i < P::TW2; i += P::T) ltw2[i] = a.tw2[i];
   __syncthreads();
-  const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_block;
+  // XCD-aware block -> frame-range map, as in stft_kernel: the dispatcher places block b on XCD b % 8 and each XCD has
+  // its own L2, so every XCD takes one contiguous eighth of the frame range — the 95 % overlap between neighbouring
+  // blocks' samples is then an L2 hit (with blocks dealt round-robin the kernel fetched 11.2 GB for 0.69 GB of audio)
+  unsigned lb = blockIdx.x;
+  {
+    const unsigned nb = gridDim.x, xcd = lb & 7u, q = nb >> 3, rr = nb & 7u;
+    lb = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (lb >> 3);
+  }
+  const int64_t f0 = (int64_t)lb * a.frames_per_block;
   const int64_t f1 = f0 + a.frames_per_block < a.frames ? f0 + a.frames_per_block : a.frames;
   // the samples of frame f + 1 are requested while frame f is in its last pass (their latency, left at the top of the
   // loop, was a third of the kernel)
@@ -173,8 +181,8 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     u32x4 *prow = reinterpret_cast<u32x4 *>(a.phase + (size_t)f * P::M) + t;
 #pragma unroll
     for (int i = 0; i < P::M / 4 / P::T; ++i) {
-      mrow[P::T * i] = qm[i];
-      prow[P::T * i] = qp[i];
+      __builtin_nontemporal_store(qm[i], &mrow[P::T * i]);  // (streamed: the rows must not push the audio out of L2)
+      __builtin_nontemporal_store(qp[i], &prow[P::T * i]);
     }
     // Peaks of the row (active, not below rho times any of its four neighbours) as a 2048-bit map: what the phase
     // sweeps need to know of the magnitudes (they find every bin's owner peak in it).
