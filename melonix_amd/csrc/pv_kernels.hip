@@ -638,7 +638,7 @@ hipError_t launch_pv_plan_const(int64_t *apos, uint32_t *hop, double *hratio, in
 hipError_t launch_pv_analyze(const PvArgs &a0, hipStream_t s) {
   PvArgs a = a0;
   if (a.frames - a.first <= 0) return hipSuccess;
-  a.frames_per_block = 8;  // (measured 8/16/32/64: 5.5/5.7/5.9/6.0 ms per 60 min)
+  a.frames_per_block = 16;  // (measured with the XCD-aware map, 4/8/16/32 frames: 5.61/5.59/5.40/5.59 ms per 60 min)
   const unsigned fb = (unsigned)((a.frames + a.frames_per_block - 1) / a.frames_per_block);
   const int64_t nchunks = pv_chunks(a);
   hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
