@@ -174,6 +174,9 @@ int check_common(mx_ctx *ctx, const mx_audio *a, int N, int64_t count, int &kmin
 int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_t first_frame,
                 const int32_t *d_ranges, int64_t count, int kmin, int kmax, float *d_mags,
                 mx_pitch *d_pitch, uint8_t *d_rgb, float cmap_k) {
+  // HIP's current device is per thread: the tables below must land on the context's GPU whichever
+  // thread makes the first call
+  HIP_TRY(hipSetDevice(ctx->device));
   NTables t;
   int rc = get_tables(ctx, N, t);
   if (rc) return rc;
@@ -200,7 +203,6 @@ int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_
     rc = get_wtab(ctx, N, hop, t, &s.wtab);
     if (rc) return rc;
   }
-  HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(launch_stft(N, mode, s, ctx->stream));
   return MX_OK;
 }
@@ -561,10 +563,10 @@ int64_t pv_first_output_at(int64_t q, double r, int64_t n) {
 int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, int64_t F_hi, bool want_totals,
                PvArgs &p, const PvPlan *plan = nullptr) {
   constexpr int N = kPvN, M = kPvM, Hs = kPvHs;
+  HIP_TRY(hipSetDevice(ctx->device));  // before any table allocation: HIP's current device is per thread
   NTables t;
   int rc = get_tables(ctx, N, t);
   if (rc) return rc;
-  HIP_TRY(hipSetDevice(ctx->device));
   const double r = std::pow(2.0, semitones / 12.0);
   const int64_t first = F_lo > 0 ? 1 : 0;
   const int64_t Fl = F_hi - F_lo + first;  // local rows

@@ -63,9 +63,6 @@ MX_HD cpx cconj(cpx a) { return mk(a.x, -a.y); }
 // push the register array into scratch)
 MX_HD cpx csel(bool c, cpx a, cpx b) { return mk(c ? a.x : b.x, c ? a.y : b.y); }
 MX_HD float fast_sqrt(float x) {
-#ifdef MX_ABL_NOSQRT
-  return x * 0.5f;
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_sqrtf(x);  // v_sqrt_f32, 1 ulp
 #else
@@ -73,6 +70,10 @@ MX_HD float fast_sqrt(float x) {
 #endif
 }
 MX_HD constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
+
+}  // namespace mx
+#include "pk_math.h"
+namespace mx {
 
 // a * exp(-2*pi*i*K/64), K a compile-time constant.
 template <int K>
@@ -94,29 +95,23 @@ MX_HD cpx mulw64(cpx a) {
 }
 
 // ---- in-register DFT of size R (natural order in, natural order out) --------
-// Radix-2 decimation in time with compile-time twiddles.  A butterfly (E, O, W) -> (E + W*O, E - W*O)
-// is computed as  out0 = E + W*O  (an FMA chain, the product is never materialised) and
-// out1 = 2*E - out0  (one FMA per component): 6 instructions for a general W instead of the 8 of
-// "t = W*O; E + t; E - t", and 6 instead of 8 for the (1 -+ i)/sqrt(2) twiddles.  Trivial twiddles
-// (1, -i, -1, i) stay plain add/sub.
+// Radix-2 decimation in time with compile-time twiddles, in packed arithmetic (pk_math.h: a complex value
+// per instruction).  A butterfly (E, O, W) -> (E + W*O, E - W*O) is three instructions:
+//   t = E + O*c (both components), out0 = t -+ i*s*O (the cross terms), out1 = 2*E - out0;
+// the trivial twiddles (1, -i) are an add and a subtract with the swap/negate folded into the operands.
 template <int K>
 MX_HD void bfly_w64(cpx E, cpx O, cpx &out0, cpx &out1) {  // W = exp(-2*pi*i*K/64)
   constexpr int k = ((K % 64) + 64) % 64;
-  constexpr float h = 0.707106781187f;
-  if constexpr (k % 16 == 0) {
-    const cpx t = mulw64<k>(O);
-    out0 = cadd(E, t);
-    out1 = csub(E, t);
+  if constexpr (k == 0) {
+    pk_bfly_1(E, O, out0, out1);
+  } else if constexpr (k == 16) {  // W = -i
+    pk_bfly_mi(E, O, out0, out1);
+  } else if constexpr (k == 32) {
+    pk_bfly_1(E, O, out1, out0);
+  } else if constexpr (k == 48) {
+    pk_bfly_mi(E, O, out1, out0);
   } else {
-    if constexpr (k == 8) out0 = mk(fma_(h, O.x + O.y, E.x), fma_(h, O.y - O.x, E.y));
-    else if constexpr (k == 24) out0 = mk(fma_(h, O.y - O.x, E.x), fma_(-h, O.x + O.y, E.y));
-    else if constexpr (k == 40) out0 = mk(fma_(-h, O.x + O.y, E.x), fma_(h, O.x - O.y, E.y));
-    else if constexpr (k == 56) out0 = mk(fma_(h, O.x - O.y, E.x), fma_(h, O.x + O.y, E.y));
-    else {
-      constexpr float c = kCos64[k], sn = kSin64[k];  // W*O = (O.x*c + O.y*sn, O.y*c - O.x*sn)
-      out0 = mk(fma_(O.x, c, fma_(O.y, sn, E.x)), fma_(O.y, c, fma_(-O.x, sn, E.y)));
-    }
-    out1 = mk(fma_(2.0f, E.x, -out0.x), fma_(2.0f, E.y, -out0.y));
+    pk_bfly_cs(E, O, mk(kCos64[k], kSin64[k]), out0, out1);  // W = cos - i*sin: a wave-uniform constant pair
   }
 }
 
@@ -145,8 +140,7 @@ struct Dft {
 template <>
 struct Dft<2> {
   static MX_HD void run(const cpx *in, cpx *out) {
-    out[0] = cadd(in[0], in[1]);
-    out[1] = csub(in[0], in[1]);
+    pk_bfly_1(in[0], in[1], out[0], out[1]);
   }
 };
 template <>
@@ -156,31 +150,16 @@ struct Dft<1> {
 
 // DFT of inputs that still carry external (run-time) twiddles: x[r] = v[r]*w[r], w[0] == 1 implied
 // (w is indexed like v; w[0] is never read).  The multiplications are folded into the leaf
-// butterflies of the recursion:  (a*wa) + (b*wb) = fma-chain on top of the product a*wa, and the
-// difference is again 2*(a*wa) - sum: 10 instructions per leaf instead of 12 (6 instead of 8 for the
-// leaf that holds x[0]).  CONJ: use conj(w[r]).
-template <bool CONJ>
-MX_HD cpx cmul_tw(cpx a, cpx w) {
-  const float wy = CONJ ? -w.y : w.y;
-  return mk(fma_(a.x, w.x, -(a.y * wy)), fma_(a.x, wy, a.y * w.x));
-}
-template <bool CONJ>
-MX_HD cpx cfma_tw(cpx a, cpx w, cpx c) {  // c + a*w
-  const float wy = CONJ ? -w.y : w.y;
-  return mk(fma_(a.x, w.x, fma_(-a.y, wy, c.x)), fma_(a.x, wy, fma_(a.y, w.x, c.y)));
-}
-
+// butterflies of the recursion:  a = v0*w0 (two instructions, none for the leaf that holds x[0]),
+// out0 = a + v1*w1 (two), out1 = 2*a - out0 (one).  CONJ: use conj(w[r]).
 // S = stride of this sub-transform's elements in the original arrays, O0 = its first original index
 template <int R, int S, int O0, bool CONJ>
 struct DftTw {
   static MX_HD void run(const cpx *v, const cpx *w, cpx *out) {
     if constexpr (R == 2) {
       constexpr int i0 = O0, i1 = O0 + S;
-      cpx a;
-      if constexpr (i0 == 0) a = v[0];
-      else a = cmul_tw<CONJ>(v[i0], w[i0]);
-      out[0] = cfma_tw<CONJ>(v[i1], w[i1], a);
-      out[1] = mk(fma_(2.0f, a.x, -out[0].x), fma_(2.0f, a.y, -out[0].y));
+      if constexpr (i0 == 0) pk_leaf0_tw<CONJ>(v[0], v[i1], w[i1], out[0], out[1]);
+      else pk_leaf_tw<CONJ>(v[i0], w[i0], v[i1], w[i1], out[0], out[1]);
     } else {
       cpx E[R / 2], O[R / 2];
       DftTw<R / 2, 2 * S, O0, CONJ>::run(v, w, E);
@@ -239,33 +218,25 @@ struct alignas(4) f2u {  // 4-byte aligned pair for frames starting at odd sampl
 
 template <class P, int WSTEP, bool ALIGNED8>
 MX_HD void load_frame(int t, cpx (&Y)[P::E], const float *x, const float *w) {
-#pragma clang fp contract(off)  // the windowed sample is a rounded binary32 product (spec.cpp:58)
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int p = 2 * (t + P::T * e);
-    float x0, x1, w0, w1;
+    cpx xs, ws;
     if constexpr (ALIGNED8 && WSTEP == 1) {
-      const cpx xs = *reinterpret_cast<const cpx *>(x + p);
-      const cpx ws = *reinterpret_cast<const cpx *>(w + p);
-      x0 = xs.x; x1 = xs.y; w0 = ws.x; w1 = ws.y;
+      xs = *reinterpret_cast<const cpx *>(x + p);
+      ws = *reinterpret_cast<const cpx *>(w + p);
     } else {
-      const f2u xs = *reinterpret_cast<const f2u *>(x + p);
-      x0 = xs.x; x1 = xs.y;
+      const f2u xu = *reinterpret_cast<const f2u *>(x + p);
+      xs = mk(xu.x, xu.y);
       if constexpr (WSTEP == 1) {
-        const f2u ws = *reinterpret_cast<const f2u *>(w + p);
-        w0 = ws.x; w1 = ws.y;
+        const f2u wu = *reinterpret_cast<const f2u *>(w + p);
+        ws = mk(wu.x, wu.y);
       } else {
-        const f2u ws = *reinterpret_cast<const f2u *>(w - p - 1);
-        w0 = ws.y; w1 = ws.x;
+        const f2u wu = *reinterpret_cast<const f2u *>(w - p - 1);
+        ws = mk(wu.y, wu.x);
       }
     }
-#ifdef MX_ABL_NOW
-    w0 = 0.75f; w1 = 0.5f;
-#endif
-#ifdef MX_ABL_NOX
-    x0 = (float)p; x1 = 1.0f;
-#endif
-    Y[e] = mk(x0 * w0, x1 * w1);  // float product, as spec.cpp:58 (times the folded 2^-k)
+    Y[e] = pk_mul(xs, ws);  // rounded binary32 products, as spec.cpp:58 (times the folded 2^-k)
   }
 }
 
@@ -281,51 +252,39 @@ template <int T>
 MX_HD constexpr float win_grow(int e) {
   return T == 64 ? kWinGrow64[e] : T == 128 ? kWinGrow128[e] : T == 256 ? kWinGrow256[e] : kWinGrow512[e];
 }
+// the geometric weights of slot e from the thread's seed pair a0 (clamped at the flat top)
+template <class P>
+MX_HD cpx geo_weight(cpx a0, int e) {
+  constexpr float sc = 0.5f / (float)P::N;
+  const float g = e == 0 ? 1.0f : win_grow<P::T>(e);
+  const cpx w = e == 0 ? a0 : pk_mul_xs(a0, mk(g, g));
+  return mk(w.x < sc ? w.x : sc, w.y < sc ? w.y : sc);
+}
 template <class P, bool ALIGNED8>
 MX_HD void load_frame_geo(int t, cpx (&Y)[P::E], const float *x, const float *wb) {
-#pragma clang fp contract(off)
   static_assert(P::T == 64 || P::T == 128 || P::T == 256 || P::T == 512, "growth table per T");
   static_assert(P::E <= 32, "growth table length");
-  constexpr float sc = 0.5f / (float)P::N;
   const cpx a0 = *reinterpret_cast<const cpx *>(wb + 2 * t);
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int p = 2 * (t + P::T * e);
-    float x0, x1;
+    cpx xs;
     if constexpr (ALIGNED8) {
-      const cpx xs = *reinterpret_cast<const cpx *>(x + p);
-      x0 = xs.x; x1 = xs.y;
+      xs = *reinterpret_cast<const cpx *>(x + p);
     } else {
-      const f2u xs = *reinterpret_cast<const f2u *>(x + p);
-      x0 = xs.x; x1 = xs.y;
+      const f2u xu = *reinterpret_cast<const f2u *>(x + p);
+      xs = mk(xu.x, xu.y);
     }
-    constexpr float one = 1.0f;
-    const float g = e == 0 ? one : win_grow<P::T>(e);
-    float w0 = a0.x * g, w1 = a0.y * g;
-    w0 = w0 < sc ? w0 : sc;
-    w1 = w1 < sc ? w1 : sc;
-#ifdef MX_ABL_NOX
-    x0 = (float)p; x1 = 1.0f;
-#endif
-    Y[e] = mk(x0 * w0, x1 * w1);
+    Y[e] = pk_mul(xs, geo_weight<P>(a0, e));
   }
 }
 
 // The same weights applied to samples fetched earlier (load_raw, the prefetching schedule).
 template <class P>
 MX_HD void apply_window_geo(int t, cpx (&Y)[P::E], const cpx (&xr)[P::E], const float *wb) {
-#pragma clang fp contract(off)
-  constexpr float sc = 0.5f / (float)P::N;
   const cpx a0 = *reinterpret_cast<const cpx *>(wb + 2 * t);
 #pragma unroll
-  for (int e = 0; e < P::E; ++e) {
-    constexpr float one = 1.0f;
-    const float g = e == 0 ? one : win_grow<P::T>(e);
-    float w0 = a0.x * g, w1 = a0.y * g;
-    w0 = w0 < sc ? w0 : sc;
-    w1 = w1 < sc ? w1 : sc;
-    Y[e] = mk(xr[e].x * w0, xr[e].y * w1);
-  }
+  for (int e = 0; e < P::E; ++e) Y[e] = pk_mul(xr[e], geo_weight<P>(a0, e));
 }
 
 // Direct modes, split in two so that the raw samples of the NEXT frame can be in flight while the
@@ -346,22 +305,20 @@ MX_HD void load_raw(int t, cpx (&xr)[P::E], const float *x) {
 }
 template <class P, int WSTEP, bool ALIGNED8>
 MX_HD void apply_window(int t, cpx (&Y)[P::E], const cpx (&xr)[P::E], const float *w) {
-#pragma clang fp contract(off)
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int p = 2 * (t + P::T * e);
-    float w0, w1;
+    cpx ws;
     if constexpr (ALIGNED8 && WSTEP == 1) {
-      const cpx ws = *reinterpret_cast<const cpx *>(w + p);
-      w0 = ws.x; w1 = ws.y;
+      ws = *reinterpret_cast<const cpx *>(w + p);
     } else if constexpr (WSTEP == 1) {
-      const f2u ws = *reinterpret_cast<const f2u *>(w + p);
-      w0 = ws.x; w1 = ws.y;
+      const f2u wu = *reinterpret_cast<const f2u *>(w + p);
+      ws = mk(wu.x, wu.y);
     } else {
-      const f2u ws = *reinterpret_cast<const f2u *>(w - p - 1);
-      w0 = ws.y; w1 = ws.x;
+      const f2u wu = *reinterpret_cast<const f2u *>(w - p - 1);
+      ws = mk(wu.y, wu.x);
     }
-    Y[e] = mk(xr[e].x * w0, xr[e].y * w1);
+    Y[e] = pk_mul(xr[e], ws);
   }
 }
 
@@ -420,17 +377,15 @@ MX_HD void slide_fetch(int t, const float *xe, cpx (&nx)[Slide<P, HOP>::D]) {
 template <class P, int HOP>
 MX_HD void slide_step(cpx (&Y)[P::E], const cpx (&nx)[Slide<P, HOP>::D], const cpx (&edge)[Slide<P, HOP>::D],
                       float g, float sc) {
-#pragma clang fp contract(off)  // keep each windowed point a rounded product, whatever consumes it
+  // every windowed point stays a rounded binary32 product, whatever consumes it (one packed multiply per point)
   using S = Slide<P, HOP>;
+  const cpx gg = mk(g, g), ss = mk(sc, sc);
 #pragma unroll
-  for (int e = 0; e < P::E - 2 * S::D; ++e) Y[e] = mk(Y[e + S::D].x * g, Y[e + S::D].y * g);
+  for (int e = 0; e < P::E - 2 * S::D; ++e) Y[e] = pk_mul_xs(Y[e + S::D], gg);
 #pragma unroll
-  for (int i = 0; i < S::D; ++i) {
-    const cpx o = Y[P::E - S::D + i];  // weight-1 slot (scaled by sc): becomes raw * edge
-    Y[P::E - 2 * S::D + i] = mk(o.x * edge[i].x, o.y * edge[i].y);
-  }
+  for (int i = 0; i < S::D; ++i) Y[P::E - 2 * S::D + i] = pk_mul(Y[P::E - S::D + i], edge[i]);  // weight-1 slot: raw * edge
 #pragma unroll
-  for (int i = 0; i < S::D; ++i) Y[P::E - S::D + i] = mk(nx[i].x * sc, nx[i].y * sc);
+  for (int i = 0; i < S::D; ++i) Y[P::E - S::D + i] = pk_mul_xs(nx[i], ss);
 }
 
 
@@ -572,11 +527,7 @@ MX_HD void pass2(int t, cpx (&v)[P::E], const cpx *tw2) {
     for (int r = 0; r < P::R2; ++r) in[r] = v[b * P::R2 + r];
 #pragma unroll
     for (int r = 1; r < P::R2; ++r) {
-#ifdef MX_ABL_NOTW
-      w[r] = mk(0.5f + r, 0.25f * k);
-#else
       w[r] = tw2[(r - 1) * P::R1 + k];
-#endif
     }
     DftTw<P::R2, 1, 0, false>::run(in, w, out);
 #pragma unroll
@@ -702,11 +653,7 @@ MX_HD void pass3(int t, cpx (&v)[P::E], const cpx *tw3) {
   }
 #pragma unroll
   for (int r = 1; r < R; ++r) {
-#ifdef MX_ABL_NOTW
-    const cpx w = mk(0.5f + r, 0.25f * col);
-#else
     const cpx w = tw3[(r - 1) * P::NS3 + col];
-#endif
     wp[r] = csel(t0, mk(1.0f, 0.0f), w);
     wq[r] = w;
   }
@@ -771,13 +718,11 @@ struct PostSlot {
       A = csel(t0, v[S - H], v[S]);
       B = csel(t0, v[(3 * H - S) & (R - 1)], v[q_index<P>(R - 1 - S)]);
     }
-    B = cconj(B);
-    const cpx Sm = cadd(A, B);
-    const cpx Dm = csub(A, B);
-    const cpx D = cmul(u[S], Dm);
-    const cpx lo = csub(Sm, D), hi = cadd(Sm, D);
-    mg[2 * S] = fast_sqrt(cnorm2(lo));
-    mg[2 * S + 1] = fast_sqrt(cnorm2(hi));
+    // lo = Sm - D, hi = Sm + D with Sm = A + conj(B), D = u*(A - conj(B)); the two squared magnitudes are
+    // formed side by side: px = (lo.x, hi.x), py = (lo.y, hi.y), n2 = px*px + py*py
+    const cpx n2 = pk_split_norm2(A, B, u[S]);
+    mg[2 * S] = fast_sqrt(n2.x);
+    mg[2 * S + 1] = fast_sqrt(n2.y);
     if constexpr (S == H) {  // thread 0: bin M/2 instead of the Nyquist bin; |X[M/2]| = |Z[M/2]|
       const cpx z = v[H];
       const float m = fast_sqrt(cnorm2(z)) * 2.0f;
@@ -807,12 +752,11 @@ struct PostSlotC {
       A = csel(t0, v[S - H], v[S]);
       B = csel(t0, v[(3 * H - S) & (R - 1)], v[q_index<P>(R - 1 - S)]);
     }
-    B = cconj(B);
-    const cpx Sm = cadd(A, B);
-    const cpx Dm = csub(A, B);
-    const cpx D = cmul(u[S], Dm);
-    X[2 * S] = csub(Sm, D);
-    X[2 * S + 1] = cconj(cadd(Sm, D));
+    const cpx Sm = pk_add_cj(A, B);
+    const cpx Dm = pk_sub_cj(A, B);
+    const cpx D = pk_cmul<false>(Dm, u[S]);
+    X[2 * S] = pk_sub(Sm, D);
+    X[2 * S + 1] = cconj(pk_add(Sm, D));
     if constexpr (S == H) {
       const cpx z = v[H];
       X[2 * S + 1] = csel(t0, mk(2.0f * z.x, -2.0f * z.y), X[2 * S + 1]);

@@ -1,6 +1,6 @@
-// stft_kernel_impl.h — the STFT workgroup kernel template (see stft_kernels.hip for
-// the design notes).  Kept in a header so tools/stft_variants.hip can instantiate
-// tuning variants of exactly the shipped code.
+// tools/lab/stft_kernel_lab.h — LAB COPY of melonix_amd/csrc/stft_kernel_impl.h with ablation hooks (MX_ABL_*: each one
+// removes a part of the work and makes the results wrong) for the energy/time attribution runs of tools/power_lab.hip.
+// Not part of the product; the product template carries no such hooks.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -9,9 +9,15 @@
 #include "stft_core.h"
 #include "stft_tables.h"
 
+// (tuning ablation: MX_ABL_NOBAR drops the workgroup barriers — results are then garbage)
+#ifdef MX_ABL_NOBAR
+#define MX_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
 #define MX_BARRIER() __syncthreads()
+#endif
 
-namespace mx {
+namespace mxlab {
+using namespace mx;
 
 // Wavefront reductions through the DPP crossbar (no LDS round trips, unlike __shfl_xor which lowers
 // to ds_bpermute): xor-1, xor-2 (quad_perm), row_half_mirror, row_mirror leave every 16-lane row
@@ -132,7 +138,11 @@ void stft_kernel(const StftArgs a0) {
   // (spec-cache.cpp:77-96) applied to the four consecutive bins a lane holds, 12 bytes per lane.
   const bool want_rows = a.mags != nullptr || (CMAP && a.rgb != nullptr);
   auto flush_row = [&](int64_t fr, int tt) {  // after a barrier that follows the scatter of frame fr
+#if defined(MX_ABL_NOOUTLDS)
+    if (false) {
+#else
     if (want_rows) {
+#endif
       using f32x4 = float __attribute__((ext_vector_type(4)));
       const f32x4 *l4 = reinterpret_cast<const f32x4 *>(lout) + tt;
       f32x4 *row4 = reinterpret_cast<f32x4 *>(a.mags + (size_t)fr * (size_t)(N / 2)) + tt;
@@ -142,7 +152,11 @@ void stft_kernel(const StftArgs a0) {
       if (!CMAP || a.mags) {
 #pragma unroll
         for (int i = 0; i < C::M / 4 / C::T; ++i) {
+#if defined(MX_ABL_NOGSTORE)
+          asm volatile("" ::"v"(q[i]), "v"(row4));
+#else
           __builtin_nontemporal_store(q[i], &row4[C::T * i]);
+#endif
         }
       }
       if constexpr (CMAP) {
@@ -225,13 +239,19 @@ void stft_kernel(const StftArgs a0) {
     }
 
     cpx v[P::E];
+#ifdef MX_ABL_NOVALU
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) v[e] = Y[e];
+#else
     pass1<P>(Y, v);
-#if defined(MX_LDS_ASM)
+#endif
+#if defined(MX_LDS_ASM) && !defined(MX_ABL_NOLDS)
     constexpr bool kTw2Batch = (TWREG >= 2) && (P::NB2 == 1);  // twiddles ride with the T1 read
 #else
     constexpr bool kTw2Batch = false;
 #endif
     cpx w2b[1][P::R2 - 1];
+#ifndef MX_ABL_NOLDS
     if constexpr (DEFER && !EARLYBAR) {
       MX_BARRIER();  // every wave is past load_t2 / scatter / red[] of the previous frame
       if (f > f0) flush_pitch(f - 1, t);
@@ -252,16 +272,29 @@ void stft_kernel(const StftArgs a0) {
       if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
     }
     MX_BARRIER();
+#endif
+#ifdef MX_ABL_NOVALU
+    if constexpr (kTw2Batch) { v[1].x += w2b[0][0].x + w2b[0][P::R2 - 2].y; }
+#else
     if constexpr (TWREG == 1) pass2_reg<P>(v, w2r);
     else if constexpr (kTw2Batch) pass2_reg<P>(v, w2b);
     else if constexpr (TWREG >= 2) pass2<P>(t, v, ltw2);
     else pass2<P>(t, v, tw2);
+#endif
+#ifndef MX_ABL_NOLDS
     store_t2<P>(t, v, lds);
     MX_BARRIER();
     load_t2<P>(t, v, lds);
     if constexpr (!OUTSEP || EARLYBAR) MX_BARRIER();  // image free (for the magnitude scatter / the next T1 scatter)
+#endif
     float mg[P::E];
-    if (NW == 1 || wave0) {  // wave-uniform: only the first wavefront contains thread 0
+#ifdef MX_ABL_NOVALU
+#pragma unroll
+    for (int e = 0; e < P::E / 2; ++e) { mg[2 * e] = v[e].x + w3r[e % (P::R3 - 1)].x; mg[2 * e + 1] = v[e].y + u[e % P::R3].y; }
+    if (false) {
+#else
+    if (NW == 1 || wave0) {
+#endif  // wave-uniform: only the first wavefront contains thread 0
       if constexpr (TWREG == 1 || TWREG == 2) pass3_reg<P, true>(t, v, w3r);
       else pass3<P, true>(t, v, tw3);
       post<P, true>(t, v, u, mg);
@@ -315,7 +348,23 @@ void stft_kernel(const StftArgs a0) {
     // consecutive bins, conflict-free), then every lane owns 4 consecutive bins and the row
     // leaves as global_store_dwordx4, 1 KiB contiguous per wavefront instruction, instead of E
     // dword stores with one stray element each (thread 0's self-paired bins).
-    if (want_rows) {
+#ifdef MX_ABL_NOOUTLDS
+    // ablation (wrong rows): what the output path would cost with the transposition for free — four
+    // 16-byte stores per lane straight from the magnitude registers
+    if (a.mags) {
+      using f32x4 = float __attribute__((ext_vector_type(4)));
+      f32x4 *row4 = reinterpret_cast<f32x4 *>(a.mags + (size_t)f * (size_t)(N / 2)) + t;
+#pragma unroll
+      for (int i = 0; i < C::E / 4; ++i) {
+        f32x4 q = {mg[4 * i], mg[4 * i + 1], mg[4 * i + 2], mg[4 * i + 3]};
+        __builtin_nontemporal_store(q, &row4[C::T * i]);
+      }
+    }
+    constexpr bool kScatter = false;
+#else
+    constexpr bool kScatter = true;
+#endif
+    if (kScatter && want_rows) {
       float *plo = lout + out_lo, *phi = lout + out_hi;
       float *mlo = lout + (C::M - out_lo), *mhi = lout + (C::M - out_hi);
 #pragma unroll
@@ -354,4 +403,4 @@ void stft_kernel(const StftArgs a0) {
 }
 
 
-}  // namespace mx
+}  // namespace mxlab
