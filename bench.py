@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py — STFT + pitch frames/s on synthetic 48 kHz mono audio (BASELINE.json metric).
+"""bench.py — STFT + pitch + resynthesis frames/s on synthetic 48 kHz mono audio (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path (STFT magnitudes + pitch pick, N=4096, hop=256)
-over one rank's 60-minute shard of synthetic audio that is already resident in HBM
-(config.workload = BASELINE.json configs[1]).  Weak scaling: every rank owns its own
-60-minute shard of one long sweep (configs[3]: 8 h over 8 GPUs) with the N-hop input halo
-of its left neighbour laid into its left pad, no data-path collective; the one exchange
-is an all-gather of the pitch tracks (8 B/frame), overlapped with the next step.
-Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one rank's 60-minute shard of synthetic audio that is
+already resident in HBM: the STFT magnitudes + pitch pick launch (N=4096, hop=256: BASELINE.json
+configs[1]) AND the +3-semitone granular resynthesis launch of the same audio into int16 PCM
+(configs[2]; its grain list and process() schedule are built once before the timed region — they
+depend on the audio and the markers only — and stay on the device).  `value` = STFT frames per
+second of that whole step.  Weak scaling: every rank owns its own 60-minute shard of one long
+sweep (configs[3]: 8 h over 8 GPUs) with the N-hop input halo of its left neighbour laid into its
+left pad, no data-path collective; the one exchange is an all-gather of the pitch tracks
+(8 B/frame), overlapped with the next step.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -53,6 +55,17 @@ def gen_shard(torch, dev, rank: int, world: int, n: int, pad: int):
         x = torch.where((i >= 0) & (i < total), x, torch.zeros_like(x))
         out[c:c + m] = x.to(torch.float32)
     return out
+
+
+def kernel_source_hash() -> str:
+    """sha1 over the STFT kernel's sources: ties a PMC traffic figure under profiles/ to the kernel it was measured on."""
+    import hashlib
+
+    h = hashlib.sha1()
+    for f in ("stft_kernels.hip", "stft_kernel_impl.h", "stft_core.h", "pk_math.h", "stft_tables.h", "stft_consts.inc"):
+        with open(os.path.join(ROOT, "melonix_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def usable_cores():
@@ -139,7 +152,9 @@ def main() -> None:
     ap.add_argument("--pitch-only", action="store_true", help="do not materialise magnitudes")
     ap.add_argument("--frames-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-resynth", action="store_true", help="skip the supplementary resynthesis measurement")
+    ap.add_argument("--no-resynth", action="store_true",
+                    help="STFT+pitch only in the timed step (configs[1] alone) and no supplementary measurements")
+    ap.add_argument("--no-supplementary", action="store_true", help="skip the end-to-end and phase-vocoder extras")
     args = ap.parse_args()
 
     import torch
@@ -193,67 +208,10 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(k: int, works: list):
-        if use_dist and k >= 2 and works[k - 2] is not None:
-            works[k - 2].wait()
-        ctx.stft_hop_dev(audio, N, hop, 0, F, mags_t.data_ptr() if mags_t is not None else None,
-                         pitch_t[k & 1].data_ptr(), band=band)
-        # the one exchange: stitch the per-rank pitch tracks (8 B/frame) into the whole-signal track,
-        # on RCCL's stream so it overlaps the next step's kernel
-        works.append(dist.all_gather_into_tensor(gathered[k & 1], pitch_t[k & 1], async_op=True)
-                     if use_dist else None)
-
-    works = []
-    for k in range(args.warmup):
-        run(k, works)
-    for wk in works[-2:]:
-        if wk is not None:
-            wk.wait()
-    barrier()
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    works = []
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if use_dist and k >= 2 and works[k - 2] is not None:
-            works[k - 2].wait()  # the all-gather that read pitch buffer k&1 two steps ago is done
-        ev[k][0].record()
-        ctx.stft_hop_dev(audio, N, hop, 0, F, mags_t.data_ptr() if mags_t is not None else None,
-                         pitch_t[k & 1].data_ptr(), band=band)
-        ev[k][1].record()
-        if use_dist:
-            works.append(dist.all_gather_into_tensor(gathered[k & 1], pitch_t[k & 1], async_op=True))
-        else:
-            works.append(None)
-    for wk in works[-2:]:
-        if wk is not None:
-            wk.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    k_max = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
-    kern_ms = float(k_max.item())
-
-    # sanity: the last step produced a plausible pitch track (guards against a silently skipped kernel)
-    bins = pitch_t[(args.steps - 1) & 1][:, 0]
-    ok = bool(((bins >= band[0]) & (bins <= band[1])).all().item())
-    if use_dist:  # the gathered whole-signal track must contain this rank's shard, bit for bit
-        g = gathered[(args.steps - 1) & 1]
-        ok = ok and bool(torch.equal(g[rank * F:(rank + 1) * F], pitch_t[(args.steps - 1) & 1]))
-        okt = torch.tensor([1 if ok else 0], device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok = bool(okt.item())
-
-    # supplementary (outside the timed region, rank 0, N=1): resynthesis +3 st of the same audio
-    # (BASELINE configs[2]) — grains on the GPU, schedule on the host, gather-lerp + int16 kernel
-    resynth = None
-    if rank == 0 and world == 1 and not args.no_resynth:
+    # ---- the resynthesis leg of the step: grains + schedule once (setup), one launch per step ----------------
+    with_resynth = not args.no_resynth
+    rs = None
+    if with_resynth:
         host = audio_t[pad:pad + n].cpu().numpy()
         t0 = time.perf_counter()
         gs, gl = ctx.grains_dev(audio)
@@ -265,28 +223,80 @@ def main() -> None:
         t0 = time.perf_counter()
         steps_arr, total = mx.schedule_build(host, SR, gs, gl, mk)
         t_sc = time.perf_counter() - t0
+        del host
         d_steps = torch.from_numpy(steps_arr.view(np.uint8).copy()).to(dev)
         pcm_i = torch.empty(total, dtype=torch.int16, device=dev)
-        for _ in range(3):
-            ctx.resynth_dev(audio, d_steps.data_ptr(), len(steps_arr), total, None, pcm_i.data_ptr())
-        rev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
-        for a_, b_ in rev:  # one event pair per launch, like the STFT kernel above
-            a_.record()
-            ctx.resynth_dev(audio, d_steps.data_ptr(), len(steps_arr), total, None, pcm_i.data_ptr())
-            b_.record()
-        torch.cuda.synchronize()
-        r_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in rev]))
-        rb = (4 * 2.0 ** (3 / 12) + 2) * total  # ~6.76 B per output sample at +3 st
-        resynth = {"pitch_bend_semitones": 3, "pcm_samples": int(total), "steps": int(len(steps_arr)), "kernel_ms": r_ms,
-                   "hop256_frames_per_s": total / 256 / (r_ms * 1e-3), "achieved_GBps": rb / (r_ms * 1e-3) / 1e9,
-                   "frac_of_hbm_peak": rb / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "grain_scan_s": t_gr, "grain_scan_warm_s": t_gr2,
-                   "schedule_host_s": t_sc, "outputs": "int16 PCM, HBM-resident"}
+        rs = {"steps": steps_arr, "total": int(total), "d_steps": d_steps, "pcm": pcm_i, "grain_scan_s": t_gr,
+              "grain_scan_warm_s": t_gr2, "schedule_host_s": t_sc}
 
+    def step(k: int, works: list, ev=None):
+        if use_dist and k >= 2 and works[k - 2] is not None:
+            works[k - 2].wait()  # the all-gather that read pitch buffer k&1 two steps ago is done
+        if ev is not None:
+            ev[0].record()
+        ctx.stft_hop_dev(audio, N, hop, 0, F, mags_t.data_ptr() if mags_t is not None else None,
+                         pitch_t[k & 1].data_ptr(), band=band)
+        if ev is not None:
+            ev[1].record()
+        if rs is not None:
+            ctx.resynth_dev(audio, rs["d_steps"].data_ptr(), len(rs["steps"]), rs["total"], None, rs["pcm"].data_ptr())
+        if ev is not None:
+            ev[2].record()
+        # the one exchange: stitch the per-rank pitch tracks (8 B/frame) into the whole-signal track,
+        # on RCCL's stream so it overlaps the next step's kernels
+        works.append(dist.all_gather_into_tensor(gathered[k & 1], pitch_t[k & 1], async_op=True)
+                     if use_dist else None)
+
+    works = []
+    for k in range(args.warmup):
+        step(k, works)
+    for wk in works[-2:]:
+        if wk is not None:
+            wk.wait()
+    barrier()
+
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    works = []
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, works, ev[k])
+    for wk in works[-2:]:
+        if wk is not None:
+            wk.wait()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    res_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if rs is not None else 0.0
+    k_max = torch.tensor([kern_ms, res_ms], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    kern_ms, res_ms = float(k_max[0].item()), float(k_max[1].item())
+
+    # sanity: the last step produced a plausible pitch track (guards against a silently skipped kernel)
+    bins = pitch_t[(args.steps - 1) & 1][:, 0]
+    ok = bool(((bins >= band[0]) & (bins <= band[1])).all().item())
+    if use_dist:  # the gathered whole-signal track must contain this rank's shard, bit for bit
+        g = gathered[(args.steps - 1) & 1]
+        ok = ok and bool(torch.equal(g[rank * F:(rank + 1) * F], pitch_t[(args.steps - 1) & 1]))
+        okt = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+
+    if rs is not None:  # the resynthesis leg produced a plausible PCM stream (guards against a skipped kernel)
+        tail_ok = not bool(rs["pcm"][-1500:].any().item())
+        body = rs["pcm"][: rs["total"] - 1500]
+        ok = ok and tail_ok and bool((body != 0).any().item())
+    supplementary = rank == 0 and world == 1 and not args.no_resynth and not args.no_supplementary
+    host = audio_t[pad:pad + n].cpu().numpy() if supplementary else None
     # supplementary (SURVEY 8d timing protocol, second figure): end to end from a host buffer — H2D of the audio
     # (mx_audio_upload, pageable memory as the editor's std::vector is) + the kernel + D2H of the pitch track;
     # magnitudes stay in HBM (their consumer is the GPU colormap).  Never `value`.
     e2e = None
-    if rank == 0 and world == 1 and not args.no_resynth:
+    if supplementary:
         try:
             host_pitch = torch.empty((F, 2), dtype=torch.int32).pin_memory()
             ts = []
@@ -312,7 +322,7 @@ def main() -> None:
     # supplementary: the build-defined phase-vocoder pitch shift (+3 st) of the same audio — the reference has no
     # phase vocoder (parity unpinned); whole call incl. its seven kernels, second call timed
     pv = None
-    if rank == 0 and world == 1 and not args.no_resynth:
+    if supplementary:
         try:
             out16 = torch.empty(n, dtype=torch.int16, device=dev)
             ctx.pv_pitch_shift_dev(audio, 3.0, None, out16.data_ptr())
@@ -332,20 +342,33 @@ def main() -> None:
     if rank == 0:
         balg = b_alg(N, hop, mags=not args.pitch_only)
         achieved = balg * F / (kern_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (profiles/pmc_latest.json, written by tools/profile_gpu.sh): only
+        # quoted while the profiled kernel IS the shipped one — same size, and the same kernel sources by hash
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
                     j = json.load(f)
-                if j.get("fft") == N and j.get("hop") == hop and j.get("frames") == F:
+                if (j.get("fft") == N and j.get("hop") == hop and j.get("frames") == F
+                        and j.get("kernel_source_sha1") == kernel_source_hash()):
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        kernels = [{"name": f"stft_kernel<Plan<{N},{'16' if N == 4096 else '32'}>, hop {hop}> (magnitudes + pitch pick)",
+                    "ms": kern_ms, "alg_bytes": balg * F, "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBS}]
+        if rs is not None:
+            rate = 2.0 ** (3.0 / 12.0)
+            rb = (4.0 * rate + 2.0) * rs["total"]  # each source sample of a grain once + 2 B of int16 per output
+            kernels.append({"name": "resynth_kernel_v (+3 st gather-lerp -> int16 PCM)", "ms": res_ms, "alg_bytes": rb,
+                            "achieved_GBps": rb / (res_ms * 1e-3) / 1e9, "frac": rb / (res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "pcm_samples": rs["total"], "process_steps": int(len(rs["steps"]))})
+        what = "STFT magnitudes" + ("" if not args.pitch_only else " (not stored)") + " + pitch pick"
+        if rs is not None:
+            what += " + granular resynthesis at +3 semitones into int16 PCM (two launches per step; grain list and " \
+                    "process() schedule prebuilt, device-resident)"
         line = {
-            # BASELINE.json's metric string, verbatim; it is quoted on configs[1] (STFT+pitch only), which is
-            # the timed workload — the resynthesis of the same audio (configs[2]) is measured right after the
-            # timed region and reported in "resynth_supplementary"
+            # BASELINE.json's metric string, verbatim: one timed step runs all three parts over the same audio
             "metric": "STFT+pitch+resynth frames/sec (48 kHz, 4096 FFT, 256 hop); % HBM roofline",
             "value": world * F * args.steps / elapsed,
             "unit": "frames/s",
@@ -360,14 +383,15 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": f"{minutes:g} min synthetic 48 kHz mono sine sweep per GPU"
-                            f"{f' ({args.strong_total_minutes:g} min in total)' if strong else ''}, FFT={N} hop={hop}, "
-                            f"STFT magnitudes{'' if not args.pitch_only else ' (not stored)'} + pitch pick "
-                            f"(BASELINE.json configs[1]: STFT+pitch only{'; configs[3] sharding' if world > 1 else ''}"
-                            f"; resynthesis = configs[2], outside the timed region, see resynth_supplementary)",
+                            f"{f' ({args.strong_total_minutes:g} min in total)' if strong else ''}, FFT={N} hop={hop}: {what} "
+                            f"(BASELINE.json configs[1] STFT+pitch{' and configs[2] resynthesis' if rs is not None else ' only'}"
+                            f"{'; configs[3] sharding' if world > 1 else ''})",
                 "frames_per_gpu": F, "fft": N, "hop": hop, "sample_rate": SR,
                 "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU",
-                "outputs": "pitch only" if args.pitch_only else "magnitudes + pitch, HBM-resident",
+                "outputs": ("pitch only" if args.pitch_only else "magnitudes + pitch") +
+                           (" + int16 PCM" if rs is not None else "") + ", HBM-resident",
             },
+            # the dominant kernel of the step (the STFT: ~90 % of it)
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -379,17 +403,23 @@ def main() -> None:
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_frame": balg,
             },
-            "pitch_track_ok": ok,
+            "kernels": kernels,
+            # labelled secondary: BASELINE configs[1] alone (what round 1 quoted as `value`)
+            "stft_pitch_only": {"frames_per_s": world * F / (kern_ms * 1e-3), "kernel_ms": kern_ms},
+            "outputs_ok": ok,
         }
-        if resynth is not None:
-            line["resynth_supplementary"] = resynth
+        if rs is not None:
+            line["resynth_setup"] = {"grain_scan_s": rs["grain_scan_s"], "grain_scan_warm_s": rs["grain_scan_warm_s"],
+                                     "schedule_host_s": rs["schedule_host_s"],
+                                     "note": "once per (audio, markers), before the timed region"}
         if pv is not None:
             line["phase_vocoder_supplementary"] = pv
         if e2e is not None:
             line["end_to_end_supplementary"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, hop)
-            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            # the CPU figure is the STFT+pitch path (the reference's FFTW loop); compare like with like
+            line["gpu_over_cpu_stft_pitch"] = line["stft_pitch_only"]["frames_per_s"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
 
     audio.free()

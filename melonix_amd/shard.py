@@ -11,6 +11,10 @@ from __future__ import annotations
 from dataclasses import dataclass
 
 MX_AUDIO_PAD = 32768
+# Shard boundaries sit on multiples of this many frames: the bulk STFT kernel walks runs of 32 consecutive frames per
+# workgroup (its sliding window restarts from the exact weights at the head of every run), so a shard whose first
+# frame is a multiple of 32 is cut into the same runs as the unsharded signal and its rows come out bit-identical.
+FRAME_ALIGN = 32
 
 
 @dataclass(frozen=True)
@@ -32,12 +36,14 @@ def frame_count(n: int, hop: int) -> int:
     return (n + hop - 1) // hop
 
 
-def shard_frames(n: int, N: int, hop: int, rank: int, world: int) -> FrameShard:
-    """Equal contiguous frame ranges (the last ranks get one frame less when F % world != 0)."""
+def shard_frames(n: int, N: int, hop: int, rank: int, world: int, align: int = FRAME_ALIGN) -> FrameShard:
+    """Contiguous frame ranges, equal up to the alignment: every boundary is a multiple of `align` frames (the last
+    rank takes what is left, at most world*align frames less than the others)."""
     F = frame_count(n, hop)
-    base, extra = divmod(F, world)
-    lo = rank * base + min(rank, extra)
-    hi = lo + base + (1 if rank < extra else 0)
+    per = -(-F // world)            # ceil(F / world)
+    per = -(-per // align) * align  # rounded up to the kernel's run length
+    lo = min(F, rank * per)
+    hi = min(F, lo + per)
     s_lo = lo * hop
     s_hi = min(n, hi * hop)
     return FrameShard(rank, world, lo, hi, s_lo, s_hi, min(N - hop, s_lo))

@@ -174,3 +174,49 @@ def test_pv_full_size_properties(gpu_ctx, oracle, hour):
     assert sel.sum() > 50000
     assert np.abs(pitch["bin"][sel] - expect[sel]).max() <= 2.0
     b.free()
+
+
+def test_export_full_hour_bit_exact_vs_oracle(gpu_ctx, oracle, mxlib, hour, tmp_path):
+    """BASELINE configs[2] at full size: the +3 st export of the whole 60 minutes (app.cpp:1194-1215) — grains, every
+    field of every process() step, the f32 PCM bitwise, the int16 PCM, sample and step counts — against the oracle's
+    restatement of the same hour (about a second of host time), and the WAV bytes through mx_resynth_to_wav."""
+    w = hour
+    n = len(w)
+    mk = [(1, 0, 0, 3.0), (n - 1, 0, 0, 3.0)]
+    ost, opcm = oracle.export_run(w, SR, mk)
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    rs, rl = oracle.grains(w)
+    assert np.array_equal(s, rs) and np.array_equal(l, rl)
+    st, total = mxlib.schedule_build(w, SR, s, l, mk)
+    # (the terminating process() call — no grain left, 1500 zeros — is not a step record on either side)
+    assert len(st) == len(ost) and total == len(opcm) and total == int(st["sz"].sum()) + 1500
+    for field in ("cursor", "grain_start", "grain_len", "rate", "next_first", "sz", "out_offset"):
+        assert np.array_equal(st[field], ost[field]), field
+    f32, i16 = gpu_ctx.resynth(a, st, total)
+    assert np.array_equal(f32.view(np.uint32), opcm.view(np.uint32))  # bitwise, all 172.8 M samples
+    o16 = oracle.pcm_to_i16(opcm)
+    assert np.array_equal(i16, o16)
+    del f32
+    path = tmp_path / "hour.wav"
+    gpu_ctx.resynth_to_wav(a, st, total, SR, path, strict=True)
+    got = path.read_bytes()
+    assert len(got) == 44 + 2 * total and got == oracle.wav_bytes(o16, SR)
+    a.free()
+
+
+def test_eight_shards_on_one_device_equal_unsharded_8h():
+    """BASELINE configs[3] played on one device (tests/tools/shard8_check.py): 8 h of the sweep cut into the 8 frame
+    shards `shard_frames` gives 8 ranks, each its own padded image with the N - hop halo, run shard by shard through
+    mx_stft_hop_dev; every magnitude row (the 7 seams included) and the concatenated pitch track bit-identical to the
+    unsharded 8 h run, seam rows against the oracle.  Runs in its own process: the 44 GB comparison happens on the
+    device through torch, which has to initialise the HIP runtime before the C-ABI library does."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "tools", "shard8_check.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "shard8_check ok" in r.stdout

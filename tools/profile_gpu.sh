@@ -7,8 +7,10 @@ set -u
 TAG=${1:-r01}; shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out
-# PROF_RESYNTH=1: keep the supplementary resynthesis in the run and summarise ITS kernel (PROF_KERNEL)
-NORES="--no-resynth"; [ "${PROF_RESYNTH:-0}" = "1" ] && NORES="" && export PROF_KERNEL=${PROF_KERNEL:-resynth_kernel_v}
+# The profiled command is the default bench step (STFT+pitch launch + resynthesis launch) without the CPU baseline and the
+# supplementary extras.  PROF_KERNEL=<substring> picks the kernel whose PMC rows are summarised (default stft_kernel;
+# PROF_RESYNTH=1 = resynth_kernel_v).
+NORES="--no-supplementary"; [ "${PROF_RESYNTH:-0}" = "1" ] && export PROF_KERNEL=${PROF_KERNEL:-resynth_kernel_v}
 BENCH="python bench.py --steps 50 --warmup 10 --no-cpu-baseline $NORES $*"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o stft -- $BENCH > $OUT/prof_${TAG}_bench.log 2>&1

@@ -64,5 +64,19 @@ if stft and "WRITE_SIZE" in p and "FETCH_SIZE" in p:
     res["hbm_bytes_per_launch"] = res["fetch_bytes_corrected"] + res["write_bytes"]
     res["hbm_bytes_note"] = ("FETCH_SIZE*1024*2 (gfx950 counts 64 B per 128-B request on wide coalesced reads, "
                              "MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024; separate --pmc passes")
+    # a ready-to-commit profiles/pmc_latest.json for the default bench workload, keyed to the kernel's sources
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from bench import kernel_source_hash
+        latest = {"fft": int(os.environ.get("PROF_FFT", 4096)), "hop": int(os.environ.get("PROF_HOP", 256)),
+                  "frames": int(os.environ.get("PROF_FRAMES", 675000)),
+                  "hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "fetch_bytes_raw": res["fetch_bytes_raw"],
+                  "fetch_bytes_corrected": res["fetch_bytes_corrected"], "write_bytes": res["write_bytes"],
+                  "note": res["hbm_bytes_note"], "kernel": stft[0]["Name"], "kernel_source_sha1": kernel_source_hash(),
+                  "rocprof_avg_ns": res["stft_kernel_avg_ns"], "source": f"tools/profile_gpu.sh {tag}"}
+        with open(os.path.join(OUT, f"pmc_latest_{tag}.json"), "w") as fh:
+            json.dump(latest, fh, indent=1)
+    except Exception as exc:  # the summary itself must not depend on this
+        print("pmc_latest not written:", exc)
 with open(os.path.join(OUT, f"prof_{tag}.json"), "w") as fh:
     json.dump(res, fh, indent=1)
