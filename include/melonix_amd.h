@@ -79,6 +79,12 @@ int mx_ctx_synchronize(mx_ctx *ctx);
 int mx_ctx_release_scratch(mx_ctx *ctx);
 /* Tuning knob: consecutive frames one workgroup walks (0 = per-N default). */
 int mx_ctx_set_frames_per_block(mx_ctx *ctx, int frames);
+/* Page-locked host memory for the buffers the host-pointer entry points fill (magnitude / texel rows, PCM): a
+ * device->host copy into it is a direct DMA at PCIe rate, a copy into fresh pageable memory is several times slower
+ * (staging + page faults).  The reference has no counterpart (its rows never leave the CPU, spec.cpp:61-65); the
+ * facade's Spec worker lands every batch in such a buffer and recycles it.  Free with mx_pinned_free. */
+int mx_pinned_alloc(mx_ctx *ctx, size_t bytes, void **out);
+void mx_pinned_free(mx_ctx *ctx, void *p);
 /* Thread-local description of the last error returned on this thread. */
 const char *mx_last_error(void);
 /* "melonix_amd <version> gfx950" */

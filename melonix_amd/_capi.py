@@ -54,6 +54,8 @@ SIGNATURES = {
     "mx_ctx_synchronize": (_i, [_vp]),
     "mx_ctx_release_scratch": (_i, [_vp]),
     "mx_ctx_set_frames_per_block": (_i, [_vp, _i]),
+    "mx_pinned_alloc": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "mx_pinned_free": (None, [_vp, _vp]),
     "mx_last_error": (C.c_char_p, []),
     "mx_version": (C.c_char_p, []),
     "mx_audio_upload": (_i, [_vp, _vp, _i64, C.POINTER(_vp)]),

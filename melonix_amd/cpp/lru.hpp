@@ -50,6 +50,13 @@ public:
     order_.pop_back();
     return std::make_pair(std::move(n.key), std::move(n.value));
   }
+  // Removes `key` if present.
+  void erase(const Key &key) {
+    auto it = index_.find(key);
+    if (it == index_.end()) return;
+    order_.erase(it->second);
+    index_.erase(it);
+  }
   void clear() {
     index_.clear();
     order_.clear();

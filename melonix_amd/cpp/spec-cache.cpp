@@ -51,19 +51,30 @@ struct SpecCache::Impl {
     // the texels normally come out of the same launch as the magnitudes (colormap fused into the STFT
     // kernel); only a row computed before this cache registered its scale is fetched by value and
     // coloured here, as the reference colours every row (spec-cache.cpp:67-96)
-    const int state = spec.requestTexRow(start, end, k, texels);
-    if (state == 0) {
-      texels.assign(16 * 3, 0);  // not ready: 16 black texels, retried on the next draw
-    } else {
-      c.filled = true;
-      if (state == 2) {
-        const std::vector<float> row = spec.getSpec(start, end);
+    Spec::TexView view;
+    int state = spec.requestTexView(start, end, k, view);
+    const unsigned char *pixels = view.data;
+    std::size_t bytes = view.bytes;
+    if (state == 2) {
+      const std::vector<float> row = spec.getSpec(start, end);
+      if (row.empty()) {
+        state = 0;  // (evicted or still on its way between the two calls)
+      } else {
         texels.resize(row.size() * 3);
         melonixColormap(row.data(), row.size(), k, texels.data());
+        pixels = texels.data();
+        bytes = texels.size();
       }
     }
-    glTexImage1D(GL_TEXTURE_1D, 0, 3, static_cast<GLsizei>(texels.size() / 3), 0, GL_RGB, GL_UNSIGNED_BYTE,
-                 texels.data());
+    if (state == 0) {
+      texels.assign(16 * 3, 0);  // not ready: 16 black texels, retried on the next draw
+      pixels = texels.data();
+      bytes = texels.size();
+    } else {
+      c.filled = true;
+    }
+    // the fused texel row goes to GL straight out of the worker's landing buffer (no intermediate copy)
+    glTexImage1D(GL_TEXTURE_1D, 0, 3, static_cast<GLsizei>(bytes / 3), 0, GL_RGB, GL_UNSIGNED_BYTE, pixels);
     return name;
   }
 };

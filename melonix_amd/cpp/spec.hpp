@@ -10,9 +10,12 @@
 //
 // Observable difference: one GPU launch drains the WHOLE pending set (the reference computes one
 // column per worker iteration, spec.cpp:68-97), so a cold 1280-column view fills within a vsync or
-// two instead of ~0.5 s.  Without a usable MI355X the object still constructs and every column
+// two instead of ~0.5 s.  Columns that only SpecCache has asked for come back from the device as
+// RGB8 texel rows alone (3 bytes per bin instead of 4 + 3); their magnitudes are computed on the
+// first getSpec of that key, which answers {} until they are there — the same contract as a first touch.  Without a usable MI355X the object still constructs and every column
 // simply stays empty — the reference's own failure mode (black columns), there is no CPU path.
 #pragma once
+#include <cstddef>
 #include <memory>
 #include <span>
 #include <vector>
@@ -42,6 +45,15 @@ public:
   // texels: 0 = not computed yet (the key is queued exactly as getSpec queues it), 1 = rgb filled,
   // 2 = the magnitudes are there but no texel row for this k (ask getSpec and colour them yourself).
   int requestTexRow(int start, int end, float k, std::vector<unsigned char> &rgb) const;
+  // The same without any copy: a view of the texel row inside the worker's landing buffer, valid for as long
+  // as `keep` is held (what SpecCache hands straight to glTexImage1D).
+  struct TexView {
+    const unsigned char *data = nullptr;
+    std::size_t bytes = 0;
+    std::shared_ptr<const void> keep;
+  };
+  int requestTexView(int start, int end, float k, TexView &view) const;
+  std::size_t cachedRows() const;  // keys currently held (<= MaxRanges), computed or not
 
   int fftSize() const;
   bool ok() const;  // false when no MI355X context / upload failed

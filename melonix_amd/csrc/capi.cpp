@@ -328,6 +328,25 @@ int mx_ctx_release_scratch(mx_ctx *ctx) {
   return MX_OK;
 }
 
+int mx_pinned_alloc(mx_ctx *ctx, size_t bytes, void **out) {
+  if (!ctx || !out) return fail(MX_ERR_INVALID, "null context / out");
+  *out = nullptr;
+  if (bytes == 0) return MX_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return fail(MX_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  }
+  return MX_OK;
+}
+
+void mx_pinned_free(mx_ctx *ctx, void *p) {
+  if (!p) return;
+  if (ctx) hipSetDevice(ctx->device);
+  hipHostFree(p);
+}
+
 int mx_ctx_set_frames_per_block(mx_ctx *ctx, int g) {  // tuning knob (bench sweeps)
   if (!ctx || g < 0) return fail(MX_ERR_INVALID, "bad argument");
   ctx->frames_per_block = g;

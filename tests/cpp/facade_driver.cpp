@@ -85,7 +85,15 @@ int main(int argc, char **argv) {
       texels.insert(texels.end(), g_tex[name].begin(), g_tex[name].end());
       const int key = (int)(t * 1280 / 10.0);
       const double left = key * 10.0 / 1280;
-      const auto r = spec.getSpec((int)(left * sr), (int)((left + 10.0 / 1280) * sr));
+      // only the texel row of this column has left the device so far (SpecCache was its only consumer): the
+      // magnitudes come on request, getSpec answering {} until they are there
+      std::vector<float> r = spec.getSpec((int)(left * sr), (int)((left + 10.0 / 1280) * sr));
+      check(r.empty(), "texel-only column: the first getSpec answers {} and fetches the magnitudes");
+      for (int spin = 0; spin < 2000 && r.empty(); ++spin) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        r = spec.getSpec((int)(left * sr), (int)((left + 10.0 / 1280) * sr));
+      }
+      check(r.size() == (size_t)N / 2, "magnitudes of a texel-only column arrive on request");
       texrows.insert(texrows.end(), r.begin(), r.end());
       check(cache.getTex(t) == name, "clean column returns the same texture");
       // the texels came out of the STFT launch itself (fused colormap), not from the host loop
@@ -121,6 +129,64 @@ int main(int argc, char **argv) {
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     check(filled == 1280, "cold screen fills");
     printf("cold_screen: N=%d 1280 columns filled after %d draw passes, %.1f ms\n", N, frames, ms);
+  }
+
+  if (N == 4096) {  // LRU eviction at MaxRanges in both caches (range.hpp:4, spec.cpp:33-40, spec-cache.cpp:26-49)
+    const int extra = 100, total = MaxRanges + extra;
+    {
+      Spec spec(std::span<float>{wav.data(), wav.size()}, N);
+      auto key = [&](int i) { return std::pair<int, int>{i * 64, i * 64 + 256}; };
+      for (int i = 0; i < total; ++i) check(spec.getSpec(key(i).first, key(i).second).empty(), "first touch is empty");
+      check(spec.cachedRows() == (size_t)MaxRanges, "Spec keeps at most MaxRanges keys");
+      std::vector<float> r;
+      for (int spin = 0; spin < 5000 && r.empty(); ++spin) {
+        r = spec.getSpec(key(total - 1).first, key(total - 1).second);
+        if (r.empty()) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
+      check(r.size() == (size_t)N / 2, "the newest key is computed");
+      check(!spec.getSpec(key(extra).first, key(extra).second).empty(), "the oldest surviving key is still cached");
+      // keys 0..extra-1 were evicted when the table overflowed: asking again is a first touch (and evicts in turn)
+      check(spec.getSpec(key(0).first, key(0).second).empty(), "an evicted key starts over with {}");
+      check(spec.cachedRows() == (size_t)MaxRanges, "re-inserting keeps the table at MaxRanges");
+      r.clear();
+      for (int spin = 0; spin < 5000 && r.empty(); ++spin) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        r = spec.getSpec(key(0).first, key(0).second);
+      }
+      check(r.size() == (size_t)N / 2, "the re-queued key is computed again");
+    }
+    {
+      Spec spec(std::span<float>{wav.data(), wav.size()}, N);
+      const int live0 = g_live;
+      SpecCache cache(spec, 512.f * 64, 1280, 10.0, [&](double v) { return (int)(v * sr); });
+      auto tcol = [&](int keyi) { return (keyi + 0.5) * 10.0 / 1280; };
+      GLuint first = 0, name = 0;
+      for (int i = 0; i < total; ++i) {
+        name = cache.getTex(tcol(i));
+        if (i == 0) first = name;
+      }
+      check(g_live - live0 == MaxRanges, "SpecCache owns at most MaxRanges textures");
+      check(spec.cachedRows() == (size_t)MaxRanges, "... and Spec at most MaxRanges rows behind them");
+      for (int spin = 0; spin < 5000 && g_tex[name].size() != (size_t)N / 2 * 3; ++spin) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        name = cache.getTex(tcol(total - 1));
+      }
+      check(g_tex[name].size() == (size_t)N / 2 * 3, "the newest column fills");
+      // column 0 was the least recently drawn: its texture name was recycled for column MaxRanges
+      // (spec-cache.cpp:34-47); drawing it again recycles the name of the now-oldest column and starts dirty
+      const GLuint again = cache.getTex(tcol(0));
+      check(g_live - live0 == MaxRanges, "recycling creates no textures");
+      check(again != first || g_tex[again].size() == 16 * 3, "an evicted column starts over (dirty, black)");
+      GLuint nm = again;
+      for (int spin = 0; spin < 5000 && g_tex[nm].size() != (size_t)N / 2 * 3; ++spin) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        nm = cache.getTex(tcol(0));
+      }
+      check(nm == again && g_tex[nm].size() == (size_t)N / 2 * 3, "the evicted column is computed again into its recycled texture");
+      cache.clear();
+      check(g_live == live0, "clear() releases every texture");
+    }
+    printf("eviction: %d keys through Spec and SpecCache (MaxRanges = %d)\n", total, MaxRanges);
   }
 
   {  // saveWav: reference signature, strict header
