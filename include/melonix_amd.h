@@ -205,7 +205,8 @@ void mx_free(void *p);
  * may be NULL).  Bit-exact vs the reference arithmetic (no FMA contraction). */
 int mx_resynth(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nsteps,
                int64_t nsamples, float *pcm_f32_out, int16_t *pcm_i16_out);
-/* Device-resident variant: d_steps / outputs in HBM, asynchronous. */
+/* Device-resident variant: d_steps / outputs in HBM, asynchronous.  Every one of the nsamples outputs is written:
+ * the samples past the last step's run (the zeros of the terminating process() calls) are cleared on the device. */
 int mx_resynth_dev(mx_ctx *ctx, const mx_audio *a, const mx_step *d_steps, int64_t nsteps,
                    int64_t nsamples, float *d_pcm_f32, int16_t *d_pcm_i16);
 

@@ -1,7 +1,15 @@
 // marker.hpp — drop-in for the reference's Marker (marker.hpp:4-19).  Layout-compatible with
-// mx_marker of the C-ABI.  The reference's `ser` property macros are applied when the caller's
-// build provides them (MELONIX_WITH_SER), so project files keep loading.
+// mx_marker of the C-ABI.  The editor's .melonix load/save (app.cpp:1142-1189) walks the struct
+// through mika314's `ser` property macros (marker.hpp:10-17): they are applied whenever the
+// including build can see <ser/macro.hpp> — as the editor's own build does — so the project-file
+// code keeps compiling with this header in place of the reference's.  -DMELONIX_WITH_SER forces
+// them on (a missing header is then an error), -DMELONIX_NO_SER leaves them out.
 #pragma once
+#if !defined(MELONIX_WITH_SER) && !defined(MELONIX_NO_SER) && defined(__has_include)
+#if __has_include(<ser/macro.hpp>)
+#define MELONIX_WITH_SER 1
+#endif
+#endif
 #ifdef MELONIX_WITH_SER
 #include <ser/macro.hpp>
 #endif

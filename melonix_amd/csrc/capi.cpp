@@ -726,11 +726,15 @@ int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, floa
 // Marker-driven variant: the vocoder steered by the editor's markers as App::exportWav is (warped time, pitch bend).
 int64_t mx_pv_render_length(int64_t n, int sampleRate, const mx_marker *markers, int nmarkers) {
   if (n < 0 || nmarkers < 0 || (nmarkers > 0 && !markers)) return fail(MX_ERR_INVALID, "bad argument");
-  PvPlan plan;
-  std::string err;
-  const int rc = build_pv_plan(markers, nmarkers, sampleRate, n, plan, err);
-  if (rc) return fail(rc, "%s", err.c_str());
-  return plan.n_out;
+  try {
+    PvPlan plan;
+    std::string err;
+    const int rc = build_pv_plan(markers, nmarkers, sampleRate, n, plan, err);
+    if (rc) return fail(rc, "%s", err.c_str());
+    return plan.n_out;
+  } catch (const std::exception &e) {  // nothing may propagate across the C boundary
+    return fail(MX_ERR_NOMEM, "phase-vocoder plan: %s", e.what());
+  }
 }
 
 int mx_pv_plan(int64_t n, int sampleRate, const mx_marker *markers, int nmarkers, int64_t **apos, double **tf,
@@ -1123,12 +1127,12 @@ int mx_resynth_dev(mx_ctx *ctx, const mx_audio *a, const mx_step *d_steps, int64
   if (!ctx || !a || nsteps < 0 || nsamples < 0 || (nsteps > 0 && !d_steps))
     return fail(MX_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(ctx->device));
-  // trailing zeros of the terminating process() call: clear the last 1500 samples
-  // (they lie past every step's run; see mx_schedule_build)
-  const int64_t tail = std::min<int64_t>(nsamples, 1500);
-  if (tail > 0) {
-    if (d_pcm_f32) HIP_TRY(hipMemsetAsync(d_pcm_f32 + (nsamples - tail), 0, (size_t)tail * sizeof(float), ctx->stream));
-    if (d_pcm_i16) HIP_TRY(hipMemsetAsync(d_pcm_i16 + (nsamples - tail), 0, (size_t)tail * sizeof(int16_t), ctx->stream));
+  // Samples past the last step's run are zeros (the terminating process() calls append 1500 zeros each: one for an
+  // export, ceil(missing/1500) for a playback refill — mx_schedule_build_from).  The device-resident entry point does
+  // not see the schedule, so the kernel itself clears [covered, nsamples): its last workgroup knows where the steps end.
+  if (nsteps == 0 && nsamples > 0) {
+    if (d_pcm_f32) HIP_TRY(hipMemsetAsync(d_pcm_f32, 0, (size_t)nsamples * sizeof(float), ctx->stream));
+    if (d_pcm_i16) HIP_TRY(hipMemsetAsync(d_pcm_i16, 0, (size_t)nsamples * sizeof(int16_t), ctx->stream));
   }
   ResynthArgs r{};
   r.audio = a->d_padded;

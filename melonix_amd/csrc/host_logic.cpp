@@ -267,8 +267,19 @@ int build_pv_plan(const mx_marker *markers, int nmarkers, int sampleRate, int64_
   if (sampleRate <= 0) { err = "sampleRate must be positive"; return MX_ERR_INVALID; }
   for (int m = 1; m < nmarkers; ++m)
     if (markers[m].sample < markers[m - 1].sample) { err = "markers must be sorted by sample"; return MX_ERR_INVALID; }
+  for (int m = 0; m < nmarkers; ++m)
+    if (!std::isfinite(markers[m].dTime) || !std::isfinite(markers[m].pitchBend)) {
+      err = "marker with a non-finite dTime / pitchBend";
+      return MX_ERR_INVALID;
+    }
   const TimeMap tm(markers, nmarkers, sampleRate, n);
   const double dur = tm.duration(), sr = (double)sampleRate;
+  // a frame advances the warped time by 256/(r*sr) >= 256/(16*sr): more frames than this cannot be a finite plan
+  if (!std::isfinite(dur) || dur * sr * 16.0 / 256.0 + 2.0 > 2147483647.0) {
+    err = "duration is not finite or the plan would exceed 2^31 frames";
+    return MX_ERR_INVALID;
+  }
+  const size_t max_frames = (size_t)(dur > 0 ? dur * sr * 16.0 / 256.0 : 0.0) + 2;
   int64_t n_out = dur > 0 ? (int64_t)std::ceil(dur * sr - 1e-12) : 0;  // the number of i with i/sr < duration()
   while (n_out > 0 && (double)(n_out - 1) / sr >= dur) --n_out;
   while ((double)n_out / sr < dur) ++n_out;
@@ -284,7 +295,7 @@ int build_pv_plan(const mx_marker *markers, int nmarkers, int sampleRate, int64_
     plan.i0.push_back(std::min<int64_t>(n_out, (int64_t)std::ceil(t * sr)));
     if (t >= dur) break;
     t = t + 256.0 / (r * sr);
-    if (plan.tf.size() > ((size_t)1 << 31)) { err = "too many frames"; return MX_ERR_INVALID; }
+    if (plan.tf.size() > max_frames) { err = "too many frames"; return MX_ERR_INVALID; }
   }
   plan.i0.push_back(n_out);
   return MX_OK;

@@ -546,8 +546,10 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 __global__ __launch_bounds__(256) void pv_fixup(const PvArgs a) {
   const int64_t fs = a.frames - a.first;
   const int64_t nb = pv_blocks(fs);
-  const int64_t b = (int64_t)blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  // boundary and offset both come from blockIdx.x (gridDim.y stops at 65535: 2.1 M frames, an hour at +20 semitones)
+  constexpr int kPerB = (kPvHalo + 255) / 256;
+  const int64_t b = (int64_t)(blockIdx.x / kPerB);
+  const int i = (int)(blockIdx.x % kPerB) * 256 + threadIdx.x;
   if (i >= kPvHalo) return;
   if (b == 0) {
     if (a.global_first) return;  // the first hops of the signal were complete when they left the ring
@@ -657,7 +659,8 @@ hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s) {
 hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
   const int64_t nb = pv_blocks(a.frames - a.first);
-  hipLaunchKernelGGL(pv_fixup, dim3((kPvHalo + 255) / 256, (unsigned)(nb + 1)), dim3(256), 0, s, a);
+  if ((nb + 1) * (int64_t)((kPvHalo + 255) / 256) > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pv_fixup, dim3((unsigned)((nb + 1) * ((kPvHalo + 255) / 256))), dim3(256), 0, s, a);
   if (a.i0)  // marker-driven: one workgroup per frame
     hipLaunchKernelGGL(pv_resample_frames, dim3((unsigned)(a.frames - a.first)), dim3(256), 0, s, a);
   else if (a.out_hi > a.out_lo)

@@ -193,13 +193,23 @@ __global__ __launch_bounds__(256) void zc_kernel(const float *__restrict__ wav /
   }
 }
 
+// Samples past the last step's run: the zeros of the terminating process() call(s) (app.cpp:303-309) are not steps.
+// The last step record says where the steps end, so a caller holding only device pointers needs no host-side sum.
+__global__ __launch_bounds__(256) void resynth_tail_kernel(const ResynthArgs a) {
+  const mx_step last = a.steps[a.nsteps - 1];
+  const int64_t covered = last.out_offset + (int64_t)last.sz;
+  for (int64_t i = covered + (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.nsamples; i += (int64_t)gridDim.x * 256) {
+    if (a.pcm_f32) a.pcm_f32[i] = 0.f;
+    if (a.pcm_i16) a.pcm_i16[i] = 0;
+  }
+}
+
 }  // namespace
 
 hipError_t launch_resynth(const ResynthArgs &a, hipStream_t s) {
   if (a.nsteps > 0x7fffffffLL) return hipErrorInvalidValue;
-  // The terminating process() call's 1500 zeros (app.cpp:303-309) are not a step:
-  // capi.cpp clears the tail [sum(sz), nsamples) with hipMemsetAsync before this launch.
   if (a.nsteps > 0) {
+    hipLaunchKernelGGL(resynth_tail_kernel, dim3(64), dim3(256), 0, s, a);
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.pcm_f32) | reinterpret_cast<uintptr_t>(a.pcm_i16) |
                            reinterpret_cast<uintptr_t>(a.audio)) & 15) == 0;
     if (aligned) {

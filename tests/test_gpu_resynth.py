@@ -257,3 +257,37 @@ def test_random_markers_bit_exact(gpu_ctx, oracle, mxlib, seed):
     assert np.array_equal(f32.view(np.uint32), opcm.view(np.uint32))
     assert np.array_equal(i16, oracle.pcm_to_i16(opcm))
     a.free()
+
+
+def test_resynth_dev_writes_every_sample_of_a_refill(gpu_ctx, oracle, mxlib):
+    """mx_resynth_dev with device pointers only (no host-side sum over the schedule): a playback refill that runs past
+    the last grain ends in SEVERAL blocks of 1500 zeros (mx_schedule_build_from); all of [sum(sz), nsamples) must come
+    out zero even when the caller's buffer held garbage."""
+    import ctypes as C
+    w = accum_sweep(3 * SR)
+    n = len(w)
+    a = gpu_ctx.upload(w)
+    s, l = gpu_ctx.grains_dev(a)
+    st, total, _ = mxlib.schedule_build_from(w, SR, s, l, [], 2.5, 60000)   # 0.5 s of audio left, 60000 wanted
+    covered = int(st["sz"].sum())
+    assert total - covered >= 2 * 1500
+    from melonix_amd import _capi
+    L = _capi.lib()
+    dp, df, di = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMalloc(C.byref(dp), st.nbytes) == 0 and hip.hipMalloc(C.byref(df), total * 4) == 0 and hip.hipMalloc(C.byref(di), total * 2) == 0
+    hip.hipMemset(df, 0x7F, total * 4)
+    hip.hipMemset(di, 0x7F, total * 2)
+    hip.hipMemcpy(dp, C.c_void_p(st.ctypes.data), st.nbytes, 1)
+    _capi.check(L.mx_resynth_dev(gpu_ctx.handle, a.handle, dp, len(st), total, df, di))
+    gpu_ctx.synchronize()
+    f32 = np.empty(total, np.float32)
+    i16 = np.empty(total, np.int16)
+    hip.hipMemcpy(C.c_void_p(f32.ctypes.data), df, total * 4, 2)
+    hip.hipMemcpy(C.c_void_p(i16.ctypes.data), di, total * 2, 2)
+    for p in (dp, df, di):
+        hip.hipFree(p)
+    _, opcm, _ = oracle.playback_fill(w, SR, [], 2.5, 60000)
+    assert len(opcm) == total and np.array_equal(f32.view(np.uint32), opcm.view(np.uint32))
+    assert not f32[covered:].any() and not i16[covered:].any()
+    a.free()

@@ -200,3 +200,15 @@ def test_playback_refill_chain(mxlib, oracle, sweep10, pb):
     a = mxlib.schedule_build_from(sweep10, SR, s, l, mk, 0.0, -1)
     b = mxlib.schedule_build(sweep10, SR, s, l, mk)
     assert _same_steps(a[0], b[0]) and a[1] == b[1]
+
+
+def test_pv_plan_rejects_non_finite_markers(mxlib):
+    """A NaN / infinite dTime or bend must come back as an error from every plan entry point (mx_pv_render_length used to
+    grow its vectors until the process died: dur = NaN makes `t >= dur` never true)."""
+    n = 480_000
+    for bad in ([(1000, 0, float("nan"), 0.0)], [(1000, 0, float("inf"), 0.0)], [(1000, 0, 0.0, float("nan"))],
+                [(1000, 0, -float("inf"), 1.0), (n - 1, 0, 0.0, 1.0)]):
+        with pytest.raises(mxlib.MxError):
+            mxlib.pv_plan(n, SR, bad)
+        from melonix_amd import _capi
+        assert _capi.lib().mx_pv_render_length(n, SR, _capi.markers_array(bad), len(bad)) < 0
