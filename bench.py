@@ -212,18 +212,18 @@ def main() -> None:
     with_resynth = not args.no_resynth
     rs = None
     if with_resynth:
-        host = audio_t[pad:pad + n].cpu().numpy()
+        # grain chain on the device (only the grain table comes back), process() schedule on the host from that table
         t0 = time.perf_counter()
-        gs, gl = ctx.grains_dev(audio)
+        gs, gl, gf = ctx.grain_table_dev(audio)
         t_gr = time.perf_counter() - t0
         t0 = time.perf_counter()
-        gs, gl = ctx.grains_dev(audio)  # second call: host landing buffers already mapped, kernel loaded
+        gs, gl, gf = ctx.grain_table_dev(audio)  # second call: work buffers exist, kernels loaded
         t_gr2 = time.perf_counter() - t0
         mk = [(1, 0, 0, 3.0), (n - 1, 0, 0, 3.0)]
+        mx.schedule_build_table(n, SR, gs, gl, gf, mk)
         t0 = time.perf_counter()
-        steps_arr, total = mx.schedule_build(host, SR, gs, gl, mk)
+        steps_arr, total, _ = mx.schedule_build_table(n, SR, gs, gl, gf, mk)
         t_sc = time.perf_counter() - t0
-        del host
         d_steps = torch.from_numpy(steps_arr.view(np.uint8).copy()).to(dev)
         pcm_i = torch.empty(total, dtype=torch.int16, device=dev)
         rs = {"steps": steps_arr, "total": int(total), "d_steps": d_steps, "pcm": pcm_i, "grain_scan_s": t_gr,

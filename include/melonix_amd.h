@@ -180,6 +180,11 @@ int mx_grains(const float *host_wav, int64_t n, int32_t **starts, int32_t **lens
 /* Device version: zero-crossing predicates evaluated on the GPU from the
  * resident audio; same outputs. */
 int mx_grains_dev(mx_ctx *ctx, const mx_audio *a, int32_t **starts, int32_t **lens, int64_t *count);
+/* The same chain as a grain TABLE: additionally firsts[g] = wav[starts[g]], the only samples the export loop reads
+ * (App::process's nextGrainFirstSample, app.cpp:323-328) — with it mx_schedule_build_table needs no host copy of
+ * the audio.  The chain itself is built on the device (ranks of the crossings, successor of every crossing, binary
+ * lifting, expansion from start 0): only the table comes back.  firsts may be NULL. */
+int mx_grain_table_dev(mx_ctx *ctx, const mx_audio *a, int32_t **starts, int32_t **lens, float **firsts, int64_t *count);
 
 /* Replays the cursor recurrence of App::exportWav / App::process
  * (app.cpp:1200-1207, 294-331) on the host: one mx_step per process() call that
@@ -198,6 +203,11 @@ int mx_schedule_build_from(const float *host_wav, int64_t n, int sampleRate, con
                            const int32_t *grain_lens, int64_t ngrains, const mx_marker *markers,
                            int nmarkers, double cursor0, int64_t need, mx_step **steps,
                            int64_t *nsteps, int64_t *nsamples, double *cursor_end);
+/* mx_schedule_build_from on a grain table (mx_grain_table_dev) instead of the audio itself. */
+int mx_schedule_build_table(int64_t n, int sampleRate, const int32_t *grain_starts, const int32_t *grain_lens,
+                            const float *grain_firsts, int64_t ngrains, const mx_marker *markers, int nmarkers,
+                            double cursor0, int64_t need, mx_step **steps, int64_t *nsteps, int64_t *nsamples,
+                            double *cursor_end);
 void mx_free(void *p);
 
 /* Gather-lerp resampler + float->int16 (app.cpp:332-343, 1209-1212) over a

@@ -187,6 +187,14 @@ class Context:
         _capi.check(_capi.lib().mx_grains_dev(self.handle, audio.handle, C.byref(s), C.byref(l), C.byref(cnt)))
         return _take_i32(s, cnt.value), _take_i32(l, cnt.value)
 
+    def grain_table_dev(self, audio: Audio):
+        """-> (starts, lens, firsts): the grain chain built on the device, with every grain's first sample."""
+        s, l, f, cnt = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_float)(), C.c_int64()
+        _capi.check(_capi.lib().mx_grain_table_dev(self.handle, audio.handle, C.byref(s), C.byref(l), C.byref(f), C.byref(cnt)))
+        firsts = np.ctypeslib.as_array(f, shape=(max(cnt.value, 1),))[:cnt.value].astype(np.float32, copy=True)
+        _capi.lib().mx_free(f)
+        return _take_i32(s, cnt.value), _take_i32(l, cnt.value), firsts
+
     def resynth(self, audio: Audio, steps, nsamples: int, want_f32: bool = True, want_i16: bool = True):
         steps = np.ascontiguousarray(steps, dtype=STEP_DTYPE)
         f32 = np.empty(nsamples, dtype=np.float32) if want_f32 else None
@@ -274,6 +282,20 @@ class Context:
                                               str(path).encode(), 1 if strict else 0))
 
 
+def _take_steps(p, count):
+    """The library-allocated step array as a numpy structured array, without a copy: the array owns the allocation
+    (mx_free runs when the last view of it goes)."""
+    if not count:
+        _capi.lib().mx_free(p)
+        return np.zeros(0, STEP_DTYPE)
+    import weakref
+
+    addr = C.addressof(p.contents)
+    buf = (C.c_char * (count * C.sizeof(_capi.Step))).from_address(addr)
+    weakref.finalize(buf, _capi.lib().mx_free, C.c_void_p(addr))
+    return np.frombuffer(buf, dtype=STEP_DTYPE)
+
+
 def _take_i32(p, cnt):
     out = np.ctypeslib.as_array(p, shape=(max(cnt, 1),))[:cnt].astype(np.int32, copy=True)
     _capi.lib().mx_free(p)
@@ -297,10 +319,21 @@ def schedule_build(wav, sr: int, starts, lens, markers):
     p, ns, tot = C.POINTER(_capi.Step)(), C.c_int64(), C.c_int64()
     _capi.check(_capi.lib().mx_schedule_build(_ptr(wav), len(wav), sr, _ptr(starts), _ptr(lens), len(starts), m,
                                               len(markers), C.byref(p), C.byref(ns), C.byref(tot)))
-    steps = np.frombuffer(C.string_at(p, ns.value * C.sizeof(_capi.Step)), dtype=STEP_DTYPE).copy() if ns.value \
-        else np.zeros(0, STEP_DTYPE)
-    _capi.lib().mx_free(p)
-    return steps, tot.value
+    return _take_steps(p, ns.value), tot.value
+
+
+def schedule_build_table(n: int, sr: int, starts, lens, firsts, markers, cursor0: float = 0.0, need: int = -1):
+    """The export / refill schedule from a grain table (Context.grain_table_dev): no host copy of the audio needed.
+    -> (steps, nsamples, cursor_end)"""
+    starts = np.ascontiguousarray(starts, dtype=np.int32)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    firsts = np.ascontiguousarray(firsts, dtype=np.float32)
+    m = _capi.markers_array(markers)
+    p, ns, tot, end = C.POINTER(_capi.Step)(), C.c_int64(), C.c_int64(), C.c_double()
+    _capi.check(_capi.lib().mx_schedule_build_table(int(n), sr, _ptr(starts), _ptr(lens), _ptr(firsts), len(starts), m,
+                                                    len(markers), float(cursor0), int(need), C.byref(p), C.byref(ns),
+                                                    C.byref(tot), C.byref(end)))
+    return _take_steps(p, ns.value), tot.value, end.value
 
 
 def schedule_build_from(wav, sr: int, starts, lens, markers, cursor0: float, need: int):
@@ -313,10 +346,7 @@ def schedule_build_from(wav, sr: int, starts, lens, markers, cursor0: float, nee
     _capi.check(_capi.lib().mx_schedule_build_from(_ptr(wav), len(wav), sr, _ptr(starts), _ptr(lens), len(starts), m,
                                                    len(markers), float(cursor0), int(need), C.byref(p), C.byref(ns),
                                                    C.byref(tot), C.byref(end)))
-    steps = np.frombuffer(C.string_at(p, ns.value * C.sizeof(_capi.Step)), dtype=STEP_DTYPE).copy() if ns.value \
-        else np.zeros(0, STEP_DTYPE)
-    _capi.lib().mx_free(p)
-    return steps, tot.value, end.value
+    return _take_steps(p, ns.value), tot.value, end.value
 
 
 def save_wav(path, pcm16, sr: int, strict: bool = True):

@@ -81,10 +81,13 @@ SIGNATURES = {
     "mx_column_range": (None, [_vp, _i, _i, _d, _i, _d, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "mx_grains": (_i, [_vp, _i64, C.POINTER(_pi32), C.POINTER(_pi32), C.POINTER(_i64)]),
     "mx_grains_dev": (_i, [_vp, _vp, C.POINTER(_pi32), C.POINTER(_pi32), C.POINTER(_i64)]),
+    "mx_grain_table_dev": (_i, [_vp, _vp, C.POINTER(_pi32), C.POINTER(_pi32), C.POINTER(C.POINTER(C.c_float)), C.POINTER(_i64)]),
     "mx_schedule_build": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i, C.POINTER(C.POINTER(Step)),
                                C.POINTER(_i64), C.POINTER(_i64)]),
     "mx_schedule_build_from": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i, _d, _i64, C.POINTER(C.POINTER(Step)),
                                     C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_d)]),
+    "mx_schedule_build_table": (_i, [_i64, _i, _vp, _vp, _vp, _i64, _vp, _i, _d, _i64, C.POINTER(C.POINTER(Step)),
+                                     C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_d)]),
     "mx_free": (None, [_vp]),
     "mx_resynth": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mx_resynth_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),

@@ -31,6 +31,7 @@ UNITS = [
     # bit-exact PCM: no FMA contraction in the resampler
     ("resynth_kernels.hip", "hip", ["-ffp-contract=off"]),
     ("colormap_kernel.hip", "hip", ["-ffp-contract=off"]),
+    ("grain_chain.hip", "hip", []),
     # build-defined phase vocoder: shares the FFT passes of stft_core.h (explicit FMAs)
     ("pv_kernels.hip", "hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
     ("capi.cpp", "hip", []),

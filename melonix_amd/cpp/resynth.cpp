@@ -10,22 +10,26 @@ static_assert(sizeof(Marker) == sizeof(mx_marker), "Marker must stay layout-comp
 namespace melonix {
 
 Resynth::Resynth(std::span<const float> wav, int sampleRate, int device)
-    : host(wav.begin(), wav.end()), sampleRate(sampleRate) {
+    : nsrc(wav.size()), sampleRate(sampleRate) {
   if (mx_ctx_create(device, &ctx) != MX_OK) {
     ctx = nullptr;
     return;
   }
-  if (mx_audio_upload(ctx, host.data(), (int64_t)host.size(), &audio) != MX_OK) {
+  if (mx_audio_upload(ctx, wav.data(), (int64_t)wav.size(), &audio) != MX_OK) {
     audio = nullptr;
     return;
   }
+  // App::preproc's grain scan (app.cpp:153-235), chain and all, on the device: the grain table comes back
   int32_t *s = nullptr, *l = nullptr;
+  float *f = nullptr;
   int64_t n = 0;
-  if (mx_grains_dev(ctx, audio, &s, &l, &n) == MX_OK) {
+  if (mx_grain_table_dev(ctx, audio, &s, &l, &f, &n) == MX_OK) {
     starts.assign(s, s + n);
     lens.assign(l, l + n);
+    firsts.assign(f, f + n);
     mx_free(s);
     mx_free(l);
+    mx_free(f);
   }
 }
 
@@ -40,9 +44,8 @@ bool Resynth::run(const std::vector<Marker> &markers, std::vector<float> *f32, s
   mx_step *steps = nullptr;
   int64_t nsteps = 0, nsamples = 0;
   const mx_marker *mk = reinterpret_cast<const mx_marker *>(markers.data());
-  if (mx_schedule_build_from(host.data(), (int64_t)host.size(), sampleRate, starts.data(), lens.data(),
-                             (int64_t)starts.size(), mk, (int)markers.size(), cursor0, need, &steps, &nsteps, &nsamples,
-                             cursorEnd) != MX_OK)
+  if (mx_schedule_build_table((int64_t)nsrc, sampleRate, starts.data(), lens.data(), firsts.data(), (int64_t)starts.size(), mk,
+                              (int)markers.size(), cursor0, need, &steps, &nsteps, &nsamples, cursorEnd) != MX_OK)
     return false;
   if (f32) f32->resize((size_t)nsamples);
   if (i16) i16->resize((size_t)nsamples);
@@ -73,7 +76,7 @@ std::vector<float> Resynth::refill(const std::vector<Marker> &markers, double cu
 std::vector<float> Resynth::phaseVocoder(double semitones) const {
   std::vector<float> pcm;
   if (!ok()) return pcm;
-  pcm.resize(host.size());
+  pcm.resize(nsrc);
   if (mx_pv_pitch_shift(ctx, audio, semitones, pcm.data(), nullptr) != MX_OK) pcm.clear();
   return pcm;
 }
@@ -82,7 +85,7 @@ std::vector<float> Resynth::renderPV(const std::vector<Marker> &markers) const {
   std::vector<float> pcm;
   if (!ok()) return pcm;
   const mx_marker *mk = reinterpret_cast<const mx_marker *>(markers.data());
-  const int64_t m = mx_pv_render_length((int64_t)host.size(), sampleRate, mk, (int)markers.size());
+  const int64_t m = mx_pv_render_length((int64_t)nsrc, sampleRate, mk, (int)markers.size());
   if (m <= 0) return pcm;
   pcm.resize((size_t)m);
   if (mx_pv_render(ctx, audio, sampleRate, mk, (int)markers.size(), pcm.data(), nullptr) != MX_OK) pcm.clear();
@@ -92,7 +95,7 @@ std::vector<float> Resynth::renderPV(const std::vector<Marker> &markers) const {
 bool Resynth::exportWavPV(const std::string &fileName, const std::vector<Marker> &markers) const {
   if (!ok()) return false;
   const mx_marker *mk = reinterpret_cast<const mx_marker *>(markers.data());
-  const int64_t m = mx_pv_render_length((int64_t)host.size(), sampleRate, mk, (int)markers.size());
+  const int64_t m = mx_pv_render_length((int64_t)nsrc, sampleRate, mk, (int)markers.size());
   if (m <= 0) return false;
   std::vector<int16_t> pcm16((size_t)m);
   if (mx_pv_render(ctx, audio, sampleRate, mk, (int)markers.size(), nullptr, pcm16.data()) != MX_OK) return false;
@@ -107,8 +110,8 @@ bool Resynth::exportWav(const std::string &fileName, const std::vector<Marker> &
   mx_step *steps = nullptr;
   int64_t nsteps = 0, nsamples = 0;
   const mx_marker *mk = reinterpret_cast<const mx_marker *>(markers.data());
-  if (mx_schedule_build(host.data(), (int64_t)host.size(), sampleRate, starts.data(), lens.data(), (int64_t)starts.size(),
-                        mk, (int)markers.size(), &steps, &nsteps, &nsamples) != MX_OK)
+  if (mx_schedule_build_table((int64_t)nsrc, sampleRate, starts.data(), lens.data(), firsts.data(), (int64_t)starts.size(), mk,
+                              (int)markers.size(), 0., -1, &steps, &nsteps, &nsamples, nullptr) != MX_OK)
     return false;
 #ifdef MELONIX_CORRECT_WAV_HEADER
   const int strict = 0;

@@ -54,11 +54,12 @@ public:
                             double *cursorEnd = nullptr) const;
 
 private:
-  std::vector<float> host;  // the schedule's nextGrainFirstSample lookups read the source audio
+  std::size_t nsrc = 0;  // samples of the source (resident on the device; the host keeps no copy)
   int sampleRate;
   mx_ctx *ctx = nullptr;
   mx_audio *audio = nullptr;
   std::vector<int32_t> starts, lens;
+  std::vector<float> firsts;  // first sample of every grain: all the export loop reads of the audio (app.cpp:323-328)
   bool run(const std::vector<Marker> &markers, std::vector<float> *f32, std::vector<int16_t> *i16, double cursor0 = 0.,
            int64_t need = -1, double *cursorEnd = nullptr) const;
 };

@@ -71,6 +71,9 @@ struct mx_ctx {
     void *p = nullptr;
     size_t cap = 0;
   } stage[4];
+  // device work buffers of the grain chain (mx_grains_dev): the two predicate bitmaps, the rank tables, the lifting
+  // tables — kept between calls like the staging buffers (guarded by zc_mu)
+  Stage chain[4];
   // work buffers of the phase vocoder (tens of GB for an hour of audio): hipMalloc of that size takes of the
   // order of a second, so the arena is kept for the next call; mx_ctx_destroy releases it
   std::mutex pv_mu;
@@ -282,6 +285,7 @@ void mx_ctx_destroy(mx_ctx *ctx) {
   }
   for (auto &kv : ctx->wtabs) hipFree(kv.second);
   for (auto &st : ctx->stage) hipFree(st.p);
+  for (auto &st : ctx->chain) hipFree(st.p);
   hipFree(ctx->pv_arena.p);
   hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -324,6 +328,10 @@ int mx_ctx_release_scratch(mx_ctx *ctx) {
   {
     std::lock_guard<std::mutex> lk(ctx->zc_mu);
     ctx->zc_scratch = ZcBitmaps{};
+    for (auto &st : ctx->chain) {
+      hipFree(st.p);
+      st = {};
+    }
   }
   return MX_OK;
 }
@@ -1014,65 +1022,92 @@ int mx_grains(const float *host_wav, int64_t n, int32_t **starts, int32_t **lens
   }
 }
 
-int mx_grains_dev(mx_ctx *ctx, const mx_audio *a, int32_t **starts, int32_t **lens, int64_t *count) {
+// grow-only device buffer `slot` of the grain chain; caller holds ctx->zc_mu
+static hipError_t chain_buf(mx_ctx *ctx, int slot, size_t bytes, void **out) {
+  mx_ctx::Stage &st = ctx->chain[slot];
+  if (st.cap < bytes) {
+    if (st.p) hipFree(st.p);
+    st = {};
+    const hipError_t e = hipMalloc(&st.p, bytes);
+    if (e != hipSuccess) return e;
+    st.cap = bytes;
+  }
+  *out = st.p;
+  return hipSuccess;
+}
+
+int mx_grain_table_dev(mx_ctx *ctx, const mx_audio *a, int32_t **starts, int32_t **lens, float **firsts, int64_t *count) {
   if (!ctx || !a || !starts || !lens || !count) return fail(MX_ERR_INVALID, "bad argument");
+  *starts = *lens = nullptr;
+  if (firsts) *firsts = nullptr;
+  *count = 0;
   HIP_TRY(hipSetDevice(ctx->device));
-  try {
-    const bool tr = getenv("MELONIX_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    const auto t0 = now();
-    std::lock_guard<std::mutex> zlk(ctx->zc_mu);
-    ZcBitmaps &zc = ctx->zc_scratch;
-    zc.n = a->n;
-    const size_t words = (size_t)((a->n + 63) >> 6);
-    zc.zc7.resize(words);  // (no-init allocator: the kernel writes every word)
-    zc.zc3.resize(words);
-    const auto t1 = now();
-    auto t2 = t1, t3 = t1, t4 = t1;
-    std::vector<int32_t> s, l;
-    if (!words) return export_vectors(s, l, starts, lens, count);
-    uint64_t *d7 = nullptr, *d3 = nullptr;
-    hipEvent_t ev7 = nullptr;
-    HIP_TRY(hipMalloc(&d7, words * 8));
-    hipError_t e = hipMalloc(&d3, words * 8);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev7, hipEventDisableTiming);
+  const bool tr = getenv("MELONIX_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](auto x, auto y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+  const auto t0 = now();
+  std::lock_guard<std::mutex> zlk(ctx->zc_mu);
+  const int64_t n = a->n;
+  const size_t words = (size_t)((n + 63) >> 6);
+  uint32_t ngr = 0;
+  int32_t *d_s = nullptr, *d_l = nullptr;
+  float *d_f = nullptr;
+  auto t1 = t0, t2 = t0;
+  if (words && n >= 1501) {  // (the reference's size_t arithmetic wraps below 1501 samples, app.cpp:161: no grains)
+    void *d7 = nullptr, *d3 = nullptr, *rk = nullptr, *ch = nullptr;
+    hipError_t e = chain_buf(ctx, 0, words * 8, &d7);
+    if (e == hipSuccess) e = chain_buf(ctx, 1, words * 8, &d3);
+    if (e == hipSuccess) e = chain_buf(ctx, 2, grain_rank_scratch_bytes(n), &rk);
+    if (e != hipSuccess) return fail(MX_ERR_NOMEM, "grain chain buffers: %s", hipGetErrorString(e));
+    HIP_TRY(launch_zc_bitmaps(a->d_padded, n, (uint64_t *)d7, (uint64_t *)d3, ctx->stream));
+    HIP_TRY(launch_grain_rank(a->d_padded, n, (const uint64_t *)d7, (const uint64_t *)d3, rk, ctx->stream));
+    uint32_t hdr[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(hdr, rk, sizeof hdr, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the node count sizes the lifting tables
+    t1 = now();
+    int levels;
+    uint32_t out_cap;
+    size_t bytes;
+    grain_chain_sizes(n, hdr[2], &levels, &out_cap, &bytes);
+    e = chain_buf(ctx, 3, bytes, &ch);
+    if (e != hipSuccess) return fail(MX_ERR_NOMEM, "grain chain tables (%zu bytes): %s", bytes, hipGetErrorString(e));
+    HIP_TRY(launch_grain_chain(a->d_padded, n, (const uint64_t *)d7, (const uint64_t *)d3, rk, hdr[2], ch, &d_s, &d_l, &d_f,
+                               ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hdr, rk, sizeof hdr, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     t2 = now();
-    if (e == hipSuccess) e = launch_zc_bitmaps(a->d_padded, a->n, d7, d3, ctx->stream);
-    if (tr && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    t3 = now();
-    // the look-around-3 bitmap is a fallback the walk rarely needs: it keeps copying while the
-    // walk already runs over the look-around-7 bitmap
-    if (e == hipSuccess) e = hipMemcpyAsync(zc.zc7.data(), d7, words * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipEventRecord(ev7, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(zc.zc3.data(), d3, words * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipEventSynchronize(ev7);
-    t4 = now();
-    hipError_t e3 = hipSuccess;
-    try {
-      if (e == hipSuccess) grains_from_bitmaps(zc, s, l, [&] { e3 = hipStreamSynchronize(ctx->stream); });
-    } catch (...) {  // the copy into zc's storage may still be running: drain it before unwinding
-      hipStreamSynchronize(ctx->stream);
-      if (ev7) hipEventDestroy(ev7);
-      hipFree(d7);
-      hipFree(d3);
-      throw;
-    }
-    const auto t5 = now();
-    const hipError_t es = hipStreamSynchronize(ctx->stream);  // zc3's copy targets zc's storage: drain before it dies
-    if (e == hipSuccess) e = e3 != hipSuccess ? e3 : es;
-    if (ev7) hipEventDestroy(ev7);
-    hipFree(d7);
-    hipFree(d3);
-    const auto t6 = now();
-    if (e != hipSuccess) return fail(MX_ERR_DEVICE, "zero-crossing bitmaps: %s", hipGetErrorString(e));
-    if (tr)
-      fprintf(stderr, "mx_grains_dev: alloc %.2f ms, kernel %.2f, D2H(zc7) %.2f, chain walk %.2f, drain+free %.2f\n",
-              ms(t0, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, t6));
-    return export_vectors(s, l, starts, lens, count);
-  } catch (const std::bad_alloc &) {
+    ngr = hdr[1];
+    if (ngr > out_cap) return fail(MX_ERR_DEVICE, "grain chain: %u grains exceed the bound %u", ngr, out_cap);
+  }
+  const size_t m = std::max<size_t>(ngr, 1);
+  int32_t *ps = (int32_t *)malloc(m * 4), *pl = (int32_t *)malloc(m * 4);
+  float *pf = firsts ? (float *)malloc(m * 4) : nullptr;
+  if (!ps || !pl || (firsts && !pf)) {
+    free(ps); free(pl); free(pf);
     return fail(MX_ERR_NOMEM, "out of host memory");
   }
+  if (ngr) {
+    hipError_t e = hipMemcpyAsync(ps, d_s, (size_t)ngr * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pl, d_l, (size_t)ngr * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && pf) e = hipMemcpyAsync(pf, d_f, (size_t)ngr * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      free(ps); free(pl); free(pf);
+      return fail(MX_ERR_DEVICE, "grain table download: %s", hipGetErrorString(e));
+    }
+  }
+  if (tr)
+    fprintf(stderr, "mx_grain_table_dev: bitmaps + ranks %.2f ms, chain %.2f, download of %u grains %.2f\n", ms(t0, t1),
+            ms(t1, t2), ngr, ms(t2, now()));
+  *starts = ps;
+  *lens = pl;
+  if (firsts) *firsts = pf;
+  *count = (int64_t)ngr;
+  return MX_OK;
+}
+
+int mx_grains_dev(mx_ctx *ctx, const mx_audio *a, int32_t **starts, int32_t **lens, int64_t *count) {
+  return mx_grain_table_dev(ctx, a, starts, lens, nullptr, count);
 }
 
 int mx_schedule_build(const float *host_wav, int64_t n, int sampleRate, const int32_t *grain_starts,
@@ -1082,11 +1117,35 @@ int mx_schedule_build(const float *host_wav, int64_t n, int sampleRate, const in
                                 steps, nsteps, nsamples, nullptr);
 }
 
+static int schedule_common(const float *host_wav, const float *firsts, int64_t n, int sampleRate, const int32_t *grain_starts,
+                           const int32_t *grain_lens, int64_t ngrains, const mx_marker *markers, int nmarkers,
+                           double cursor0, int64_t need, mx_step **steps, int64_t *nsteps, int64_t *nsamples,
+                           double *cursor_end);
+
 int mx_schedule_build_from(const float *host_wav, int64_t n, int sampleRate, const int32_t *grain_starts,
                            const int32_t *grain_lens, int64_t ngrains, const mx_marker *markers, int nmarkers,
                            double cursor0, int64_t need, mx_step **steps, int64_t *nsteps, int64_t *nsamples,
                            double *cursor_end) {
-  if (!steps || !nsteps || !nsamples || n < 0 || ngrains < 0 || nmarkers < 0 || (n > 0 && !host_wav) ||
+  if (n > 0 && !host_wav) return fail(MX_ERR_INVALID, "bad argument");
+  return schedule_common(host_wav, nullptr, n, sampleRate, grain_starts, grain_lens, ngrains, markers, nmarkers, cursor0,
+                         need, steps, nsteps, nsamples, cursor_end);
+}
+
+int mx_schedule_build_table(int64_t n, int sampleRate, const int32_t *grain_starts, const int32_t *grain_lens,
+                            const float *grain_firsts, int64_t ngrains, const mx_marker *markers, int nmarkers,
+                            double cursor0, int64_t need, mx_step **steps, int64_t *nsteps, int64_t *nsamples,
+                            double *cursor_end) {
+  if (ngrains > 0 && !grain_firsts) return fail(MX_ERR_INVALID, "bad argument");
+  static const float kNoGrain = 0.f;  // (an empty table: the loop never reads a first sample)
+  return schedule_common(nullptr, grain_firsts ? grain_firsts : &kNoGrain, n, sampleRate, grain_starts, grain_lens, ngrains,
+                         markers, nmarkers, cursor0, need, steps, nsteps, nsamples, cursor_end);
+}
+
+static int schedule_common(const float *host_wav, const float *firsts, int64_t n, int sampleRate, const int32_t *grain_starts,
+                           const int32_t *grain_lens, int64_t ngrains, const mx_marker *markers, int nmarkers,
+                           double cursor0, int64_t need, mx_step **steps, int64_t *nsteps, int64_t *nsamples,
+                           double *cursor_end) {
+  if (!steps || !nsteps || !nsamples || n < 0 || ngrains < 0 || nmarkers < 0 ||
       (ngrains > 0 && (!grain_starts || !grain_lens)) || (nmarkers > 0 && !markers))
     return fail(MX_ERR_INVALID, "bad argument");
   const bool tr = getenv("MELONIX_TIMING") != nullptr;
@@ -1100,16 +1159,17 @@ int mx_schedule_build_from(const float *host_wav, int64_t n, int sampleRate, con
     int64_t total = 0;
     const auto t1 = std::chrono::steady_clock::now();
     const int rc = build_schedule(host_wav, n, sampleRate, grain_starts, grain_lens, ngrains, markers, nmarkers, v,
-                                  total, err, cursor0, need, cursor_end);
+                                  total, err, cursor0, need, cursor_end, firsts);
     const auto t2 = std::chrono::steady_clock::now();
-    if (tr)
-      fprintf(stderr, "mx_schedule_build: validate %.2f ms, recurrence %.2f ms (%zu steps)\n",
-              std::chrono::duration<double, std::milli>(t1 - t0).count(),
-              std::chrono::duration<double, std::milli>(t2 - t1).count(), v.size());
     if (rc) return fail(rc, "%s", err.c_str());
     mx_step *p = (mx_step *)malloc(sizeof(mx_step) * std::max<size_t>(v.size(), 1));
     if (!p) return fail(MX_ERR_NOMEM, "out of host memory");
     if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(mx_step));
+    if (tr)
+      fprintf(stderr, "mx_schedule_build: validate %.2f ms, recurrence %.2f ms (%zu steps), hand-over %.2f ms\n",
+              std::chrono::duration<double, std::milli>(t1 - t0).count(),
+              std::chrono::duration<double, std::milli>(t2 - t1).count(), v.size(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
     *steps = p;
     *nsteps = (int64_t)v.size();
     *nsamples = total;

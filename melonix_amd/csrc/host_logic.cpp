@@ -29,6 +29,12 @@ TimeMap::TimeMap(const mx_marker *markers, int nmarkers, int sampleRate, int64_t
   lastSample_ = prevSample;
   lastTime_ = prevTime;
   lastPitchBend_ = prevPitchBend;
+  floor_.resize(segs_.size());
+  double hi = -HUGE_VAL;
+  for (size_t i = 0; i < segs_.size(); ++i) {
+    floor_[i] = hi;
+    hi = std::max(hi, segs_[i].rightTime);
+  }
 }
 
 double TimeMap::sample2time(int val) const {
@@ -46,6 +52,50 @@ int TimeMap::time2sample(double val) const {
       return static_cast<int>(s.prevSample +
                               (val - s.prevTime) * (s.sample - s.prevSample) / (s.rightTime - s.prevTime));
   return static_cast<int>(lastSample_ + (val - lastTime_) * sr_);
+}
+
+int TimeMap::time2sample(double val, int &hint) const {
+  if (val <= 0) return static_cast<int>(val * sr_);
+  if (hint >= 0 && hint < (int)segs_.size()) {
+    // the segments' (prevTime, rightTime] need not be disjoint when a stretch runs backwards: the scan returns the
+    // FIRST match, so the hint may only be used when no earlier segment matches — true when it is the first one, or
+    // when val lies beyond every earlier segment's right end (checked once per hint change below)
+    const Seg &s = segs_[(size_t)hint];
+    if (val > s.prevTime && val <= s.rightTime && val > hintFloor_(hint))
+      return static_cast<int>(s.prevSample + (val - s.prevTime) * (s.sample - s.prevSample) / (s.rightTime - s.prevTime));
+  }
+  for (size_t i = 0; i < segs_.size(); ++i) {
+    const Seg &s = segs_[i];
+    if (val > s.prevTime && val <= s.rightTime) {
+      hint = (int)i;
+      return static_cast<int>(s.prevSample + (val - s.prevTime) * (s.sample - s.prevSample) / (s.rightTime - s.prevTime));
+    }
+  }
+  return static_cast<int>(lastSample_ + (val - lastTime_) * sr_);
+}
+
+float TimeMap::time2pitchbend(double val, int &hint) const {
+  if (val <= 0) return 0;
+  if (hint >= 0 && hint < (int)segs_.size()) {
+    const Seg &s = segs_[(size_t)hint];
+    if (val > s.prevTime && val <= s.rightTime && val > hintFloor_(hint)) {
+      // a constant bend: prev + (val - t0)*0/(t1 - t0) = prev exactly (the quotient is a zero, t1 > t0 here)
+      if (s.pitchBend == s.prevPitchBend) return static_cast<float>(s.prevPitchBend + 0.0);
+      return static_cast<float>(s.prevPitchBend + (val - s.prevTime) * (s.pitchBend - s.prevPitchBend) /
+                                                      (s.rightTime - s.prevTime));
+    }
+  }
+  for (size_t i = 0; i < segs_.size(); ++i) {
+    const Seg &s = segs_[i];
+    if (val > s.prevTime && val <= s.rightTime) {
+      hint = (int)i;
+      return static_cast<float>(s.prevPitchBend + (val - s.prevTime) * (s.pitchBend - s.prevPitchBend) /
+                                                      (s.rightTime - s.prevTime));
+    }
+  }
+  const double dur = duration();
+  if (val > dur) return 0;
+  return static_cast<float>(lastPitchBend_ + (val - lastTime_) * (0 - lastPitchBend_) / (dur - lastTime_));
 }
 
 double TimeMap::duration() const { return sample2time(static_cast<int>(n_ - 1)); }
@@ -188,7 +238,7 @@ int64_t step_size(float rate, int32_t L) {
 int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *gstarts,
                    const int32_t *glens, int64_t ngrains, const mx_marker *markers, int nmarkers,
                    std::vector<mx_step> &steps, int64_t &nsamples, std::string &err, double cursor0, int64_t need,
-                   double *cursor_end) {
+                   double *cursor_end, const float *firsts) {
   steps.clear();
   nsamples = 0;
   if (sampleRate <= 0) { err = "sampleRate must be positive"; return MX_ERR_INVALID; }
@@ -196,7 +246,16 @@ int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *g
     if (markers[m].sample < markers[m - 1].sample) { err = "markers must be sorted by sample"; return MX_ERR_INVALID; }
   const TimeMap tm(markers, nmarkers, sampleRate, n);
   const int32_t *gend = gstarts + ngrains;
-  steps.reserve((size_t)ngrains + 16);
+  steps.reserve((size_t)ngrains + (size_t)ngrains / 2 + 16);
+  // process() emits step_size(rate, L) samples: a pure function of the two, asked ~n/1500 times with a few thousand
+  // distinct grain lengths — remembered per length for the current rate
+  constexpr int kSzCache = 4096;
+  struct SzEntry {
+    float rate;  // the rate the size was computed for (0: empty — never a valid rate)
+    int32_t sz;
+  };
+  std::vector<SzEntry> szc((size_t)kSzCache, SzEntry{0.f, 0});
+  int hintA = 0, hintB = 0, hintP = 0;  // segment hints of the three map evaluations per step
 
   // std::lower_bound(gstarts, gend, key) with a hint: the cursor moves about one grain per step, so
   // the answer is almost always within a few entries of the previous one (exact for any key: falls
@@ -215,15 +274,20 @@ int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *g
 
   double cursor = cursor0;  // app.cpp:1201 (0) / :272 (playback position)
   int64_t hint = 0;
+  // the grain lookup at cursor + dt (the step's nextGrainFirstSample) IS the next step's own lookup: the same pure
+  // function of the same double
+  double memoCursor = 0.;
+  const int32_t *memoIt = nullptr;
   float lastBend = 0.f, lastRate = powf(2, 0.f / 12);
   for (;;) {
     if (need >= 0 && nsamples >= need) break;  // app.cpp:273
-    const float pitchBend = tm.time2pitchbend(cursor);
+    const float pitchBend = tm.time2pitchbend(cursor, hintP);
     // app.cpp:297; the same libm call on the same argument, made once per distinct bend
     const float rate = (pitchBend == lastBend) ? lastRate : powf(2, pitchBend / 12);
     lastBend = pitchBend;
     lastRate = rate;
-    const int32_t *it1 = first_ge(tm.time2sample(cursor), hint);  // app.cpp:298-301
+    const int32_t *it1 = (memoIt && cursor == memoCursor) ? memoIt
+                                                           : first_ge(tm.time2sample(cursor, hintA), hint);  // app.cpp:298-301
     if (it1 == gend) {
       nsamples += 1500;  // app.cpp:303-309: preferredGrainSize zeros, then dt = 0 ends the export
       if (need >= 0) {       // playback: the loop simply asks again until it has enough samples
@@ -233,20 +297,29 @@ int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *g
     }
     const int64_t g = it1 - gstarts;
     hint = g + 1;
-    if (g + 3 < ngrains) __builtin_prefetch(wav + gstarts[g + 3]);  // a later step's next_first
-    const int64_t sz = step_size(rate, glens[g]);
+    if (!firsts && g + 3 < ngrains) __builtin_prefetch(wav + gstarts[g + 3]);  // a later step's next_first
+    const int32_t L = glens[g];
+    int64_t sz;
+    if (L < kSzCache && szc[(size_t)L].rate == rate) {
+      sz = szc[(size_t)L].sz;
+    } else {
+      sz = step_size(rate, L);
+      if (L < kSzCache && sz > 0 && sz < 0x7fffffffLL) szc[(size_t)L] = SzEntry{rate, (int32_t)sz};
+    }
     if (sz <= 0) {
       err = "pitch bend drives the resampling rate out of range (rate=" + std::to_string(rate) + ")";
       return MX_ERR_INVALID;
     }
     const double dt = 1. * (int)sz / sampleRate;  // app.cpp:323 / :344
-    const int32_t *it2 = first_ge(tm.time2sample(cursor + dt), g + 1);
+    const int32_t *it2 = first_ge(tm.time2sample(cursor + dt, hintB), g + 1);
+    memoCursor = cursor + dt;
+    memoIt = it2;
     mx_step st;
     st.cursor = cursor;
     st.grain_start = gstarts[g];
     st.grain_len = glens[g];
     st.rate = rate;
-    st.next_first = (it2 == gend) ? 0.f : wav[*it2];  // app.cpp:325-328
+    st.next_first = (it2 == gend) ? 0.f : (firsts ? firsts[it2 - gstarts] : wav[*it2]);  // app.cpp:325-328
     st.sz = (int32_t)sz;
     st._pad = 0;
     st.out_offset = nsamples;

@@ -31,6 +31,10 @@ class TimeMap {
   int time2sample(double val) const;     // app.cpp:1052-1082
   double duration() const;               // app.cpp:1084-1087
   float time2pitchbend(double val) const;  // app.cpp:1089-1122
+  // The same two maps with a segment hint (the export loop's cursor moves forward, so the segment that matched last
+  // time nearly always matches again): identical results, no scan over the segments.
+  int time2sample(double val, int &hint) const;
+  float time2pitchbend(double val, int &hint) const;
 
  private:
   struct Seg {
@@ -39,6 +43,8 @@ class TimeMap {
     double prevPitchBend, pitchBend;
   };
   std::vector<Seg> segs_;
+  std::vector<double> floor_;  // floor_[i] = max rightTime of the segments before i: above it none of them can match
+  double hintFloor_(int i) const { return floor_[(size_t)i]; }
   int sr_;
   int64_t n_;
   int lastSample_ = 0;
@@ -84,10 +90,12 @@ void grains_from_bitmaps(const ZcBitmaps &zc, std::vector<int32_t> &starts, std:
 // (its 1500 zeros are counted in nsamples).  need >= 0: App::playback's refill loop (app.cpp:272-274) —
 // calls chained from cursor0 until nsamples >= need; a call that finds no grain adds 1500 zeros and
 // leaves the cursor where it is, as often as the loop asks.  cursor_end: the loop's cursor on exit.
+// firsts (optional): firsts[g] = wav[gstarts[g]] (the grain table of mx_grain_table_dev) — then `wav` is not touched
+// at all (may be null): the only use the loop has for the audio is the next grain's first sample (app.cpp:325-328).
 int build_schedule(const float *wav, int64_t n, int sampleRate, const int32_t *gstarts,
                    const int32_t *glens, int64_t ngrains, const mx_marker *markers, int nmarkers,
                    std::vector<mx_step> &steps, int64_t &nsamples, std::string &err, double cursor0 = 0.,
-                   int64_t need = -1, double *cursor_end = nullptr);
+                   int64_t need = -1, double *cursor_end = nullptr, const float *firsts = nullptr);
 
 // Number of samples one process() call emits: #{ i >= 0 : floor(float(i)*rate) < L }
 // (app.cpp:313-322), in closed form + exact float correction.  Returns -1 when the

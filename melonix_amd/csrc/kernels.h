@@ -115,4 +115,14 @@ hipError_t launch_picks(const float *audio_padded, int64_t n, float *d_out, int6
 hipError_t launch_zc_bitmaps(const float *audio_padded, int64_t n, uint64_t *zc7, uint64_t *zc3,
                              hipStream_t s);
 
+// The grain chain of App::preproc on the device (grain_chain.hip): phase 1 ranks the look-around-3 bits (read header word 2
+// = node count back), phase 2 builds the chain; header word 1 = grain count, table = starts / lens / first samples.
+size_t grain_rank_scratch_bytes(int64_t n);
+hipError_t launch_grain_rank(const float *audio_padded, int64_t n, const uint64_t *zc7, const uint64_t *zc3, void *rank_scratch,
+                             hipStream_t s);
+void grain_chain_sizes(int64_t n, uint32_t nodes, int *levels_out, uint32_t *out_cap_out, size_t *bytes_out);
+hipError_t launch_grain_chain(const float *audio_padded, int64_t n, const uint64_t *zc7, const uint64_t *zc3, void *rank_scratch,
+                              uint32_t nodes, void *chain_scratch, int32_t **d_starts, int32_t **d_lens, float **d_firsts,
+                              hipStream_t s);
+
 }  // namespace mx

@@ -291,3 +291,27 @@ def test_resynth_dev_writes_every_sample_of_a_refill(gpu_ctx, oracle, mxlib):
     assert len(opcm) == total and np.array_equal(f32.view(np.uint32), opcm.view(np.uint32))
     assert not f32[covered:].any() and not i16[covered:].any()
     a.free()
+
+
+def test_device_grain_chain_hard_cases(gpu_ctx, oracle, mxlib):
+    """The chain is built on the device from the successor of EVERY crossing (binary lifting), so nothing depends on
+    chains merging: pure tones (two chains a period apart never meet), a long silence (the look-around-3 fallback has
+    to skip tens of thousands of empty bitmap words), a tone whose crossings are all more than 749 samples from the
+    preferred cut for a while (every grain a fallback grain), and the first samples of the grain table."""
+    t = np.arange(20 * SR)
+    cases = [
+        (0.5 * np.sin(2 * np.pi * 441.0 * t / SR)).astype(np.float32),
+        (0.5 * np.sin(2 * np.pi * 97.3 * t[: 6 * SR] / SR + 1.0)).astype(np.float32),
+        np.concatenate([accum_sweep(2 * SR), np.zeros(9 * SR, np.float32), accum_sweep(3 * SR)]),
+        (0.5 * np.sin(2 * np.pi * 12.0 * t[: 8 * SR] / SR)).astype(np.float32),   # period 4000 samples
+        np.concatenate([np.full(7000, -0.3, np.float32), accum_sweep(SR), np.full(5000, 0.2, np.float32)]),
+    ]
+    for w in cases:
+        a = gpu_ctx.upload(w)
+        s, l, f = gpu_ctx.grain_table_dev(a)
+        rs, rl = oracle.grains(w)
+        assert np.array_equal(s, rs) and np.array_equal(l, rl)
+        assert np.array_equal(f, w[rs]) if len(rs) else len(f) == 0
+        s2, l2 = gpu_ctx.grains_dev(a)
+        assert np.array_equal(s2, rs) and np.array_equal(l2, rl)
+        a.free()

@@ -212,3 +212,19 @@ def test_pv_plan_rejects_non_finite_markers(mxlib):
             mxlib.pv_plan(n, SR, bad)
         from melonix_amd import _capi
         assert _capi.lib().mx_pv_render_length(n, SR, _capi.markers_array(bad), len(bad)) < 0
+
+
+def test_schedule_from_grain_table_equals_schedule_from_audio(mxlib, sweep10):
+    """mx_schedule_build_table (first samples from the grain table, no audio) == mx_schedule_build_from, exports and
+    refills, constant bends, ramps and time warps (the hinted time maps and the step-size cache are exercised too)."""
+    w = noisy(sweep10, level=0.02)
+    n = len(w)
+    s, l = mxlib.grains_host(w)
+    firsts = w[s]
+    for mk in ([], [(1, 0, 0, 3.0), (n - 1, 0, 0, 3.0)], [(1, 0, 0, -2.0), (n - 1, 0, 0, 4.0)],
+               [(1000, 0, 0.0, 2.0), (100000, 0, 0.5, -3.0), (300000, 0, -0.2, 5.0), (n - 1, 0, 0, 0)],
+               [(5000, 0, 0.3, 1.0), (200000, 0, -1.5, 1.0), (400000, 0, 2.0, -7.0)]):
+        for cur, need in ((0.0, -1), (2.5, 40000), (9.7, 30000)):
+            a, ta, ea = mxlib.schedule_build_from(w, SR, s, l, mk, cur, need)
+            b, tb, eb = mxlib.schedule_build_table(n, SR, s, l, firsts, mk, cur, need)
+            assert _same_steps(a, b) and ta == tb and ea == eb
