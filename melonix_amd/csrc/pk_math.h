@@ -187,6 +187,22 @@ __device__ __forceinline__ void pk_leaf0_tw(cpx a, cpx v1, cpx w1, cpx &out0, cp
   out0 = pkc(o0);
   out1 = pkc(o1);
 }
+// a * (cs.x - i*cs.y), cs wave-uniform: a rotation by a compile-time angle
+__device__ __forceinline__ cpx pk_rot_cs(cpx a, cpx cs) {
+  mx_v2 d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 " MX_PK_YWC
+      : "=&v"(d) : "v"(pkv(a)), "s"(pkv(cs)));
+  return pkc(d);
+}
+// a * b (both per-thread values)
+__device__ __forceinline__ cpx pk_cmul2(cpx a, cpx b) {
+  mx_v2 d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 " MX_PK_YW
+      : "=&v"(d) : "v"(pkv(a)), "v"(pkv(b)));
+  return pkc(d);
+}
 // real-FFT split of one (k, M-k) pair, A = Z[k], B = Z[M-k], u = i*w_k:
 //   Sm = A + conj(B), D = u*(A - conj(B)), lo = Sm - D, hi = Sm + D  ->  (|lo|^2, |hi|^2)
 __device__ __forceinline__ cpx pk_split_norm2(cpx A, cpx B, cpx u) {
@@ -204,6 +220,14 @@ __device__ __forceinline__ cpx pk_split_norm2(cpx A, cpx B, cpx u) {
 }
 #endif
 
+MX_PK_HOST cpx pk_rot_cs(cpx a, cpx cs) {
+  const cpx t = pk_mul_xs(a, cs);
+  return pk_fma_ywcs(a, cs, t);
+}
+MX_PK_HOST cpx pk_cmul2(cpx a, cpx b) {
+  const cpx t = pk_mul_x(a, b);
+  return pk_fma_yw(a, b, t);
+}
 MX_PK_HOST void pk_bfly_cs(cpx E, cpx O, cpx cs, cpx &out0, cpx &out1) {
   const cpx t = pk_fma_xs(O, cs, E);
   out0 = pk_fma_ywcs(O, cs, t);

@@ -303,6 +303,20 @@ MX_HD void load_raw(int t, cpx (&xr)[P::E], const float *x) {
     }
   }
 }
+// slots [E0, E1) only (a prefetch issued in two halves keeps fewer registers in flight at a time)
+template <class P, bool ALIGNED8, int E0, int E1>
+MX_HD void load_raw_part(int t, cpx (&xr)[P::E], const float *x) {
+#pragma unroll
+  for (int e = E0; e < E1; ++e) {
+    const int p = 2 * (t + P::T * e);
+    if constexpr (ALIGNED8) {
+      xr[e] = *reinterpret_cast<const cpx *>(x + p);
+    } else {
+      const f2u xs = *reinterpret_cast<const f2u *>(x + p);
+      xr[e] = mk(xs.x, xs.y);
+    }
+  }
+}
 template <class P, int WSTEP, bool ALIGNED8>
 MX_HD void apply_window(int t, cpx (&Y)[P::E], const cpx (&xr)[P::E], const float *w) {
 #pragma unroll
@@ -546,6 +560,32 @@ MX_HD void fetch_tw2(int t, const cpx *tw2, cpx (&w)[P::NB2][P::R2 - 1]) {
     for (int r = 1; r < P::R2; ++r) w[b][r - 1] = tw2[(r - 1) * P::R1 + k];
   }
 }
+// Two-level pass-2 twiddles (one butterfly per thread, R2 = 16): w_r = beta^r with beta = exp(-2*pi*i*k/(R1*R2)) this
+// thread's base.  Six powers stay in registers (beta^1..3 and beta^4, 8, 12); the other nine are one complex product
+// each per frame — 18 packed instructions instead of 15 LDS reads (an LDS read costs ~10x the energy of a packed op).
+template <class P>
+MX_HD void fetch_tw2_bases(int t, const cpx *tw2, cpx (&wb)[6]) {
+  static_assert(P::NB2 == 1 && P::R2 == 16, "two-level twiddles are written for one radix-16 butterfly per thread");
+  const int k = t & (P::R1 - 1);
+  constexpr int rr[6] = {1, 2, 3, 4, 8, 12};
+#pragma unroll
+  for (int i = 0; i < 6; ++i) wb[i] = tw2[(rr[i] - 1) * P::R1 + k];
+}
+template <class P>
+MX_HD void pass2_reg(cpx (&v)[P::E], const cpx (&w)[P::NB2][P::R2 - 1]);
+template <class P>
+MX_HD void pass2_bases(cpx (&v)[P::E], const cpx (&wb)[6]) {
+  cpx w[1][P::R2 - 1];
+#pragma unroll
+  for (int r = 1; r < P::R2; ++r) {
+    const int hi = r >> 2, lo = r & 3;  // beta^r = beta^(4*hi) * beta^lo
+    if (hi == 0) w[0][r - 1] = wb[lo - 1];
+    else if (lo == 0) w[0][r - 1] = wb[2 + hi];
+    else w[0][r - 1] = pk_cmul2(wb[2 + hi], wb[lo - 1]);
+  }
+  pass2_reg<P>(v, w);
+}
+
 template <class P>
 MX_HD void pass2_reg(cpx (&v)[P::E], const cpx (&w)[P::NB2][P::R2 - 1]) {
 #pragma unroll
@@ -734,6 +774,38 @@ struct PostSlot {
 
 template <class P, bool MAY0 = true>
 MX_HD void post(int t, const cpx (&v)[P::E], const cpx (&u)[P::R3], float (&mg)[P::E]) {
+  PostSlot<P, 0>::run(MAY0 && t == 0, v, u, mg);
+}
+
+// The same with the R3 post-split twiddles rebuilt from their base every frame (u[s] = base * exp(-2*pi*i*s/(2*R3)):
+// a rotation by a compile-time angle, two packed instructions) instead of being held in 2*R3 registers — the
+// registers go to the pass-2 twiddle bases (stft_kernel_impl.h, TWREG == 4), which saves R2-1 LDS reads per frame.
+template <class P, int S>
+struct PostFly {
+  static MX_HD void run(cpx lo, cpx hi, cpx (&u)[P::R3]) {
+    constexpr int k = ((32 / P::R3) * S) % 64;
+    const cpx b = S < P::R3 / 2 ? lo : hi;
+    if constexpr (k == 0) u[S] = b;
+    else if constexpr (k == 16) u[S] = mk(b.y, -b.x);
+    else u[S] = pk_rot_cs(b, mk(kCos64[k], kSin64[k]));
+    if constexpr (S + 1 < P::R3) PostFly<P, S + 1>::run(lo, hi, u);
+  }
+};
+template <class P>
+MX_HD void post_bases(int t, const cpx *ubase, cpx &lo, cpx &hi) {
+  if (t) {
+    lo = ubase[t];
+    hi = lo;
+  } else {
+    constexpr int k = 16 / P::R3;
+    lo = mk(kSin64[k], kCos64[k]);
+    hi = mk(-1.0f, 0.0f);
+  }
+}
+template <class P, bool MAY0 = true>
+MX_HD void post_fly(int t, const cpx (&v)[P::E], cpx lo, cpx hi, float (&mg)[P::E]) {
+  cpx u[P::R3];
+  PostFly<P, 0>::run(lo, MAY0 ? hi : lo, u);
   PostSlot<P, 0>::run(MAY0 && t == 0, v, u, mg);
 }
 

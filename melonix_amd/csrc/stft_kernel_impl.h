@@ -48,7 +48,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 // NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
 // and window loads are not hoisted out of the frame loop into hundreds of registers.
 template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, int TWREG = 0, bool OUTSEP = false,
-          bool DEFER = false, bool PREFETCH = false, bool EARLYBAR = false, bool CMAP = false>
+          bool DEFER = false, int PREFETCH = 0, bool EARLYBAR = false, bool CMAP = false>
 __global__ __launch_bounds__(P::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void stft_kernel(const StftArgs a0) {
   const StftArgs &a = a0;
@@ -61,7 +61,16 @@ void stft_kernel(const StftArgs a0) {
   // the next frame without an extra barrier
   constexpr int kRed = (NW > 1) ? ((NW + 1) / 2) * 2 : 0;
   // TWREG == 2: the (small) pass-2 twiddle table lives in LDS, shared by the workgroup's waves
-  constexpr int kTw2 = (TWREG >= 2) ? ((C::TW2 + 1) / 2) * 2 : 0;  // TWREG == 3: tw2 in LDS, tw3 from L2
+  // TWREG == 3: tw2 in LDS, tw3 from L2;  TWREG == 4: nothing in LDS — six pass-2 base powers + the pass-3 twiddles
+  // in registers, the post-split twiddles rebuilt per frame (post_fly)
+  constexpr bool kTwoLevel = (TWREG == 4);
+  // PREFETCH (direct modes): 1 = the next frame's raw samples are requested once pass 3 has freed the transform's
+  // registers; 2 = right after pass 2 (into the registers its twiddles held), so that the load — bound by the ~15 B/clk
+  // a CU can have in flight from L2: 8 800 cycles for the 128 KiB of an N = 32768 frame — runs under the second
+  // transposition, pass 3 and the output instead of in front of pass 1.  With 2 the post-split twiddles are rebuilt per frame (post_fly): the
+  // registers they occupied hold samples in flight.
+  constexpr bool kPostFly = kTwoLevel || (PREFETCH == 2) || (TWREG == 5);  // TWREG == 5: placement 2 + post_fly
+  constexpr int kTw2 = (TWREG == 2 || TWREG == 3 || TWREG == 5) ? ((C::TW2 + 1) / 2) * 2 : 0;
   // EARLYBAR (needs DEFER): the barrier that frees the image for the next frame sits right after
   // the T2 read instead of in front of the next T1 scatter, so that scatter can be issued while
   // pass 1 is still computing (same number of barriers per frame).
@@ -72,8 +81,13 @@ void stft_kernel(const StftArgs a0) {
 
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;  // wave-uniform
-  cpx u[P::R3];  // post-split twiddles: E registers that replace R3 complex multiplies per frame
-  post_twiddles<P>(t_, a.ubase, u);
+  cpx u[kPostFly ? 1 : P::R3];  // post-split twiddles: E registers that replace R3 complex multiplies per frame
+  cpx ulo, uhi;
+  if constexpr (kPostFly) {
+    post_bases<P>(t_, a.ubase, ulo, uhi);
+  } else {
+    post_twiddles<P>(t_, a.ubase, *reinterpret_cast<cpx(*)[P::R3]>(&u));
+  }
   const uint32_t bmask_ = band_mask<P>(t_, a.kmin, a.kmax);
   // output slots some lane of this wavefront needs for the pitch pick (wave-uniform)
   uint32_t umask = 0;
@@ -85,9 +99,11 @@ void stft_kernel(const StftArgs a0) {
   constexpr float kSc = 0.5f / (float)N;
   // TWREG: this thread's pass-2/pass-3 twiddles live in registers for the whole workgroup
   cpx w2r[TWREG == 1 ? P::NB2 : 1][P::R2 - 1], w3r[P::R3 - 1];
+  cpx w2base[6];
+  if constexpr (kTwoLevel) fetch_tw2_bases<P>(t_, a.tw2, w2base);
   if constexpr (TWREG == 1) fetch_tw2<P>(t_, a.tw2, w2r);
-  if constexpr (TWREG == 1 || TWREG == 2) fetch_tw3<P>(t_, a.tw3, w3r);
-  if constexpr (TWREG >= 2) {
+  if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) fetch_tw3<P>(t_, a.tw3, w3r);
+  if constexpr (TWREG == 2 || TWREG == 3 || TWREG == 5) {
     for (int i = t_; i < C::TW2; i += C::T) ltw2[i] = a.tw2[i];
     MX_BARRIER();
   }
@@ -227,7 +243,7 @@ void stft_kernel(const StftArgs a0) {
     cpx v[P::E];
     pass1<P>(Y, v);
 #if defined(MX_LDS_ASM)
-    constexpr bool kTw2Batch = (TWREG >= 2) && (P::NB2 == 1);  // twiddles ride with the T1 read
+    constexpr bool kTw2Batch = (TWREG == 2 || TWREG == 3 || TWREG == 5) && (P::NB2 == 1);  // twiddles ride with the T1 read
 #else
     constexpr bool kTw2Batch = false;
 #endif
@@ -252,26 +268,47 @@ void stft_kernel(const StftArgs a0) {
       if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
     }
     MX_BARRIER();
-    if constexpr (TWREG == 1) pass2_reg<P>(v, w2r);
+    if constexpr (kTwoLevel) pass2_bases<P>(v, w2base);
+    else if constexpr (TWREG == 1) pass2_reg<P>(v, w2r);
     else if constexpr (kTw2Batch) pass2_reg<P>(v, w2b);
     else if constexpr (TWREG >= 2) pass2<P>(t, v, ltw2);
     else pass2<P>(t, v, tw2);
+    if constexpr (PREFETCH == 2 && !kSlide) {
+      if (f + 1 < f1) {  // the pass-2 twiddles are dead: their registers take the first half of the next frame's samples
+        const float *xn;
+        const float *wn;
+        frame_ptrs(f + 1, zoff, xn, wn);
+        asm volatile("" ::: "memory");  // (keeps the scheduler from hoisting these loads into pass 2's register peak)
+        load_raw_part<P, (MODE == kBulkAligned), 0, P::E / 2>(t, xr, xn);
+      }
+    }
     store_t2<P>(t, v, lds);
     MX_BARRIER();
     load_t2<P>(t, v, lds);
     if constexpr (!OUTSEP || EARLYBAR) MX_BARRIER();  // image free (for the magnitude scatter / the next T1 scatter)
     float mg[P::E];
     if (NW == 1 || wave0) {  // wave-uniform: only the first wavefront contains thread 0
-      if constexpr (TWREG == 1 || TWREG == 2) pass3_reg<P, true>(t, v, w3r);
+      if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, true>(t, v, w3r);
       else pass3<P, true>(t, v, tw3);
-      post<P, true>(t, v, u, mg);
+      if constexpr (kPostFly) post_fly<P, true>(t, v, ulo, uhi, mg);
+      else post<P, true>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
     } else {
-      if constexpr (TWREG == 1 || TWREG == 2) pass3_reg<P, false>(t, v, w3r);
+      if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, false>(t, v, w3r);
       else pass3<P, false>(t, v, tw3);
-      post<P, false>(t, v, u, mg);
+      if constexpr (kPostFly) post_fly<P, false>(t, v, ulo, uhi, mg);
+      else post<P, false>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
     }
 
-    if constexpr (PREFETCH && !kSlide) {
+    if constexpr (PREFETCH == 2 && !kSlide) {
+      if (f + 1 < f1) {  // ... and the transform's own registers the second half
+        const float *xn;
+        const float *wn;
+        frame_ptrs(f + 1, zoff, xn, wn);
+        asm volatile("" ::: "memory");
+        load_raw_part<P, (MODE == kBulkAligned), P::E / 2, P::E>(t, xr, xn);
+      }
+    }
+    if constexpr (PREFETCH == 1 && !kSlide) {
       // the transform's registers are free again: request the next frame's samples now, so that they
       // arrive under the pitch pick, the magnitude transposition and the row's stores
       if (f + 1 < f1) {

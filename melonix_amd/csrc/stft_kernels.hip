@@ -31,6 +31,11 @@ struct Tune {
   //   3 = only the pass-2 table in LDS (1.9 / 3.8 / 7.9 KiB), pass-3 twiddles from L2 — for the sliding
   //       N >= 16384 kernels, whose register image of the frame leaves no room for 30 more VGPRs;
   //   (1 = all in registers: spills; 0 = both from L2 every frame.)
+  //   4 = (one radix-16 pass-2 butterfly per thread, i.e. N = 4096) no twiddle in LDS at all: six pass-2 base powers
+  //       and the pass-3 twiddles in registers, the other nine pass-2 twiddles and the post-split twiddles rebuilt
+  //       per frame (32 packed instructions instead of 15 LDS reads).  Measured: 1.89 ms either way at N = 4096 —
+  //       the twiddle reads are broadcasts (16 distinct words per wave instruction) and cost far less than the
+  //       transposition traffic — so 2 stays the default.
   template <bool SLIDING>
   static constexpr int twreg() { return (P::N >= 16384 && SLIDING) ? 3 : 2; }
   // hops the sliding kernel is instantiated for (the larger shifts D = hop/2T need more edge/prefetch registers

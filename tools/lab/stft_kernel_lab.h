@@ -19,6 +19,22 @@
 namespace mxlab {
 using namespace mx;
 
+// Phase timeline probe: with -DMX_TIMELINE the waves of one workgroup (blockIdx.x == MX_TL_BLOCK) stamp s_memtime at the
+// phase boundaries of one frame; tools/timeline_lab.hip prints the deltas.  g_tl[wave][stamp].
+#ifdef MX_TIMELINE
+__device__ unsigned long long g_tl[16][24];
+#define MX_TS(i)                                                                                       \
+  do {                                                                                                 \
+    if (blockIdx.x == MX_TL_BLOCK && f == f0 + MX_TL_FRAME) {                                          \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+      const unsigned long long ts_ = __builtin_amdgcn_s_memtime();                                     \
+      if ((threadIdx.x & 63) == 0) g_tl[threadIdx.x >> 6][i] = ts_;                                    \
+    }                                                                                                  \
+  } while (0)
+#else
+#define MX_TS(i)
+#endif
+
 // Wavefront reductions through the DPP crossbar (no LDS round trips, unlike __shfl_xor which lowers
 // to ds_bpermute): xor-1, xor-2 (quad_perm), row_half_mirror, row_mirror leave every 16-lane row
 // with its result; row_bcast:15 / row_bcast:31 fold the rows; lane 63 holds the wavefront's.
@@ -218,6 +234,7 @@ void stft_kernel(const StftArgs a0) {
     int out_lo, out_hi;
     out_bases<P>(t, out_lo, out_hi);
 
+    MX_TS(0);
     if constexpr (kSlide) {
       // in-place shift+decay into this frame (Y[e] <- Y[e+D]*g reads ahead of what it writes), then
       // prefetch the next frame's newest hop (1 KiB per wavefront) under this frame's math
@@ -238,6 +255,7 @@ void stft_kernel(const StftArgs a0) {
       }
     }
 
+    MX_TS(1);
     cpx v[P::E];
 #ifdef MX_ABL_NOVALU
 #pragma unroll
@@ -245,6 +263,7 @@ void stft_kernel(const StftArgs a0) {
 #else
     pass1<P>(Y, v);
 #endif
+    MX_TS(2);
 #if defined(MX_LDS_ASM) && !defined(MX_ABL_NOLDS)
     constexpr bool kTw2Batch = (TWREG >= 2) && (P::NB2 == 1);  // twiddles ride with the T1 read
 #else
@@ -256,14 +275,28 @@ void stft_kernel(const StftArgs a0) {
       MX_BARRIER();  // every wave is past load_t2 / scatter / red[] of the previous frame
       if (f > f0) flush_pitch(f - 1, t);
     }
+#ifndef MX_ABL_NOT1W
     store_t1<P>(t, v, lds);
+#endif
+    MX_TS(3);
     MX_BARRIER();
+    MX_TS(4);
     if constexpr (EARLYBAR) {
       if (f > f0) flush_pitch(f - 1, t);
     }
     if constexpr (kTw2Batch) {
 #ifdef MX_LDS_ASM
+#ifdef MX_ABL_NOTW2READ
+      // energy probe: the 15 pass-2 twiddles are NOT read from LDS (constants instead: wrong results)
+      load_t1<P>(t, v, lds);
+#pragma unroll
+      for (int r = 0; r < P::R2 - 1; ++r) w2b[0][r] = mk(0.5f + 0.01f * r, 0.25f);
+#elif defined(MX_ABL_NOT1R)
+#pragma unroll
+      for (int r = 0; r < P::R2 - 1; ++r) w2b[0][r] = v[r];  // (no LDS read at all: data stays where it is)
+#else
       load_t1_tw2<P>(t, v, lds, ltw2, w2b);
+#endif
 #endif
     } else {
       load_t1<P>(t, v, lds);
@@ -271,7 +304,9 @@ void stft_kernel(const StftArgs a0) {
     if constexpr (DEFER) {
       if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
     }
+    MX_TS(5);
     MX_BARRIER();
+    MX_TS(6);
 #endif
 #ifdef MX_ABL_NOVALU
     if constexpr (kTw2Batch) { v[1].x += w2b[0][0].x + w2b[0][P::R2 - 2].y; }
@@ -282,10 +317,19 @@ void stft_kernel(const StftArgs a0) {
     else pass2<P>(t, v, tw2);
 #endif
 #ifndef MX_ABL_NOLDS
+    MX_TS(7);
+#ifndef MX_ABL_NOT2W
     store_t2<P>(t, v, lds);
+#endif
+    MX_TS(8);
     MX_BARRIER();
+    MX_TS(9);
+#ifndef MX_ABL_NOT2R
     load_t2<P>(t, v, lds);
+#endif
+    MX_TS(10);
     if constexpr (!OUTSEP || EARLYBAR) MX_BARRIER();  // image free (for the magnitude scatter / the next T1 scatter)
+    MX_TS(11);
 #endif
     float mg[P::E];
 #ifdef MX_ABL_NOVALU
@@ -315,6 +359,7 @@ void stft_kernel(const StftArgs a0) {
       }
     }
 
+    MX_TS(12);
     // ---- pitch pick: per-thread best, then wavefront max (registers only) ----
     // key = (magnitude bits << 32) | (0x7fffffff - bin): non-negative floats order like their
     // bit patterns, so max(key) = largest magnitude, lowest bin on ties; out-of-band -> 0.
@@ -343,6 +388,7 @@ void stft_kernel(const StftArgs a0) {
       }
     }
 
+    MX_TS(13);
     // ---- magnitudes ----
     // Transpose through LDS: each lane scatters its E bins as dwords (consecutive lanes ->
     // consecutive bins, conflict-free), then every lane owns 4 consecutive bins and the row
@@ -375,6 +421,7 @@ void stft_kernel(const StftArgs a0) {
         else (s < H ? mlo : mhi)[-C::NS3 * s] = mg[2 * s + 1];
       }
     }
+    MX_TS(14);
     if constexpr (!DEFER) {
       if (want_rows) {
         MX_BARRIER();  // (also: every wave is past load_t2, so the image may be refilled)
@@ -392,6 +439,7 @@ void stft_kernel(const StftArgs a0) {
         a.pitch[f] = p;
       }
     }
+    MX_TS(15);
   }
   if constexpr (DEFER) {
     if (f0 < f1) {  // the last frame of this workgroup

@@ -2,7 +2,7 @@
 # tools/power_lab.sh [build|run] — energy attribution of the headline STFT kernel (see tools/power_lab.hip).
 #   build (here, CPU container): one binary per variant under tools/bin/
 #   run (GPU box): each variant for 3 s with rocm-smi power/sclk sampled every ~60 ms -> gpurun_out/r2/power_lab.log
-VARIANTS="base:-DDUMMY nolds:-DMX_ABL_NOLDS nogstore:-DMX_ABL_NOGSTORE pitchonly:-DLAB_PITCH_ONLY novalu:-DMX_ABL_NOVALU noldsnovalu:-DMX_ABL_NOLDS,-DMX_ABL_NOVALU idle:-DLAB_IDLE"
+VARIANTS="${LAB_VARIANTS:-base:-DDUMMY notw2read:-DMX_ABL_NOTW2READ nolds:-DMX_ABL_NOLDS nogstore:-DMX_ABL_NOGSTORE pitchonly:-DLAB_PITCH_ONLY novalu:-DMX_ABL_NOVALU noldsnovalu:-DMX_ABL_NOLDS,-DMX_ABL_NOVALU idle:-DLAB_IDLE}"
 if [ "$1" = "build" ]; then
   mkdir -p tools/bin
   for v in $VARIANTS; do
