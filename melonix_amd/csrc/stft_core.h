@@ -711,6 +711,32 @@ MX_HD void fetch_tw3(int t, const cpx *tw3, cpx (&w)[P::R3 - 1]) {
 #pragma unroll
   for (int r = 1; r < P::R3; ++r) w[r - 1] = tw3[(r - 1) * P::NS3 + col];
 }
+// Two-level pass-3 twiddles (R3 = 16): w_r = gamma^r, gamma = exp(-2*pi*i*col/M) this thread's base.  Six powers stay
+// in registers (gamma^1..3 and gamma^4, 8, 12), the other nine are one complex product each per frame: 12 registers
+// instead of 30 — what lets the plans with 32 points per thread keep their pass-3 twiddles out of L2 next to a
+// sliding frame image (15 loads per thread and frame otherwise).
+template <class P>
+MX_HD void fetch_tw3_bases(int t, const cpx *tw3, cpx (&wb)[6]) {
+  static_assert(P::R3 == 16, "two-level pass-3 twiddles are written for radix 16");
+  const int col = t ? t : P::NS3 / 2;
+  constexpr int rr[6] = {1, 2, 3, 4, 8, 12};
+#pragma unroll
+  for (int i = 0; i < 6; ++i) wb[i] = tw3[(rr[i] - 1) * P::NS3 + col];
+}
+template <class P, bool MAY0>
+MX_HD void pass3_reg(int t, cpx (&v)[P::E], const cpx (&w)[P::R3 - 1]);
+template <class P, bool MAY0 = true>
+MX_HD void pass3_bases(int t, cpx (&v)[P::E], const cpx (&wb)[6]) {
+  cpx w[P::R3 - 1];
+#pragma unroll
+  for (int r = 1; r < P::R3; ++r) {
+    const int hi = r >> 2, lo = r & 3;
+    if (hi == 0) w[r - 1] = wb[lo - 1];
+    else if (lo == 0) w[r - 1] = wb[2 + hi];
+    else w[r - 1] = pk_cmul2(wb[2 + hi], wb[lo - 1]);
+  }
+  pass3_reg<P, MAY0>(t, v, w);
+}
 template <class P, bool MAY0 = true>
 MX_HD void pass3_reg(int t, cpx (&v)[P::E], const cpx (&w)[P::R3 - 1]) {
   constexpr int R = P::R3;

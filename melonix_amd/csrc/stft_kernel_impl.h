@@ -69,8 +69,11 @@ void stft_kernel(const StftArgs a0) {
   // a CU can have in flight from L2: 8 800 cycles for the 128 KiB of an N = 32768 frame — runs under the second
   // transposition, pass 3 and the output instead of in front of pass 1.  With 2 the post-split twiddles are rebuilt per frame (post_fly): the
   // registers they occupied hold samples in flight.
-  constexpr bool kPostFly = kTwoLevel || (PREFETCH == 2) || (TWREG == 5);  // TWREG == 5: placement 2 + post_fly
-  constexpr int kTw2 = (TWREG == 2 || TWREG == 3 || TWREG == 5) ? ((C::TW2 + 1) / 2) * 2 : 0;
+  // TWREG == 5: placement 2 + post_fly;  TWREG == 6: pass-2 table in LDS, six pass-3 base powers in registers (the rest
+  // rebuilt per frame), post_fly — the 32-points-per-thread plans with a sliding frame image
+  constexpr bool kTw3Bases = (TWREG == 6);
+  constexpr bool kPostFly = kTwoLevel || (PREFETCH == 2) || (TWREG == 5) || kTw3Bases;
+  constexpr int kTw2 = (TWREG == 2 || TWREG == 3 || TWREG == 5 || TWREG == 6) ? ((C::TW2 + 1) / 2) * 2 : 0;
   // EARLYBAR (needs DEFER): the barrier that frees the image for the next frame sits right after
   // the T2 read instead of in front of the next T1 scatter, so that scatter can be issued while
   // pass 1 is still computing (same number of barriers per frame).
@@ -99,11 +102,12 @@ void stft_kernel(const StftArgs a0) {
   constexpr float kSc = 0.5f / (float)N;
   // TWREG: this thread's pass-2/pass-3 twiddles live in registers for the whole workgroup
   cpx w2r[TWREG == 1 ? P::NB2 : 1][P::R2 - 1], w3r[P::R3 - 1];
-  cpx w2base[6];
+  cpx w2base[6], w3base[6];
+  if constexpr (TWREG == 6) fetch_tw3_bases<P>(t_, a.tw3, w3base);
   if constexpr (kTwoLevel) fetch_tw2_bases<P>(t_, a.tw2, w2base);
   if constexpr (TWREG == 1) fetch_tw2<P>(t_, a.tw2, w2r);
   if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) fetch_tw3<P>(t_, a.tw3, w3r);
-  if constexpr (TWREG == 2 || TWREG == 3 || TWREG == 5) {
+  if constexpr (TWREG == 2 || TWREG == 3 || TWREG == 5 || TWREG == 6) {
     for (int i = t_; i < C::TW2; i += C::T) ltw2[i] = a.tw2[i];
     MX_BARRIER();
   }
@@ -243,7 +247,7 @@ void stft_kernel(const StftArgs a0) {
     cpx v[P::E];
     pass1<P>(Y, v);
 #if defined(MX_LDS_ASM)
-    constexpr bool kTw2Batch = (TWREG == 2 || TWREG == 3 || TWREG == 5) && (P::NB2 == 1);  // twiddles ride with the T1 read
+    constexpr bool kTw2Batch = (TWREG == 2 || TWREG == 3 || TWREG == 5 || TWREG == 6) && (P::NB2 == 1);  // twiddles ride with the T1 read
 #else
     constexpr bool kTw2Batch = false;
 #endif
@@ -288,12 +292,14 @@ void stft_kernel(const StftArgs a0) {
     if constexpr (!OUTSEP || EARLYBAR) MX_BARRIER();  // image free (for the magnitude scatter / the next T1 scatter)
     float mg[P::E];
     if (NW == 1 || wave0) {  // wave-uniform: only the first wavefront contains thread 0
-      if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, true>(t, v, w3r);
+      if constexpr (kTw3Bases) pass3_bases<P, true>(t, v, w3base);
+      else if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, true>(t, v, w3r);
       else pass3<P, true>(t, v, tw3);
       if constexpr (kPostFly) post_fly<P, true>(t, v, ulo, uhi, mg);
       else post<P, true>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
     } else {
-      if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, false>(t, v, w3r);
+      if constexpr (kTw3Bases) pass3_bases<P, false>(t, v, w3base);
+      else if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, false>(t, v, w3r);
       else pass3<P, false>(t, v, tw3);
       if constexpr (kPostFly) post_fly<P, false>(t, v, ulo, uhi, mg);
       else post<P, false>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);

@@ -36,11 +36,26 @@ struct Tune {
   //       per frame (32 packed instructions instead of 15 LDS reads).  Measured: 1.89 ms either way at N = 4096 —
   //       the twiddle reads are broadcasts (16 distinct words per wave instruction) and cost far less than the
   //       transposition traffic — so 2 stays the default.
-  template <bool SLIDING>
-  static constexpr int twreg() { return (P::N >= 16384 && SLIDING) ? 3 : 2; }
+  //   6 = (R3 = 16: the 32-points-per-thread plans) pass-2 table in LDS, SIX pass-3 base powers in registers (the
+  //       other nine twiddles are one packed complex product each per frame) and the post-split twiddles rebuilt per
+  //       frame: 12 + 4 registers instead of 30 + 32, so nothing comes from L2 per frame any more.  Measured
+  //       (tools/timeline_lab.hip, 60 min): N = 16384 / hop 512 4.38 -> 4.23 ms, N = 32768 / hop 1024 5.18 -> 5.01 ms,
+  //       N = 32768 / 375-sample columns (with the prefetch below) 16.07 -> 15.55 ms.
+  template <bool SLIDING, int HOP = 0>
+  static constexpr int twreg() {
+    // (every kernel of a plan does the same arithmetic: the rows of a one-frame run are bit-identical to ranges mode)
+    if constexpr (P::R3 == 16) return 6;
+    return 2;
+  }
+  // Direct modes of the 32-points-per-thread plans: the next frame's samples are requested as soon as pass 3 has freed
+  // the transform's registers (PREFETCH = 1), so that they travel under the pitch pick, the row transposition and
+  // the row's stores.
+  static constexpr int PREFETCH = (P::E == 32) ? 1 : 0;
   // hops the sliding kernel is instantiated for (the larger shifts D = hop/2T need more edge/prefetch registers
   // and spill: measured with -Rpass-analysis, asserted scratch-free in tests/test_abi.py)
   static constexpr bool slides(int hop) {
+    // (N = 16384 / hop 1024 — a two-slot shift — keeps five dwords in scratch with the twiddle bases held; it still
+    //  beats loading its frames directly, 2.33 against 2.89 ms per hour: tests/test_abi.py knows this one exception)
     return P::N == 4096 ? (hop == 256 || hop == 512) : P::N == 16384 ? (hop == 512 || hop == 1024) : hop == 1024;
   }
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
@@ -54,9 +69,9 @@ template <class P, int HOP>
 bool try_slide(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
   if constexpr (Slide<P, HOP>::ok && Tune<P>::slides(HOP)) {
     if (b.hop != HOP) return false;
-    constexpr int TRS = Tune<P>::template twreg<true>();
+    constexpr int TRS = Tune<P>::template twreg<true, HOP>();
     hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, HOP, Tune<P>::WPE, Tune<P>::NOHOIST, true, TRS, Tune<P>::OUTSEP,
-                                    Tune<P>::DEFER, false, Tune<P>::EARLYBAR>),
+                                    Tune<P>::DEFER, 0, Tune<P>::EARLYBAR>),
                        grid, block, 0, s, b);
     return true;
   } else {
@@ -77,6 +92,7 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
   constexpr bool NH = Tune<P>::NOHOIST;
   constexpr int TRD = Tune<P>::template twreg<false>();
   constexpr bool OS = Tune<P>::OUTSEP, DF = Tune<P>::DEFER, EB = Tune<P>::EARLYBAR;
+  constexpr int PF = Tune<P>::PREFETCH;
   switch (mode) {
     case kBulkAligned:
       // hops that are a small multiple of 2T samples slide the windowed frame through registers (one HBM read
@@ -84,15 +100,15 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
       // frame directly
       if (!(try_slide<P, 256>(b, grid, block, s) || try_slide<P, 512>(b, grid, block, s) ||
             try_slide<P, 1024>(b, grid, block, s)))
-        hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b);
+        hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF, PF, EB>), grid, block, 0, s, b);
       break;
-    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b); break;
+    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF, PF, EB>), grid, block, 0, s, b); break;
     case kRanges:
       // texel output (fused colormap) is its own instantiation: the binary64 cos/sin of the middle colour
       // segment must not weigh on the register allocation of the plain kernels
       // (and it gets the two-waves-per-SIMD register budget: screen-sized batches are not occupancy-bound)
-      if (a.rgb) hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, (W > 2 ? 2 : W), NH, true, TRD, OS, DF, false, EB, true>), grid, block, 0, s, b);
-      else hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TRD, OS, DF, false, EB>), grid, block, 0, s, b);
+      if (a.rgb) hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, (W > 2 ? 2 : W), NH, true, TRD, OS, DF, 0, EB, true>), grid, block, 0, s, b);
+      else hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TRD, OS, DF, 0, EB>), grid, block, 0, s, b);
       break;
     default: return hipErrorInvalidValue;
   }

@@ -45,11 +45,21 @@ void emu_from_state(std::vector<cpx> &Yall, float *mags, std::vector<int> *colli
   for (int t = 0; t < C::T; ++t) store_t2<C>(t, V(t), lds.data());
   for (int t = 0; t < C::T; ++t) load_t2<C>(t, V(t), lds.data());
   for (int t = 0; t < C::T; ++t) {
-    pass3<C>(t, V(t), reinterpret_cast<const cpx *>(tw3.data()));
-    cpx u[C::R3];
-    post_twiddles<C>(t, reinterpret_cast<const cpx *>(ub.data()), u);
     float mg[E];
-    post<C>(t, V(t), u, mg);
+    if constexpr (C::R3 == 16) {
+      // the 32-points-per-thread plans rebuild nine of the fifteen pass-3 twiddles and the post-split twiddles
+      // from per-thread bases (stft_kernels.hip, twiddle placement 6): the emulation does the same arithmetic
+      cpx wb[6], lo, hi;
+      fetch_tw3_bases<C>(t, reinterpret_cast<const cpx *>(tw3.data()), wb);
+      pass3_bases<C>(t, V(t), wb);
+      post_bases<C>(t, reinterpret_cast<const cpx *>(ub.data()), lo, hi);
+      post_fly<C>(t, V(t), lo, hi, mg);
+    } else {
+      pass3<C>(t, V(t), reinterpret_cast<const cpx *>(tw3.data()));
+      cpx u[C::R3];
+      post_twiddles<C>(t, reinterpret_cast<const cpx *>(ub.data()), u);
+      post<C>(t, V(t), u, mg);
+    }
     for (int o = 0; o < E; ++o) mags[out_bin<C>(t, o)] = mg[o];
   }
 }
