@@ -1201,7 +1201,6 @@ int mx_resynth_dev(mx_ctx *ctx, const mx_audio *a, const mx_step *d_steps, int64
   r.nsamples = nsamples;
   r.pcm_f32 = d_pcm_f32;
   r.pcm_i16 = d_pcm_i16;
-  r.has_long_grains = 1;  // the device-resident entry point does not see the schedule: always run the (cheap, early-exit) long-grain pass
   HIP_TRY(launch_resynth(r, ctx->stream));
   return MX_OK;
 }

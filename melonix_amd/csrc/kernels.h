@@ -50,7 +50,6 @@ struct ResynthArgs {
   int64_t nsamples;    // total incl. trailing zeros
   float *pcm_f32;      // may be null
   int16_t *pcm_i16;    // may be null
-  int has_long_grains; // 1: some grain exceeds the LDS-staged kernel's capacity (fallback grains, app.cpp:198-228), or unknown
 };
 hipError_t launch_resynth(const ResynthArgs &a, hipStream_t s);
 

@@ -64,8 +64,24 @@ __global__ __launch_bounds__(kResynthThreads) void resynth_kernel_v(const Resynt
   __shared__ __attribute__((aligned(16))) float lds[kMaxGrain + 8];
   const mx_step st = a.steps[blockIdx.x];
   const int L = st.grain_len, sz = st.sz, tid = threadIdx.x;
-  if (L > kMaxGrain) return;  // handled by the scalar launch (wave-uniform: whole block exits)
   const float *g = a.audio + MX_AUDIO_PAD + st.grain_start;
+  if (L > kMaxGrain) {
+    // a fallback grain (app.cpp:198-228) beyond the LDS stage: straight from L2, the arithmetic of resynth_kernel
+    // (block-uniform branch; rare — one launch serves both kinds of steps)
+    float *of = a.pcm_f32 ? a.pcm_f32 + st.out_offset : nullptr;
+    int16_t *oi = a.pcm_i16 ? a.pcm_i16 + st.out_offset : nullptr;
+    for (int i = tid; i < sz; i += kResynthThreads) {
+      const float x = (float)i * st.rate;
+      const float ip = __builtin_truncf(x);
+      const float f = x - ip;
+      const int idx = (int)ip;
+      const float a1 = (idx + 1 < L) ? g[idx + 1] : st.next_first;
+      const float v = (1.f - f) * g[idx] + f * a1;
+      if (of) of[i] = v;
+      if (oi) oi[i] = (int16_t)((double)v * 32767.);
+    }
+    return;
+  }
   // stage [g - shift, g + L] with aligned float4 loads (the padded image makes g - 3 readable)
   const int shift = (int)((reinterpret_cast<uintptr_t>(g) >> 2) & 3);
   const float4 *ga = reinterpret_cast<const float4 *>(g - shift);
@@ -110,26 +126,6 @@ __global__ __launch_bounds__(kResynthThreads) void resynth_kernel_v(const Resynt
     const float v = lerp_tap(lg, ii, rate);
     if (of) of[ii] = v;
     if (oi) oi[ii] = (int16_t)((double)v * 32767.);
-  }
-}
-
-// scalar kernel restricted to the steps the vector kernel skips (grains longer than kMaxGrain)
-__global__ __launch_bounds__(kResynthThreads) void resynth_kernel_long(const ResynthArgs a) {
-  const mx_step st = a.steps[blockIdx.x];
-  if (st.grain_len <= kMaxGrain) return;
-  const float *g = a.audio + MX_AUDIO_PAD + st.grain_start;
-  const int L = st.grain_len;
-  float *of = a.pcm_f32 ? a.pcm_f32 + st.out_offset : nullptr;
-  int16_t *oi = a.pcm_i16 ? a.pcm_i16 + st.out_offset : nullptr;
-  for (int i = threadIdx.x; i < st.sz; i += kResynthThreads) {
-    const float x = (float)i * st.rate;
-    const float ip = __builtin_truncf(x);
-    const float f = x - ip;
-    const int idx = (int)ip;
-    const float a1 = (idx + 1 < L) ? g[idx + 1] : st.next_first;
-    const float v = (1.f - f) * g[idx] + f * a1;
-    if (of) of[i] = v;
-    if (oi) oi[i] = (int16_t)((double)v * 32767.);
   }
 }
 
@@ -214,7 +210,6 @@ hipError_t launch_resynth(const ResynthArgs &a, hipStream_t s) {
                            reinterpret_cast<uintptr_t>(a.audio)) & 15) == 0;
     if (aligned) {
       hipLaunchKernelGGL(resynth_kernel_v, dim3((unsigned)a.nsteps), dim3(kResynthThreads), 0, s, a);
-      if (a.has_long_grains) hipLaunchKernelGGL(resynth_kernel_long, dim3((unsigned)a.nsteps), dim3(kResynthThreads), 0, s, a);
     } else {
       hipLaunchKernelGGL(resynth_kernel, dim3((unsigned)a.nsteps), dim3(kResynthThreads), 0, s, a);
     }

@@ -17,6 +17,7 @@
 // around its loop; the host prints mean cycles per instruction per wave for each role.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -351,6 +352,49 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&d_out, sizeof(float) * 256 * 8 * 1024));
   CK(hipMalloc(&d_g, sizeof(f4) * 1024 * 256 * 8 * 16));
   const int IT = 4000;
+  if (argc > 3 && !strcmp(argv[1], "power")) {
+    // one stream at full occupancy (4 waves per SIMD) for argv[3] seconds, so that the package power can be sampled
+    // next to it (tools/energy_lab.sh): energy per operation = (power - idle power) / rate
+    const double secs = atof(argv[3]);
+    const std::string k = argv[2];
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const auto t0 = std::chrono::steady_clock::now();
+    double ms_sum = 0;
+    long launches = 0;
+    const int wpb = 4, bpc = 4, blocks = 256 * bpc, it = 20000;
+    const size_t lds = (160 * 1024 / bpc) & ~(size_t)255;
+    auto go = [&](auto kern) {
+      CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, 0, d_rec, d_out, d_g, it, it, 4);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms_sum += ms;
+        launches += 10;
+      }
+    };
+    int kv = 0, km = 0, bytes = 0;
+    if (k == "fma") { go(bench<K_FMA_INDEP, K_FMA_INDEP>); kv = 16; }
+    else if (k == "pkfma") { go(bench<K_PKFMA_INDEP, K_PKFMA_INDEP>); kv = 16; }
+    else if (k == "ldsw64") { go(bench<K_LDSW64, K_LDSW64>); km = 16; bytes = 512; }
+    else if (k == "ldsr64") { go(bench<K_LDSR64, K_LDSR64>); km = 16; bytes = 512; }
+    else if (k == "ldsw32") { go(bench<K_LDSW32, K_LDSW32>); km = 16; bytes = 256; }
+    else if (k == "ldsr128") { go(bench<K_LDSR128, K_LDSR128>); km = 16; bytes = 1024; }
+    else if (k == "gstore") { go(bench<K_GSTORE, K_GSTORE>); km = 4; bytes = 1024; }
+    else if (k == "idle") { go(bench<K_IDLE, K_IDLE>); }
+    else { printf("unknown kind\n"); return 2; }
+    const double s_total = ms_sum * 1e-3;
+    const double waves = (double)blocks * wpb * launches;
+    printf("ENERGY %-8s %.3f s busy: %.4g wave-instructions/s", k.c_str(), s_total, waves * it * (kv + km) / s_total);
+    if (bytes) printf(", %.4g GB/s", waves * it * km * bytes / s_total / 1e9);
+    printf("\n");
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "nop")) {
     printf("== what an s_nop / SALU instruction between VALU instructions costs a wave ==\n");
     for (int bpc : {1, 3}) {
