@@ -454,10 +454,12 @@ __device__ __forceinline__ void static_for(F &&f) {
 template <class P>
 MX_HD void store_t1(int t, const cpx (&v)[P::E], cpx *lds) {
   // swz1((t + T*b)*R1 + r) = (((t*R1) ^ (t & 15)) ^ r) + b*T*R1   (T is a multiple of 16)
-  const int B = (t * P::R1) ^ (t & 15);
+  // (in bytes, so that each of the R1 scatter addresses is ONE xor with a constant — the shift by 3 is done once)
+  const unsigned B8 = (unsigned)((t * P::R1) ^ (t & 15)) << 3;
+  char *const base = reinterpret_cast<char *>(lds);
 #pragma unroll
   for (int r = 0; r < P::R1; ++r) {
-    cpx *p = lds + (B ^ r);
+    cpx *p = reinterpret_cast<cpx *>(base + (B8 ^ ((unsigned)r << 3)));
 #pragma unroll
     for (int b = 0; b < P::NB1; ++b) p[b * P::T * P::R1] = v[b * P::R1 + r];
   }

@@ -40,7 +40,12 @@ __device__ __forceinline__ unsigned wave_reduce_u32(unsigned k) {
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
   const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
   const unsigned mhi = wave_reduce_u32<true>(hi);
-  const unsigned mlo = wave_reduce_u32<true>(hi == mhi ? lo : 0u);
+  // the low word of the lane(s) that hold the maximum: almost always ONE lane — read it directly; ties (silence,
+  // equal magnitudes in two lanes) take the second reduction
+  const unsigned long long tie = __ballot(hi == mhi);
+  unsigned mlo;
+  if (__builtin_popcountll(tie) == 1) mlo = (unsigned)__builtin_amdgcn_readlane((int)lo, __builtin_ctzll(tie));
+  else mlo = wave_reduce_u32<true>(hi == mhi ? lo : 0u);
   return ((unsigned long long)mhi << 32) | mlo;
 }
 
