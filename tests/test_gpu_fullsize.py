@@ -220,3 +220,18 @@ def test_eight_shards_on_one_device_equal_unsharded_8h():
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "shard8_check ok" in r.stdout
+
+
+def test_pv_more_than_2M_frames(gpu_ctx, hour):
+    """+24 semitones over the hour is 2.7 M analysis frames: the boundary fix-up kernel used to put one block row per
+    32 frames on gridDim.y (capped at 65 535, i.e. 2.1 M frames) and the call failed after all the work was done."""
+    w = hour
+    n = len(w)
+    a = gpu_ctx.upload(w)
+    y, _ = gpu_ctx.pv_pitch_shift(a, 24.0, want_i16=False)
+    assert len(y) == n and np.isfinite(y).all()
+    # the 110..1760 Hz sweep lands two octaves up: still a tone of the input's level where it stays below Nyquist
+    seg = slice(n // 8, n // 4)
+    assert 0.5 < np.sqrt((y[seg].astype(np.float64) ** 2).mean()) / np.sqrt((w[seg].astype(np.float64) ** 2).mean()) < 1.1
+    gpu_ctx.release_scratch()
+    a.free()
