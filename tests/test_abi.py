@@ -87,9 +87,10 @@ def test_stft_kernels_do_not_spill():
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
     vgprs = [int(x) for x in re.findall(r"\bVGPRs: (\d+)", out.stderr)]
     assert len(names) == len(scratch) == len(vgprs) and len(names) >= 9
-    # one known exception: the two-slot sliding kernel of N = 16384 / hop 1024 parks five dwords (it is still the faster
-    # way to run that hop, stft_kernels.hip Tune::slides)
-    allowed = {"PlanILi16384ELi32EEELi0ELi1024E": 24}
+    # known exceptions: the two-slot sliding kernel of N = 16384 / hop 1024 parks five dwords, the sliding kernel of
+    # N = 32768 / hop 1024 two (with its row stores straight from the registers) — each is still the faster way to run
+    # its hop (stft_kernels.hip, Tune::slides / Tune::DIRECT)
+    allowed = {"PlanILi16384ELi32EEELi0ELi1024E": 24, "PlanILi32768ELi32EEELi0ELi1024E": 12}
     bad = [(n, s) for n, s in zip(names, scratch)
            if "stft_kernel" in n and s > max([v for k, v in allowed.items() if k in n] or [0])]
     assert not bad, bad

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""STFT launch time per (N, hop) on 60 min of synthetic audio: `stft_sizes.py 32768x375 16384x512 ...`
+(one line per size: N hop ms frac-of-8TB/s).  A/B helper for kernel variants; bench_extra.py is the full table."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import melonix_amd as mx  # noqa: E402
+from bench import SR, b_alg, gen_shard  # noqa: E402
+
+dev = torch.device("cuda", 0)
+sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(32768, 375), (32768, 1024), (16384, 512)]
+n = 60 * 60 * SR
+audio_t = gen_shard(torch, dev, 0, 1, n, mx.MX_AUDIO_PAD)
+ctx = mx.Context(0)
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+audio = ctx.wrap_device(audio_t.data_ptr(), n, keepalive=audio_t)
+for N, hop in sizes:
+    F = mx.frame_count(n, hop)
+    mags = torch.empty((F, N // 2), dtype=torch.float32, device=dev)
+    pitch = torch.empty((F, 2), dtype=torch.int32, device=dev)
+    band = mx.pitch_band(N, SR)
+    fn = lambda: ctx.stft_hop_dev(audio, N, hop, 0, F, mags.data_ptr(), pitch.data_ptr(), band=band)  # noqa: E731
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 5
+    print(N, hop, round(ms, 3), round(b_alg(N, hop) * F / ms / 1e6 / 8000, 3), flush=True)
+    del mags, pitch
+    torch.cuda.empty_cache()
