@@ -73,16 +73,6 @@ MX_HD constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
 
 }  // namespace mx
 #include "pk_math.h"
-
-// A scheduling fence: nothing is moved across it by the instruction scheduler.  The four-waves-per-SIMD kernels
-// (128 registers per thread for 32 complex points) use it to keep derive-a-twiddle / use-it / drop-it sequences
-// together, which the scheduler otherwise spreads out until the frame spills.  Arithmetic is unaffected.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define MX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define MX_SCHED_FENCE() ((void)0)
-#endif
-
 namespace mx {
 
 // a * exp(-2*pi*i*K/64), K a compile-time constant.
@@ -225,6 +215,18 @@ MX_HD int swz2(int i) {
 struct alignas(4) f2u {  // 4-byte aligned pair for frames starting at odd samples
   float x, y;
 };
+// The pair of floats at element index i (a 32-bit, non-negative offset) from base: with a wave-uniform base the load
+// takes the SGPR-base + 32-bit-VGPR-offset form — one address add per load instead of a 64-bit sign-extend/shift/add.
+template <bool ALIGNED8>
+MX_HD cpx ld_pair(const float *base, int i) {
+  const char *a = reinterpret_cast<const char *>(base) + (size_t)(4u * (unsigned)i);
+  if constexpr (ALIGNED8) {
+    return *reinterpret_cast<const cpx *>(a);
+  } else {
+    const f2u u = *reinterpret_cast<const f2u *>(a);
+    return mk(u.x, u.y);
+  }
+}
 
 template <class P, int WSTEP, bool ALIGNED8>
 MX_HD void load_frame(int t, cpx (&Y)[P::E], const float *x, const float *w) {
@@ -233,14 +235,12 @@ MX_HD void load_frame(int t, cpx (&Y)[P::E], const float *x, const float *w) {
     const int p = 2 * (t + P::T * e);
     cpx xs, ws;
     if constexpr (ALIGNED8 && WSTEP == 1) {
-      xs = *reinterpret_cast<const cpx *>(x + p);
-      ws = *reinterpret_cast<const cpx *>(w + p);
+      xs = ld_pair<true>(x, p);
+      ws = ld_pair<true>(w, p);
     } else {
-      const f2u xu = *reinterpret_cast<const f2u *>(x + p);
-      xs = mk(xu.x, xu.y);
+      xs = ld_pair<false>(x, p);
       if constexpr (WSTEP == 1) {
-        const f2u wu = *reinterpret_cast<const f2u *>(w + p);
-        ws = mk(wu.x, wu.y);
+        ws = ld_pair<false>(w, p);
       } else {
         const f2u wu = *reinterpret_cast<const f2u *>(w - p - 1);
         ws = mk(wu.y, wu.x);
@@ -262,39 +262,59 @@ template <int T>
 MX_HD constexpr float win_grow(int e) {
   return T == 64 ? kWinGrow64[e] : T == 128 ? kWinGrow128[e] : T == 256 ? kWinGrow256[e] : kWinGrow512[e];
 }
-// the geometric weights of slot e from the thread's seed pair a0 (clamped at the flat top)
-template <class P>
+// the geometric weights of slot e from the thread's seed pair a0, clamped at the flat top.  The clamp only ever binds
+// inside the flat top (the newest `hop` samples: one sample before it the weight is already sc*(1 - 2.5e-4), a
+// thousand ulps below sc), i.e. in the last ceil(hop / 2T) slots: CLAMP = false leaves it out for the slots in front
+// of those — the same values with two instructions less per slot.  Positive floats order like their bit patterns, so
+// the clamp itself is an integer minimum (no NaN canonicalisation in front of it).
+template <class P, bool CLAMP = true>
 MX_HD cpx geo_weight(cpx a0, int e) {
   constexpr float sc = 0.5f / (float)P::N;
   const float g = e == 0 ? 1.0f : win_grow<P::T>(e);
-  const cpx w = e == 0 ? a0 : pk_mul_xs(a0, mk(g, g));
-  return mk(w.x < sc ? w.x : sc, w.y < sc ? w.y : sc);
+  // two literal-operand multiplies rather than one packed multiply by an SGPR pair: the 31 growth factors would
+  // otherwise occupy 62 scalar registers for the whole frame loop and push the twiddle constants into VGPR lanes
+  // (53 SGPR spills, ~100 v_readlane / v_writelane per frame in the 32-points-per-thread kernels)
+  const cpx w = e == 0 ? a0 : mk(a0.x * g, a0.y * g);
+  if constexpr (!CLAMP) {
+    return w;
+  } else {
+    const unsigned sb = __builtin_bit_cast(unsigned, sc), xb = __builtin_bit_cast(unsigned, w.x), yb = __builtin_bit_cast(unsigned, w.y);
+    return mk(__builtin_bit_cast(float, xb < sb ? xb : sb), __builtin_bit_cast(float, yb < sb ? yb : sb));
+  }
 }
+// number of trailing slots whose weights can reach the flat top
+template <class P>
+MX_HD int geo_clamped_slots(int hop) { return (hop + 2 * P::T - 1) / (2 * P::T); }
+constexpr int kGeoTail = 2;  // slots the fast path still clamps (hop <= 2 * 2T)
 template <class P, bool ALIGNED8>
-MX_HD void load_frame_geo(int t, cpx (&Y)[P::E], const float *x, const float *wb) {
+MX_HD void load_frame_geo(int t, cpx (&Y)[P::E], const float *x, const float *wb, int hop) {
   static_assert(P::T == 64 || P::T == 128 || P::T == 256 || P::T == 512, "growth table per T");
   static_assert(P::E <= 32, "growth table length");
-  const cpx a0 = *reinterpret_cast<const cpx *>(wb + 2 * t);
+  const cpx a0 = ld_pair<true>(wb, 2 * t);
+  if (geo_clamped_slots<P>(hop) <= kGeoTail) {  // wave-uniform
 #pragma unroll
-  for (int e = 0; e < P::E; ++e) {
-    const int p = 2 * (t + P::T * e);
-    cpx xs;
-    if constexpr (ALIGNED8) {
-      xs = *reinterpret_cast<const cpx *>(x + p);
-    } else {
-      const f2u xu = *reinterpret_cast<const f2u *>(x + p);
-      xs = mk(xu.x, xu.y);
+    for (int e = 0; e < P::E; ++e) {
+      const cpx xs = ld_pair<ALIGNED8>(x, 2 * (t + P::T * e));
+      Y[e] = pk_mul(xs, e < P::E - kGeoTail ? geo_weight<P, false>(a0, e) : geo_weight<P, true>(a0, e));
     }
-    Y[e] = pk_mul(xs, geo_weight<P>(a0, e));
+  } else {
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) Y[e] = pk_mul(ld_pair<ALIGNED8>(x, 2 * (t + P::T * e)), geo_weight<P, true>(a0, e));
   }
 }
 
 // The same weights applied to samples fetched earlier (load_raw, the prefetching schedule).
 template <class P>
-MX_HD void apply_window_geo(int t, cpx (&Y)[P::E], const cpx (&xr)[P::E], const float *wb) {
-  const cpx a0 = *reinterpret_cast<const cpx *>(wb + 2 * t);
+MX_HD void apply_window_geo(int t, cpx (&Y)[P::E], const cpx (&xr)[P::E], const float *wb, int hop) {
+  const cpx a0 = ld_pair<true>(wb, 2 * t);
+  if (geo_clamped_slots<P>(hop) <= kGeoTail) {  // wave-uniform
 #pragma unroll
-  for (int e = 0; e < P::E; ++e) Y[e] = pk_mul(xr[e], geo_weight<P>(a0, e));
+    for (int e = 0; e < P::E; ++e)
+      Y[e] = pk_mul(xr[e], e < P::E - kGeoTail ? geo_weight<P, false>(a0, e) : geo_weight<P, true>(a0, e));
+  } else {
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) Y[e] = pk_mul(xr[e], geo_weight<P, true>(a0, e));
+  }
 }
 
 // Direct modes, split in two so that the raw samples of the NEXT frame can be in flight while the
@@ -304,13 +324,7 @@ template <class P, bool ALIGNED8>
 MX_HD void load_raw(int t, cpx (&xr)[P::E], const float *x) {
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
-    const int p = 2 * (t + P::T * e);
-    if constexpr (ALIGNED8) {
-      xr[e] = *reinterpret_cast<const cpx *>(x + p);
-    } else {
-      const f2u xs = *reinterpret_cast<const f2u *>(x + p);
-      xr[e] = mk(xs.x, xs.y);
-    }
+    xr[e] = ld_pair<ALIGNED8>(x, 2 * (t + P::T * e));
   }
 }
 // slots [E0, E1) only (a prefetch issued in two halves keeps fewer registers in flight at a time)
@@ -318,13 +332,7 @@ template <class P, bool ALIGNED8, int E0, int E1>
 MX_HD void load_raw_part(int t, cpx (&xr)[P::E], const float *x) {
 #pragma unroll
   for (int e = E0; e < E1; ++e) {
-    const int p = 2 * (t + P::T * e);
-    if constexpr (ALIGNED8) {
-      xr[e] = *reinterpret_cast<const cpx *>(x + p);
-    } else {
-      const f2u xs = *reinterpret_cast<const f2u *>(x + p);
-      xr[e] = mk(xs.x, xs.y);
-    }
+    xr[e] = ld_pair<ALIGNED8>(x, 2 * (t + P::T * e));
   }
 }
 template <class P, int WSTEP, bool ALIGNED8>
@@ -333,11 +341,8 @@ MX_HD void apply_window(int t, cpx (&Y)[P::E], const cpx (&xr)[P::E], const floa
   for (int e = 0; e < P::E; ++e) {
     const int p = 2 * (t + P::T * e);
     cpx ws;
-    if constexpr (ALIGNED8 && WSTEP == 1) {
-      ws = *reinterpret_cast<const cpx *>(w + p);
-    } else if constexpr (WSTEP == 1) {
-      const f2u wu = *reinterpret_cast<const f2u *>(w + p);
-      ws = mk(wu.x, wu.y);
+    if constexpr (WSTEP == 1) {
+      ws = ld_pair<ALIGNED8>(w, p);
     } else {
       const f2u wu = *reinterpret_cast<const f2u *>(w - p - 1);
       ws = mk(wu.y, wu.x);
@@ -440,24 +445,6 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 }
 template <int N>
 __device__ __forceinline__ void lds_wait(mx_f2v (&q)[N]) {
-  static_assert(N % 8 == 0, "tied in groups of 8");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int i = 0; i < N; i += 8)
-    asm volatile("" : "+v"(q[i]), "+v"(q[i + 1]), "+v"(q[i + 2]), "+v"(q[i + 3]), "+v"(q[i + 4]),
-                 "+v"(q[i + 5]), "+v"(q[i + 6]), "+v"(q[i + 7]));
-}
-// 4-byte reads of the split exchanges, kept single on purpose: a merged ds_read2_b32 returns two values of DIFFERENT
-// complex points in one register pair, and re-pairing them with their other components costs a move per value.
-template <int OFF>
-__device__ __forceinline__ float lds_rd32(uint32_t addr) {
-  static_assert(OFF >= 0 && OFF < 65536, "the ds offset field is 16 bits");
-  float r;
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
-  return r;
-}
-template <int N>
-__device__ __forceinline__ void lds_wait(float (&q)[N]) {
   static_assert(N % 8 == 0, "tied in groups of 8");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -653,90 +640,6 @@ MX_HD void store_t2(int t, const cpx (&v)[P::E], cpx *lds) {
   }
 }
 
-// ---- split transpositions (one component at a time through a 4-byte image) ---------------
-// The 32-points-per-thread plans at four waves per SIMD: the image holds M floats instead of M complex points, so
-// that TWO workgroups fit a CU's LDS and one computes while the other waits at a barrier.  Each transposition moves
-// the real parts, then the imaginary parts, through the same M*4 bytes (write, barrier, read, barrier, twice);
-// the values and their arithmetic are exactly those of the 8-byte path.  Float-granular swizzle of T1 (R1 = 32):
-// swz1f(i) = i ^ ((i >> 5) & 31) — the 32 lanes of an LDS lane group write 32 distinct banks, the contiguous reads
-// stay permutations of aligned 32-float blocks.
-template <class P>
-MX_HD int swz1f(int i) { return i ^ ((i >> 5) & 31); }
-template <class P, int C>
-MX_HD void store_t1_c(int t, const cpx (&v)[P::E], float *img) {
-  static_assert(P::R1 == 32 && P::NB1 == 1, "split exchange: one radix-32 pass-1 butterfly per thread");
-  // swz1f(t*32 + r) = (t*32 + r) ^ (t & 31); in bytes, one xor per store
-  const unsigned B4 = (unsigned)((t * 32) ^ (t & 31)) << 2;
-  char *const base = reinterpret_cast<char *>(img);
-#pragma unroll
-  for (int r = 0; r < P::R1; ++r) *reinterpret_cast<float *>(base + (B4 ^ ((unsigned)r << 2))) = C ? v[r].y : v[r].x;
-}
-template <class P, int C>
-MX_HD void load_t1_c(int t, cpx (&v)[P::E], const float *img) {
-  // swz1f(j + r*S) = ((j ^ (j >> 5)) ^ ((r & 1) << 4)) + r*S for j < 512 and S = 512
-  constexpr int S = P::M / P::R2;
-  static_assert(S == 512 && P::T * P::NB2 <= 512, "T1 read is base(+alt base) + offset");
-#ifdef MX_LDS_ASM
-  float q[P::E];
-  static_for<0, P::NB2>([&](auto bb) {
-    constexpr int b = decltype(bb)::value;
-    const int j = t + P::T * b;
-    const uint32_t ae = lds_addr(img + (j ^ (j >> 5))), ao = lds_addr(img + ((j ^ (j >> 5)) ^ 16));
-    static_for<0, P::R2>([&](auto rr) {
-      constexpr int r = decltype(rr)::value;
-      q[b * P::R2 + r] = lds_rd32<r * S * 4>((r & 1) ? ao : ae);
-    });
-  });
-  lds_wait(q);
-#pragma unroll
-  for (int i = 0; i < P::E; ++i) (C ? v[i].y : v[i].x) = q[i];
-#else
-#pragma unroll
-  for (int b = 0; b < P::NB2; ++b) {
-    const int j = t + P::T * b;
-    const float *pe = img + (j ^ (j >> 5)), *po = img + ((j ^ (j >> 5)) ^ 16);
-#pragma unroll
-    for (int r = 0; r < P::R2; ++r) (C ? v[b * P::R2 + r].y : v[b * P::R2 + r].x) = ((r & 1) ? po : pe)[r * S];
-  }
-#endif
-}
-template <class P, int C>
-MX_HD void store_t2_c(int t, const cpx (&v)[P::E], float *img) {
-  static_assert(P::R1 == 32, "split exchange: R1 = 32 (no T2 swizzle)");
-#pragma unroll
-  for (int b = 0; b < P::NB2; ++b) {
-    const int j = t + P::T * b;
-    const int k = j & (P::R1 - 1);
-    float *p = img + ((j - k) * P::R2 + k);
-#pragma unroll
-    for (int r = 0; r < P::R2; ++r) p[r * P::R1] = C ? v[b * P::R2 + r].y : v[b * P::R2 + r].x;
-  }
-}
-template <class P> MX_HD int k0p(int t);
-template <class P> MX_HD int k0q(int t);
-template <class P, int C>
-MX_HD void load_t2_c(int t, cpx (&v)[P::E], const float *img) {
-#ifdef MX_LDS_ASM
-  const uint32_t pa = lds_addr(img + k0p<P>(t)), qa = lds_addr(img + k0q<P>(t));
-  float q[P::E];
-  static_for<0, P::R3>([&](auto rr) {
-    constexpr int r = decltype(rr)::value;
-    q[r] = lds_rd32<P::NS3 * r * 4>(pa);
-    q[P::R3 + r] = lds_rd32<P::NS3 * r * 4>(qa);
-  });
-  lds_wait(q);
-#pragma unroll
-  for (int i = 0; i < P::E; ++i) (C ? v[i].y : v[i].x) = q[i];
-#else
-  const float *pp = img + k0p<P>(t), *qq = img + k0q<P>(t);
-#pragma unroll
-  for (int r = 0; r < P::R3; ++r) {
-    (C ? v[r].y : v[r].x) = pp[P::NS3 * r];
-    (C ? v[P::R3 + r].y : v[P::R3 + r].x) = qq[P::NS3 * r];
-  }
-#endif
-}
-
 // Butterfly indices of pass 3: P-butterfly = k0p(t), Q-butterfly = k0q(t); {P,Q} = {t, NS3-t},
 // thread 0 takes the two self-paired ones {0, NS3/2}.
 template <class P>
@@ -875,60 +778,6 @@ MX_HD void pass3_reg(int t, cpx (&v)[P::E], const cpx (&w)[P::R3 - 1]) {
   for (int r = 0; r < R; ++r) v[R + r] = out[r];
 }
 
-// The same pass with the P and Q butterflies walked in lockstep and every twiddle derived from the six bases right
-// where its leaf uses it (same products, same leaves, same combines as pass3_bases + pass3_reg — only the order of
-// independent operations differs): at most two derived twiddles are alive at a time instead of fifteen.
-template <int r>
-MX_HD cpx tw3_from_bases(const cpx (&wb)[6]) {
-  constexpr int hi = r >> 2, lo = r & 3;
-  if constexpr (hi == 0) return wb[lo - 1];
-  else if constexpr (lo == 0) return wb[2 + hi];
-  else return pk_cmul2(wb[2 + hi], wb[lo - 1]);
-}
-template <int R, int S, int O0, bool MAY0>
-struct DftTw2 {
-  static MX_HD void run(const cpx *vp, const cpx *vq, const cpx (&wb)[6], bool t0, cpx *outp, cpx *outq) {
-    if constexpr (R == 2) {
-      constexpr int i0 = O0, i1 = O0 + S;
-      const cpx one = mk(1.0f, 0.0f);
-      const cpx w1 = tw3_from_bases<i1>(wb);
-      if constexpr (i0 == 0) {
-        pk_leaf0_tw<false>(vp[0], vp[i1], MAY0 ? csel(t0, one, w1) : w1, outp[0], outp[1]);
-        pk_leaf0_tw<true>(vq[0], vq[i1], w1, outq[0], outq[1]);
-      } else {
-        const cpx w0 = tw3_from_bases<i0>(wb);
-        pk_leaf_tw<false>(vp[i0], MAY0 ? csel(t0, one, w0) : w0, vp[i1], MAY0 ? csel(t0, one, w1) : w1, outp[0], outp[1]);
-        pk_leaf_tw<true>(vq[i0], w0, vq[i1], w1, outq[0], outq[1]);
-      }
-      MX_SCHED_FENCE();
-    } else {
-      cpx Ep[R / 2], Op[R / 2], Eq[R / 2], Oq[R / 2];
-      DftTw2<R / 2, 2 * S, O0, MAY0>::run(vp, vq, wb, t0, Ep, Eq);
-      DftTw2<R / 2, 2 * S, O0 + S, MAY0>::run(vp, vq, wb, t0, Op, Oq);
-      Combine<R, 0>::run(Ep, Op, outp);
-      Combine<R, 0>::run(Eq, Oq, outq);
-      MX_SCHED_FENCE();
-    }
-  }
-};
-template <class P, bool MAY0 = true>
-MX_HD void pass3_lean(int t, cpx (&v)[P::E], const cpx (&wb)[6]) {
-  constexpr int R = P::R3;
-  static_assert(R == 16, "two-level pass-3 twiddles are written for radix 16");
-  cpx inp[R], inq[R], outp[R], outq[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    inp[r] = v[r];
-    inq[r] = v[R + r];
-  }
-  DftTw2<R, 1, 0, MAY0>::run(inp, inq, wb, MAY0 && (t == 0), outp, outq);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    v[r] = outp[r];
-    v[R + r] = outq[r];
-  }
-}
-
 // ---- real-FFT split + magnitude ---------------------------------------------
 // After pass 3: v[r] = Z[k0p + NS3*r], v[q_index(r)] = Z[k0q + NS3*r] (natural order).
 // Slot s pairs A = Z[k_s] with B = conj(Z[M-k_s]):
@@ -941,32 +790,28 @@ MX_HD void pass3_lean(int t, cpx (&v)[P::E], const cpx (&wb)[6]) {
 // and — instead of the Nyquist bin, which the reference does not emit — bin M/2 = |Z[M/2]|.
 // u[s] = i*w_k for the slot's bin (per-thread constants, see post_twiddles()).
 template <class P, int S>
-MX_HD void post_slot(bool t0, const cpx (&v)[P::E], cpx uS, float (&mg)[P::E]) {
-  constexpr int R = P::R3, H = R / 2;
-  cpx A, B;
-  if constexpr (S < H) {
-    A = csel(t0, v[q_index<P>(S)], v[S]);
-    B = v[q_index<P>(R - 1 - S)];
-  } else {
-    A = csel(t0, v[S - H], v[S]);
-    B = csel(t0, v[(3 * H - S) & (R - 1)], v[q_index<P>(R - 1 - S)]);
-  }
-  // lo = Sm - D, hi = Sm + D with Sm = A + conj(B), D = u*(A - conj(B)); the two squared magnitudes are
-  // formed side by side: px = (lo.x, hi.x), py = (lo.y, hi.y), n2 = px*px + py*py
-  const cpx n2 = pk_split_norm2(A, B, uS);
-  mg[2 * S] = fast_sqrt(n2.x);
-  mg[2 * S + 1] = fast_sqrt(n2.y);
-  if constexpr (S == H) {  // thread 0: bin M/2 instead of the Nyquist bin; |X[M/2]| = |Z[M/2]|
-    const cpx z = v[H];
-    const float m = fast_sqrt(cnorm2(z)) * 2.0f;
-    mg[2 * S + 1] = t0 ? m : mg[2 * S + 1];
-  }
-}
-template <class P, int S>
 struct PostSlot {
   static MX_HD void run(bool t0, const cpx (&v)[P::E], const cpx (&u)[P::R3], float (&mg)[P::E]) {
-    post_slot<P, S>(t0, v, u[S], mg);
-    if constexpr (S + 1 < P::R3) PostSlot<P, S + 1>::run(t0, v, u, mg);
+    constexpr int R = P::R3, H = R / 2;
+    cpx A, B;
+    if constexpr (S < H) {
+      A = csel(t0, v[q_index<P>(S)], v[S]);
+      B = v[q_index<P>(R - 1 - S)];
+    } else {
+      A = csel(t0, v[S - H], v[S]);
+      B = csel(t0, v[(3 * H - S) & (R - 1)], v[q_index<P>(R - 1 - S)]);
+    }
+    // lo = Sm - D, hi = Sm + D with Sm = A + conj(B), D = u*(A - conj(B)); the two squared magnitudes are
+    // formed side by side: px = (lo.x, hi.x), py = (lo.y, hi.y), n2 = px*px + py*py
+    const cpx n2 = pk_split_norm2(A, B, u[S]);
+    mg[2 * S] = fast_sqrt(n2.x);
+    mg[2 * S + 1] = fast_sqrt(n2.y);
+    if constexpr (S == H) {  // thread 0: bin M/2 instead of the Nyquist bin; |X[M/2]| = |Z[M/2]|
+      const cpx z = v[H];
+      const float m = fast_sqrt(cnorm2(z)) * 2.0f;
+      mg[2 * S + 1] = t0 ? m : mg[2 * S + 1];
+    }
+    if constexpr (S + 1 < R) PostSlot<P, S + 1>::run(t0, v, u, mg);
   }
 };
 
@@ -1005,26 +850,6 @@ MX_HD void post_fly(int t, const cpx (&v)[P::E], cpx lo, cpx hi, float (&mg)[P::
   cpx u[P::R3];
   PostFly<P, 0>::run(lo, MAY0 ? hi : lo, u);
   PostSlot<P, 0>::run(MAY0 && t == 0, v, u, mg);
-}
-
-// ... and slot by slot: the slot's twiddle is rebuilt, used and dropped (post_fly builds all R3 first)
-template <class P, int S, bool MAY0>
-struct PostLean {
-  static MX_HD void run(bool t0, const cpx (&v)[P::E], cpx lo, cpx hi, float (&mg)[P::E]) {
-    constexpr int k = ((32 / P::R3) * S) % 64;
-    const cpx b = S < P::R3 / 2 ? lo : (MAY0 ? hi : lo);
-    cpx uS;
-    if constexpr (k == 0) uS = b;
-    else if constexpr (k == 16) uS = mk(b.y, -b.x);
-    else uS = pk_rot_cs(b, mk(kCos64[k], kSin64[k]));
-    post_slot<P, S>(t0, v, uS, mg);
-    if constexpr (S % 2 == 1) MX_SCHED_FENCE();
-    if constexpr (S + 1 < P::R3) PostLean<P, S + 1, MAY0>::run(t0, v, lo, hi, mg);
-  }
-};
-template <class P, bool MAY0 = true>
-MX_HD void post_lean(int t, const cpx (&v)[P::E], cpx lo, cpx hi, float (&mg)[P::E]) {
-  PostLean<P, 0, MAY0>::run(MAY0 && t == 0, v, lo, hi, mg);
 }
 
 // The same split with the complex bins kept (phase-vocoder analysis, pv_kernels.hip):

@@ -53,7 +53,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 // NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
 // and window loads are not hoisted out of the frame loop into hundreds of registers.
 template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, int TWREG = 0, bool OUTSEP = false,
-          bool DEFER = false, int PREFETCH = 0, bool EARLYBAR = false, bool CMAP = false, bool DIRECT = false, bool SPLIT = false>
+          bool DEFER = false, int PREFETCH = 0, bool EARLYBAR = false, bool CMAP = false, bool DIRECT = false>
 __global__ __launch_bounds__(P::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void stft_kernel(const StftArgs a0) {
   const StftArgs &a = a0;
@@ -76,12 +76,9 @@ void stft_kernel(const StftArgs a0) {
   // registers they occupied hold samples in flight.
   // TWREG == 5: placement 2 + post_fly;  TWREG == 6: pass-2 table in LDS, six pass-3 base powers in registers (the rest
   // rebuilt per frame), post_fly — the 32-points-per-thread plans with a sliding frame image
-  // TWREG == 7: as 6, but the six pass-3 bases and the post-split base are fetched from L2 every frame (7 loads per
-  // thread) instead of living in 16 registers: the four-waves-per-SIMD kernels
-  constexpr bool kTw3Bases = (TWREG == 6 || TWREG == 7);
-  constexpr bool kTwFrame = (TWREG == 7);
+  constexpr bool kTw3Bases = (TWREG == 6);
   constexpr bool kPostFly = kTwoLevel || (PREFETCH == 2) || (TWREG == 5) || kTw3Bases;
-  constexpr int kTw2 = (TWREG == 2 || TWREG == 3 || TWREG == 5 || TWREG == 6 || TWREG == 7) ? ((C::TW2 + 1) / 2) * 2 : 0;
+  constexpr int kTw2 = (TWREG == 2 || TWREG == 3 || TWREG == 5 || TWREG == 6) ? ((C::TW2 + 1) / 2) * 2 : 0;
   // EARLYBAR (needs DEFER): the barrier that frees the image for the next frame sits right after
   // the T2 read instead of in front of the next T1 scatter, so that scatter can be issued while
   // pass 1 is still computing (same number of barriers per frame).
@@ -91,21 +88,15 @@ void stft_kernel(const StftArgs a0) {
   // transposed through LDS into 16-byte stores: no LDS round trip and no barrier in the output path, and the pitch
   // record of frame f is written after frame f+1's first barrier.
   static_assert(!DIRECT || (NW > 1 && !DEFER && !OUTSEP && !CMAP), "direct row stores: multi-wave, non-deferred plans");
-  // SPLIT: the transpositions move one component at a time through an image of M floats (stft_core.h), so that two
-  // workgroups share a CU's LDS — at half the registers per thread (WPE = 4), with direct row stores and no prefetch
-  static_assert(!SPLIT || (DIRECT && !PREFETCH && HOP == 0 && kTw3Bases), "split exchange: direct loads and stores");
-  constexpr int kImg = SPLIT ? C::M / 2 : C::M;  // image size in 8-byte units
-  __shared__ __attribute__((aligned(16))) float2 lds[kImg + kRed + (OUTSEP ? C::M / 2 : 0) + kTw2];
-  float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + kImg + kRed : lds);
-  float2 *const ltw2 = lds + kImg + kRed + (OUTSEP ? C::M / 2 : 0);
-  float *const limg = reinterpret_cast<float *>(lds);
+  __shared__ __attribute__((aligned(16))) float2 lds[C::M + kRed + (OUTSEP ? C::M / 2 : 0) + kTw2];
+  float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + C::M + kRed : lds);
+  float2 *const ltw2 = lds + C::M + kRed + (OUTSEP ? C::M / 2 : 0);
 
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;  // wave-uniform
   cpx u[kPostFly ? 1 : P::R3];  // post-split twiddles: E registers that replace R3 complex multiplies per frame
   cpx ulo, uhi;
-  if constexpr (kTwFrame) {
-  } else if constexpr (kPostFly) {
+  if constexpr (kPostFly) {
     post_bases<P>(t_, a.ubase, ulo, uhi);
   } else {
     post_twiddles<P>(t_, a.ubase, *reinterpret_cast<cpx(*)[P::R3]>(&u));
@@ -126,7 +117,7 @@ void stft_kernel(const StftArgs a0) {
   if constexpr (kTwoLevel) fetch_tw2_bases<P>(t_, a.tw2, w2base);
   if constexpr (TWREG == 1) fetch_tw2<P>(t_, a.tw2, w2r);
   if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) fetch_tw3<P>(t_, a.tw3, w3r);
-  if constexpr (kTw2 > 0) {
+  if constexpr (TWREG == 2 || TWREG == 3 || TWREG == 5 || TWREG == 6) {
     for (int i = t_; i < C::TW2; i += C::T) ltw2[i] = a.tw2[i];
     MX_BARRIER();
   }
@@ -155,7 +146,7 @@ void stft_kernel(const StftArgs a0) {
   // during frame f+1 — scatter at the end of f, LDS read + global stores after f+1's T1 barrier —
   // so no barrier and no LDS round trip sits in the output path.
   static_assert(!DEFER || OUTSEP, "deferred output needs its own LDS region");
-  unsigned long long *const red = reinterpret_cast<unsigned long long *>(lds + kImg);
+  unsigned long long *const red = reinterpret_cast<unsigned long long *>(lds + C::M);
   auto flush_pitch = [&](int64_t fr, int tt) {  // after a barrier that follows red[] of frame fr
     if (a.pitch && tt == 0) {
       unsigned long long b = red[0];
@@ -228,11 +219,6 @@ void stft_kernel(const StftArgs a0) {
     }
   }
 
-  // WAVESPLIT: the first wavefront (it holds thread 0, whose two butterflies are the self-paired ones) and the other
-  // wavefronts get their own copy of the frame loop, so that the register allocation of the common case is not shaped
-  // by the selects of the special one.  (Same barriers in the same order in both copies.)
-  auto frame_loop = [&](auto w0tag) {
-  constexpr int kW0 = decltype(w0tag)::value;  // 1: this wavefront holds thread 0, 0: it does not, -1: decided per frame
   for (int64_t f = f0; f < f1; ++f) {
     // Everything below that depends only on the thread index is frame-invariant; left alone,
     // LICM hoists ~150 addresses, masks and table values out of the frame loop and the kernel
@@ -260,11 +246,11 @@ void stft_kernel(const StftArgs a0) {
       if constexpr (PREFETCH) {
         // this frame's samples were requested while the previous frame was being finished (below)
         if constexpr (MODE == kRanges) apply_window<P, -1, false>(t, Y, xr, w);
-        else apply_window_geo<P>(t, Y, xr, a.wtab + N + zoff);
+        else apply_window_geo<P>(t, Y, xr, a.wtab + N + zoff, a.hop);
       } else if constexpr (MODE == kRanges) {
         load_frame<P, -1, false>(t, Y, x, w);  // exact d-indexed weights (per-column calls)
       } else {
-        load_frame_geo<P, (MODE == kBulkAligned)>(t, Y, x, a.wtab + N + zoff);  // samples only
+        load_frame_geo<P, (MODE == kBulkAligned)>(t, Y, x, a.wtab + N + zoff, a.hop);  // samples only
       }
     }
 
@@ -280,81 +266,52 @@ void stft_kernel(const StftArgs a0) {
       MX_BARRIER();  // every wave is past load_t2 / scatter / red[] of the previous frame
       if (f > f0) flush_pitch(f - 1, t);
     }
-    if constexpr (SPLIT) {
-      store_t1_c<P, 0>(t, v, limg);
-      MX_BARRIER();
+    store_t1<P>(t, v, lds);
+    MX_BARRIER();
+    if constexpr (EARLYBAR || DIRECT) {
       if (f > f0) flush_pitch(f - 1, t);
-      load_t1_c<P, 0>(t, v, limg);
-      MX_BARRIER();
-      store_t1_c<P, 1>(t, v, limg);
-      MX_BARRIER();
-      load_t1_c<P, 1>(t, v, limg);
-      MX_BARRIER();
-      pass2<P>(t, v, ltw2);
-      store_t2_c<P, 0>(t, v, limg);
-      MX_BARRIER();
-      load_t2_c<P, 0>(t, v, limg);
-      MX_BARRIER();
-      store_t2_c<P, 1>(t, v, limg);
-      MX_BARRIER();
-      load_t2_c<P, 1>(t, v, limg);
-      MX_BARRIER();  // image free for the next frame's first scatter
-    } else {
-      store_t1<P>(t, v, lds);
-      MX_BARRIER();
-      if constexpr (EARLYBAR || DIRECT) {
-        if (f > f0) flush_pitch(f - 1, t);
-      }
-      if constexpr (kTw2Batch) {
+    }
+    if constexpr (kTw2Batch) {
 #ifdef MX_LDS_ASM
-        load_t1_tw2<P>(t, v, lds, ltw2, w2b);
+      load_t1_tw2<P>(t, v, lds, ltw2, w2b);
 #endif
-      } else {
-        load_t1<P>(t, v, lds);
-      }
-      if constexpr (DEFER) {
-        if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
-      }
-      MX_BARRIER();
-      if constexpr (kTwoLevel) pass2_bases<P>(v, w2base);
-      else if constexpr (TWREG == 1) pass2_reg<P>(v, w2r);
-      else if constexpr (kTw2Batch) pass2_reg<P>(v, w2b);
-      else if constexpr (TWREG >= 2) pass2<P>(t, v, ltw2);
-      else pass2<P>(t, v, tw2);
-      if constexpr (PREFETCH == 2 && !kSlide) {
-        if (f + 1 < f1) {  // the pass-2 twiddles are dead: their registers take the first half of the next frame's samples
-          const float *xn;
-          const float *wn;
-          frame_ptrs(f + 1, zoff, xn, wn);
-          asm volatile("" ::: "memory");  // (keeps the scheduler from hoisting these loads into pass 2's register peak)
-          load_raw_part<P, (MODE == kBulkAligned), 0, P::E / 2>(t, xr, xn);
-        }
-      }
-      store_t2<P>(t, v, lds);
-      MX_BARRIER();
-      load_t2<P>(t, v, lds);
-      if constexpr (!OUTSEP || EARLYBAR) MX_BARRIER();  // image free (for the magnitude scatter / the next T1 scatter)
+    } else {
+      load_t1<P>(t, v, lds);
     }
-    if constexpr (kTwFrame) {
-      fetch_tw3_bases<P>(t, tw3, w3base);
-      post_bases<P>(t, a.ubase + zoff, ulo, uhi);
+    if constexpr (DEFER) {
+      if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
     }
+    MX_BARRIER();
+    if constexpr (kTwoLevel) pass2_bases<P>(v, w2base);
+    else if constexpr (TWREG == 1) pass2_reg<P>(v, w2r);
+    else if constexpr (kTw2Batch) pass2_reg<P>(v, w2b);
+    else if constexpr (TWREG >= 2) pass2<P>(t, v, ltw2);
+    else pass2<P>(t, v, tw2);
+    if constexpr (PREFETCH == 2 && !kSlide) {
+      if (f + 1 < f1) {  // the pass-2 twiddles are dead: their registers take the first half of the next frame's samples
+        const float *xn;
+        const float *wn;
+        frame_ptrs(f + 1, zoff, xn, wn);
+        asm volatile("" ::: "memory");  // (keeps the scheduler from hoisting these loads into pass 2's register peak)
+        load_raw_part<P, (MODE == kBulkAligned), 0, P::E / 2>(t, xr, xn);
+      }
+    }
+    store_t2<P>(t, v, lds);
+    MX_BARRIER();
+    load_t2<P>(t, v, lds);
+    if constexpr (!OUTSEP || EARLYBAR) MX_BARRIER();  // image free (for the magnitude scatter / the next T1 scatter)
     float mg[P::E];
-    if (kW0 == 1 || (kW0 < 0 && (NW == 1 || wave0))) {  // wave-uniform: only the first wavefront contains thread 0
-      if constexpr (SPLIT) pass3_lean<P, true>(t, v, w3base);
-      else if constexpr (kTw3Bases) pass3_bases<P, true>(t, v, w3base);
+    if (NW == 1 || wave0) {  // wave-uniform: only the first wavefront contains thread 0
+      if constexpr (kTw3Bases) pass3_bases<P, true>(t, v, w3base);
       else if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, true>(t, v, w3r);
       else pass3<P, true>(t, v, tw3);
-      if constexpr (SPLIT) post_lean<P, true>(t, v, ulo, uhi, mg);
-      else if constexpr (kPostFly) post_fly<P, true>(t, v, ulo, uhi, mg);
+      if constexpr (kPostFly) post_fly<P, true>(t, v, ulo, uhi, mg);
       else post<P, true>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
     } else {
-      if constexpr (SPLIT) pass3_lean<P, false>(t, v, w3base);
-      else if constexpr (kTw3Bases) pass3_bases<P, false>(t, v, w3base);
+      if constexpr (kTw3Bases) pass3_bases<P, false>(t, v, w3base);
       else if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, false>(t, v, w3r);
       else pass3<P, false>(t, v, tw3);
-      if constexpr (SPLIT) post_lean<P, false>(t, v, ulo, uhi, mg);
-      else if constexpr (kPostFly) post_fly<P, false>(t, v, ulo, uhi, mg);
+      if constexpr (kPostFly) post_fly<P, false>(t, v, ulo, uhi, mg);
       else post<P, false>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
     }
 
@@ -455,13 +412,6 @@ void stft_kernel(const StftArgs a0) {
         a.pitch[f] = p;
       }
     }
-  }
-  };
-  if constexpr (SPLIT && NW > 1) {
-    if (wave0) frame_loop(std::integral_constant<int, 1>{});
-    else frame_loop(std::integral_constant<int, 0>{});
-  } else {
-    frame_loop(std::integral_constant<int, -1>{});
   }
   if constexpr (DEFER || DIRECT) {
     if (f0 < f1) {  // the last frame of this workgroup

@@ -13,16 +13,6 @@
 #include "kernels.h"
 #include "stft_kernel_impl.h"
 
-#ifndef MX_DIRECT_ROWS
-#define MX_DIRECT_ROWS 1
-#endif
-#ifndef MX_SPLIT
-#define MX_SPLIT 1
-#endif
-#ifndef MX_SPLIT_NOSLIDE
-#define MX_SPLIT_NOSLIDE 0
-#endif
-
 namespace mx {
 
 namespace {
@@ -72,13 +62,7 @@ struct Tune {
   // the registers (256 contiguous bytes per wavefront instruction) — no LDS transposition and two barriers fewer per
   // frame: 15.4 -> 14.8 ms per hour at 375-sample columns, 5.03 -> 4.89 ms at hop 1024.  (N = 16384 measures the
   // same either way and keeps the transposition; the two-wave N = 4096 plan's row leaves in the shadow of the next frame.)
-  static constexpr bool DIRECT = (P::N == 32768) && MX_DIRECT_ROWS;
-  // ... and its direct-load kernels exchange one component at a time through a half-size LDS image at four waves per
-  // SIMD (128 registers per thread, pass-3 / post twiddle bases re-fetched per frame, TWREG 7): two workgroups per CU
-  // instead of one, so one computes while the other sits at a barrier.  14 % fewer shader cycles per launch
-  // (GRBM_GUI_ACTIVE 277 M -> 237 M), which moves the kernel from latency-bound at 1235 W / 2.39 GHz to the
-  // 1400 W package limit at ~2.0 GHz: 15.1 -> 14.6 ms per hour (profiles/README.md).
-  static constexpr bool SPLIT = DIRECT && MX_SPLIT;
+  static constexpr bool DIRECT = (P::N == 32768);
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
   static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
   // with DEFER: free the image right after the T2 read, so the next T1 scatter can start under pass 1 (+1%)
@@ -88,7 +72,7 @@ struct Tune {
 // Launches the sliding-window kernel for HOP if the plan can slide by it (Slide<P,HOP>::ok) and the call asks for it.
 template <class P, int HOP>
 bool try_slide(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
-  if constexpr (Slide<P, HOP>::ok && Tune<P>::slides(HOP) && !(Tune<P>::SPLIT && MX_SPLIT_NOSLIDE)) {
+  if constexpr (Slide<P, HOP>::ok && Tune<P>::slides(HOP)) {
     if (b.hop != HOP) return false;
     constexpr int TRS = Tune<P>::template twreg<true, HOP>();
     hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, HOP, Tune<P>::WPE, Tune<P>::NOHOIST, true, TRS, Tune<P>::OUTSEP,
@@ -114,8 +98,7 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
   constexpr int TRD = Tune<P>::template twreg<false>();
   constexpr bool OS = Tune<P>::OUTSEP, DF = Tune<P>::DEFER, EB = Tune<P>::EARLYBAR;
   constexpr int PF = Tune<P>::PREFETCH;
-  constexpr bool DR = Tune<P>::DIRECT, SP = Tune<P>::SPLIT;
-  constexpr int WD = SP ? 4 : W, PFD = SP ? 0 : PF, TWD = SP ? 7 : TRD;  // the direct-load kernels
+  constexpr bool DR = Tune<P>::DIRECT;
   switch (mode) {
     case kBulkAligned:
       // hops that are a small multiple of 2T samples slide the windowed frame through registers (one HBM read
@@ -123,15 +106,15 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
       // frame directly
       if (!(try_slide<P, 256>(b, grid, block, s) || try_slide<P, 512>(b, grid, block, s) ||
             try_slide<P, 1024>(b, grid, block, s)))
-        hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, WD, NH, true, TWD, OS, DF, PFD, EB, false, DR, SP>), grid, block, 0, s, b);
+        hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF, PF, EB, false, DR>), grid, block, 0, s, b);
       break;
-    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, WD, NH, true, TWD, OS, DF, PFD, EB, false, DR, SP>), grid, block, 0, s, b); break;
+    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF, PF, EB, false, DR>), grid, block, 0, s, b); break;
     case kRanges:
       // texel output (fused colormap) is its own instantiation: the binary64 cos/sin of the middle colour
       // segment must not weigh on the register allocation of the plain kernels
       // (and it gets the two-waves-per-SIMD register budget: screen-sized batches are not occupancy-bound)
       if (a.rgb) hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, (W > 2 ? 2 : W), NH, true, TRD, OS, DF, 0, EB, true>), grid, block, 0, s, b);
-      else hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, WD, NH, true, TWD, OS, DF, 0, EB, false, DR, SP>), grid, block, 0, s, b);
+      else hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TRD, OS, DF, 0, EB, false, DR>), grid, block, 0, s, b);
       break;
     default: return hipErrorInvalidValue;
   }

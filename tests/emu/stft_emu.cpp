@@ -62,59 +62,17 @@ void emu_from_state(std::vector<cpx> &Yall, float *mags, std::vector<int> *colli
     }
     for (int o = 0; o < E; ++o) mags[out_bin<C>(t, o)] = mg[o];
   }
-  if constexpr (C::R1 == 32 && C::R3 == 16) {
-    // The four-waves-per-SIMD kernels of these plans move one component at a time through an image of M floats and
-    // walk pass 3 / the split leaf by leaf and slot by slot (stft_core.h: store_t1_c .. post_lean).  Same frame
-    // through that path: every image slot written exactly once per round, and the row bit-identical.
-    std::vector<float> img((size_t)C::M);
-    std::vector<cpx> r2((size_t)C::T * E);
-    auto W = [&](int t) -> cpx(&)[E] { return *reinterpret_cast<cpx(*)[E]>(&r2[(size_t)t * E]); };
-    auto once = [&](auto &&store) {
-      std::fill(img.begin(), img.end(), -12345.0f);
-      std::fill(written.begin(), written.end(), 0);
-      for (int t = 0; t < C::T; ++t) store(t);
-    };
-    for (int t = 0; t < C::T; ++t) pass1<C>(Y(t), W(t));
-    for (int c = 0; c < 2; ++c) {
-      once([&](int t) { c ? store_t1_c<C, 1>(t, W(t), img.data()) : store_t1_c<C, 0>(t, W(t), img.data()); });
-      for (int t = 0; t < C::T; ++t)
-        for (int r = 0; r < C::R1; ++r) {
-          const int a = swz1f<C>(t * C::R1 + r);
-          if (img[(size_t)a] != (c ? W(t)[r].y : W(t)[r].x) && collisions) collisions->push_back(-a - 1);
-          if (written[(size_t)a]++ && collisions) collisions->push_back(a);
-        }
-      // (reads go to a copy so that the other component's store still sees pass-1 outputs)
-      for (int t = 0; t < C::T; ++t) c ? load_t1_c<C, 1>(t, V(t), img.data()) : load_t1_c<C, 0>(t, V(t), img.data());
-    }
-    for (int t = 0; t < C::T; ++t) pass2<C>(t, V(t), reinterpret_cast<const cpx *>(tw2.data()));
-    for (int c = 0; c < 2; ++c) {
-      once([&](int t) { c ? store_t2_c<C, 1>(t, V(t), img.data()) : store_t2_c<C, 0>(t, V(t), img.data()); });
-      for (size_t i = 0; i < img.size(); ++i)
-        if (img[i] == -12345.0f && collisions) collisions->push_back((int)i);  // a slot nobody wrote
-      for (int t = 0; t < C::T; ++t) c ? load_t2_c<C, 1>(t, W(t), img.data()) : load_t2_c<C, 0>(t, W(t), img.data());
-    }
-    for (int t = 0; t < C::T; ++t) {
-      float mg[E];
-      cpx wb[6], lo, hi;
-      fetch_tw3_bases<C>(t, reinterpret_cast<const cpx *>(tw3.data()), wb);
-      pass3_lean<C>(t, W(t), wb);
-      post_bases<C>(t, reinterpret_cast<const cpx *>(ub.data()), lo, hi);
-      post_lean<C>(t, W(t), lo, hi, mg);
-      for (int o = 0; o < E; ++o)
-        if (std::memcmp(&mags[out_bin<C>(t, o)], &mg[o], 4) != 0 && collisions) collisions->push_back(-1000000 - t);
-    }
-  }
 }
 
 // WSTEP = -1: ranges mode (exact d-indexed weights); WSTEP = +1: bulk mode, whose weights the
 // kernel derives from a per-thread seed (load_frame_geo; w then points at the table's 2nd section)
 template <class C, int WSTEP>
-void emu_frame(const float *x, const float *w, float *mags, std::vector<int> *collisions) {
+void emu_frame(const float *x, const float *w, int hop, float *mags, std::vector<int> *collisions) {
   constexpr int E = C::E;
   std::vector<cpx> Yall((size_t)C::T * E);
   for (int t = 0; t < C::T; ++t) {
     auto &Y = *reinterpret_cast<cpx(*)[E]>(&Yall[(size_t)t * E]);
-    if constexpr (WSTEP == 1) load_frame_geo<C, false>(t, Y, x, w);
+    if constexpr (WSTEP == 1) load_frame_geo<C, false>(t, Y, x, w, hop);
     else load_frame<C, WSTEP, false>(t, Y, x, w);
   }
   emu_from_state<C>(Yall, mags, collisions);
@@ -170,12 +128,12 @@ int run(const float *wav, long n, int start, int end, int hop_mode, float *mags)
   std::vector<int> coll;
   if (hop_mode) {
     const std::vector<float> wtab = make_wtab(N, end - start, wext);
-    emu_frame<C, 1>(x, wtab.data() + N, mags, &coll);
+    emu_frame<C, 1>(x, wtab.data() + N, end - start, mags, &coll);
   } else {
     long D0 = (long)N - ((long)end - (long)start);
     D0 = std::max<long>(D0, (long)N - 1 - kWOff);
     D0 = std::min<long>(D0, (long)kWDmax + kWTail);
-    emu_frame<C, -1>(x, wext.data() + kWOff + D0, mags, &coll);
+    emu_frame<C, -1>(x, wext.data() + kWOff + D0, end - start, mags, &coll);
   }
   return (int)coll.size();
 }

@@ -247,11 +247,11 @@ void stft_kernel(const StftArgs a0) {
       if constexpr (PREFETCH) {
         // this frame's samples were requested while the previous frame was being finished (below)
         if constexpr (MODE == kRanges) apply_window<P, -1, false>(t, Y, xr, w);
-        else apply_window_geo<P>(t, Y, xr, a.wtab + N + zoff);
+        else apply_window_geo<P>(t, Y, xr, a.wtab + N + zoff, a.hop);
       } else if constexpr (MODE == kRanges) {
         load_frame<P, -1, false>(t, Y, x, w);  // exact d-indexed weights (per-column calls)
       } else {
-        load_frame_geo<P, (MODE == kBulkAligned)>(t, Y, x, a.wtab + N + zoff);  // samples only
+        load_frame_geo<P, (MODE == kBulkAligned)>(t, Y, x, a.wtab + N + zoff, a.hop);  // samples only
       }
     }
 

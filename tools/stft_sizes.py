@@ -9,6 +9,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import melonix_amd as mx  # noqa: E402
+
+if os.environ.get("MX_AB_LIB"):  # A/B against another build of the library (tools/ab_prev.sh)
+    mx._capi.LIB_PATH = os.environ["MX_AB_LIB"]
 from bench import SR, b_alg, gen_shard  # noqa: E402
 
 dev = torch.device("cuda", 0)
