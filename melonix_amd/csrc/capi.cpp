@@ -95,12 +95,12 @@ namespace {
 // Consecutive frames one workgroup walks.  Long runs amortise the per-workgroup setup (full window
 // load, twiddle fetch) over 16-32 frames; short batches (a screen of 1280 columns) use fewer frames per
 // workgroup so that every CU still gets work (>= ~8 workgroups per CU when there are enough frames).
-int default_frames_per_block(int N, int64_t count) {
+int default_frames_per_block(int N, int mode, int hop, int64_t count) {
   if (const char *e = getenv("MELONIX_FRAMES_PER_BLOCK")) {
     const int v = atoi(e);
     if (v > 0) return v;
   }
-  const int cap = N == 32768 ? 8 : (N == 4096 ? 32 : 16);  // (4096: 32 measured 1% over 16; 48 no better)
+  const int cap = stft_frames_per_block_cap(N, mode, hop);
   const int64_t want_blocks = 2048;
   const int64_t g = count / want_blocks;
   return (int)std::max<int64_t>(1, std::min<int64_t>(cap, g));
@@ -201,7 +201,7 @@ int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_
   s.pitch = d_pitch;
   s.rgb = d_rgb;
   s.cmap_k = cmap_k;
-  s.frames_per_block = ctx->frames_per_block > 0 ? ctx->frames_per_block : default_frames_per_block(N, count);
+  s.frames_per_block = ctx->frames_per_block > 0 ? ctx->frames_per_block : default_frames_per_block(N, mode, hop, count);
   if (mode != kRanges) {
     rc = get_wtab(ctx, N, hop, t, &s.wtab);
     if (rc) return rc;

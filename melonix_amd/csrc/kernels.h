@@ -42,6 +42,9 @@ hipError_t launch_stft(int N, int mode, const StftArgs &a, hipStream_t s);
 #endif
 constexpr int kPlan4096E = MX_PLAN_4096_E;
 int stft_points_per_thread(int N);
+// Longest run of consecutive frames worth giving one workgroup for (N, mode, hop): the kernels that carry a register
+// image from frame to frame amortise their first frame's direct load over the run.
+int stft_frames_per_block_cap(int N, int mode, int hop);
 
 struct ResynthArgs {
   const float *audio;  // padded image

@@ -418,6 +418,103 @@ MX_HD void slide_step(cpx (&Y)[P::E], const cpx (&nx)[Slide<P, HOP>::D], const c
 }
 
 
+// ---- circular sliding window (uniform hops that are not a multiple of 2T samples) ----------------------
+// |DFT| does not change under a circular shift of the (real) input, so the register image need not start at the
+// frame's first sample.  Here it starts at the last multiple of 2T samples (one slot) at or before it: frame position
+// q lives at circular position (o + q) mod N, o = (frame start) mod 2T — slot 0 holds the frame's newest o samples in
+// front of its oldest 2T - o ones.  Stepping to the next frame then is
+//   * the whole image ages by one hop (one multiply by exp(-2.5e-4*hop) per point, as in slide_step), rotated down by
+//     s = (o + hop) div 2T slots on the way (s in {0, 1, 2}: the multiply reads the register s slots up, no moves);
+//   * the newest 2*hop samples are overwritten with audio * exact table weight: the newest hop enter with the flat
+//     top, the hop before them leaves it, each sample by its own factor.  They always sit in the LAST slots and in
+//     slot 0 — compile-time registers — and are 2*hop samples from L2 instead of the N a direct load re-reads.
+// Only products older than two hops carry a multiply chain, restarted from a direct load at every workgroup's first
+// frame.  The slot-aligned sliding kernels are the special case o = 0, hop = 2T*D.
+template <class P>
+struct Circ {
+  static constexpr int W = 2 * P::T;                 // samples per slot
+  static constexpr int CS = (P::T == 128) ? 4 : (P::T == 256) ? 3 : 2;  // slots the newest 2*hop samples can touch (incl. slot 0)
+  static MX_HD bool ok(int hop) { return hop >= 1 && hop <= (CS - 1) * P::T && hop <= 2 * W; }
+  static constexpr int slot(int k) { return (P::E - (CS - 1) + k) & (P::E - 1); }  // k = 0..CS-1; the last one is slot 0
+};
+template <class P>
+struct CircGeo {
+  int o;    // (frame start) mod 2T: circular position of frame position 0
+  int s;    // slots the image rotates down coming from the previous frame
+  int cr;   // circular position of the first of the newest 2*hop samples
+  int len;  // 2 * hop
+};
+template <class P>
+MX_HD CircGeo<P> circ_geo(long long frame_end, int hop) {
+  constexpr int W = Circ<P>::W;
+  const long long start = frame_end - P::N;
+  CircGeo<P> g;
+  g.o = (int)(start & (long long)(W - 1));
+  g.s = ((int)((start - hop) & (long long)(W - 1)) + hop) / W;
+  g.len = 2 * hop;
+  g.cr = (g.o - g.len) & (P::N - 1);
+  return g;
+}
+// a workgroup's first frame: direct load.  xa = the frame's first sample, w = the exact weight table
+template <class P>
+MX_HD void circ_load_first(int t, cpx (&Y)[P::E], const float *xa, const float *w, int o) {
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const int c2 = 2 * (t + P::T * e);
+    const int q0 = (c2 - o) & (P::N - 1), q1 = (c2 + 1 - o) & (P::N - 1);  // positions inside the frame
+    Y[e] = mk(xa[q0] * w[q0], xa[q1] * w[q1]);  // rounded binary32 products, as everywhere
+  }
+}
+// the newest 2*hop samples of the frame `g` describes and their weights, for this thread's points in the candidate
+// slots: xs = audio at (frame end - 2*hop), wt = wtab + (N - 2*hop).  Lanes outside fetch a clamped (valid, unused) position.
+template <class P>
+MX_HD void circ_fetch(int t, const float *xs, const float *wt, const CircGeo<P> &g, float (&px)[2 * Circ<P>::CS],
+                      float (&pw)[2 * Circ<P>::CS]) {
+#pragma unroll
+  for (int k = 0; k < Circ<P>::CS; ++k) {
+    const int c2 = 2 * (t + P::T * Circ<P>::slot(k));
+    int d0 = (c2 - g.cr) & (P::N - 1), d1 = (c2 + 1 - g.cr) & (P::N - 1);
+    d0 = d0 < g.len ? d0 : g.len - 1;
+    d1 = d1 < g.len ? d1 : g.len - 1;
+    px[2 * k] = xs[d0];
+    px[2 * k + 1] = xs[d1];
+    pw[2 * k] = wt[d0];
+    pw[2 * k + 1] = wt[d1];
+  }
+}
+template <class P, int S>
+MX_HD void circ_age(cpx (&Y)[P::E], cpx gg) {
+  cpx head[S > 0 ? S : 1];
+#pragma unroll
+  for (int i = 0; i < S; ++i) head[i] = Y[i];
+#pragma unroll
+  for (int e = 0; e < P::E - S; ++e) Y[e] = pk_mul_xs(Y[e + S], gg);
+#pragma unroll
+  for (int i = 0; i < S; ++i) Y[P::E - S + i] = pk_mul_xs(head[i], gg);
+}
+// the step into the frame `g` describes
+template <class P>
+MX_HD void circ_step(int t, cpx (&Y)[P::E], float decay, const CircGeo<P> &g, const float (&px)[2 * Circ<P>::CS],
+                     const float (&pw)[2 * Circ<P>::CS]) {
+  const cpx gg = mk(decay, decay);
+  constexpr int SMAX = (Circ<P>::W - 1 + (Circ<P>::CS - 1) * P::T) / Circ<P>::W;  // largest rotation ok() admits
+  static_assert(SMAX <= 2, "rotations by 0, 1 or 2 slots");
+  if (g.s == 0) circ_age<P, 0>(Y, gg);  // wave-uniform
+  else if (SMAX == 1 || g.s == 1) circ_age<P, 1>(Y, gg);
+  else circ_age<P, 2>(Y, gg);
+#pragma unroll
+  for (int k = 0; k < Circ<P>::CS; ++k) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int e = Circ<P>::slot(k);
+    const int c2 = 2 * (t + P::T * e);
+    const int d0 = (c2 - g.cr) & (P::N - 1), d1 = (c2 + 1 - g.cr) & (P::N - 1);
+    const float n0 = px[2 * k] * pw[2 * k], n1 = px[2 * k + 1] * pw[2 * k + 1];
+    Y[e] = mk(d0 < g.len ? n0 : Y[e].x, d1 < g.len ? n1 : Y[e].y);
+  }
+}
+
+
 // ---- unmerged LDS reads ---------------------------------------------------------
 // The compiler fuses neighbouring 8-byte LDS reads into ds_read2(st64)_b64, which the LDS
 // serves at half the rate of two plain ds_read_b64 (MI355X_MICROARCH.md, LDS table: 8 cycles

@@ -53,7 +53,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 // NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
 // and window loads are not hoisted out of the frame loop into hundreds of registers.
 template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, int TWREG = 0, bool OUTSEP = false,
-          bool DEFER = false, int PREFETCH = 0, bool EARLYBAR = false, bool CMAP = false, bool DIRECT = false>
+          bool DEFER = false, int PREFETCH = 0, bool EARLYBAR = false, bool CMAP = false, bool DIRECT = false, bool CIRC = false>
 __global__ __launch_bounds__(P::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void stft_kernel(const StftArgs a0) {
   const StftArgs &a = a0;
@@ -88,6 +88,9 @@ void stft_kernel(const StftArgs a0) {
   // transposed through LDS into 16-byte stores: no LDS round trip and no barrier in the output path, and the pitch
   // record of frame f is written after frame f+1's first barrier.
   static_assert(!DIRECT || (NW > 1 && !DEFER && !OUTSEP && !CMAP), "direct row stores: multi-wave, non-deferred plans");
+  // CIRC (uniform hop, not a multiple of 2T samples): the register image holds the windowed samples by absolute
+  // position and only the newest 2*hop of them are fetched per frame (stft_core.h, circular sliding window)
+  static_assert(!CIRC || (MODE != kRanges && HOP == 0 && PREFETCH == 0 && !CMAP), "circular window: bulk modes");
   __shared__ __attribute__((aligned(16))) float2 lds[C::M + kRed + (OUTSEP ? C::M / 2 : 0) + kTw2];
   float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + C::M + kRed : lds);
   float2 *const ltw2 = lds + C::M + kRed + (OUTSEP ? C::M / 2 : 0);
@@ -209,6 +212,13 @@ void stft_kernel(const StftArgs a0) {
       w = a.wtab + zo;
     }
   };
+  float cpx_[2 * Circ<P>::CS], cpw_[2 * Circ<P>::CS];  // CIRC: the next frame's newest samples and weights, in flight
+  if constexpr (CIRC) {
+    if (f0 < f1) {
+      const int64_t pe = (a.first_frame + f0 + 1) * (int64_t)a.hop;
+      circ_load_first<P>(t_, Y, a.audio + MX_AUDIO_PAD + (pe - N), a.wtab, circ_geo<P>(pe, a.hop).o);
+    }
+  }
   cpx xr[(PREFETCH && !kSlide) ? P::E : 1];  // raw samples of the next frame, in flight
   if constexpr (PREFETCH && !kSlide) {
     if (f0 < f1) {
@@ -234,7 +244,9 @@ void stft_kernel(const StftArgs a0) {
     int out_lo, out_hi;
     out_bases<P>(t, out_lo, out_hi);
 
-    if constexpr (kSlide) {
+    if constexpr (CIRC) {
+      if (f > f0) circ_step<P>(t, Y, a.decay, circ_geo<P>((a.first_frame + f + 1) * (int64_t)a.hop, a.hop), cpx_, cpw_);
+    } else if constexpr (kSlide) {
       // in-place shift+decay into this frame (Y[e] <- Y[e+D]*g reads ahead of what it writes), then
       // prefetch the next frame's newest hop (1 KiB per wavefront) under this frame's math
       if (f > f0) slide_step<P, HOP>(Y, nx, edge, a.decay, kSc);
@@ -322,6 +334,13 @@ void stft_kernel(const StftArgs a0) {
         frame_ptrs(f + 1, zoff, xn, wn);
         asm volatile("" ::: "memory");
         load_raw_part<P, (MODE == kBulkAligned), P::E / 2, P::E>(t, xr, xn);
+      }
+    }
+    if constexpr (CIRC) {
+      if (f + 1 < f1) {  // the transform's registers are free again: request the next frame's newest 2*hop samples
+        const int64_t pe = (a.first_frame + f + 2) * (int64_t)a.hop;
+        circ_fetch<P>(t, a.audio + MX_AUDIO_PAD + (pe - 2 * (int64_t)a.hop), a.wtab + zoff + (N - 2 * a.hop),
+                      circ_geo<P>(pe, a.hop), cpx_, cpw_);
       }
     }
     if constexpr (PREFETCH == 1 && !kSlide) {

@@ -63,6 +63,13 @@ struct Tune {
   // frame: 15.4 -> 14.8 ms per hour at 375-sample columns, 5.03 -> 4.89 ms at hop 1024.  (N = 16384 measures the
   // same either way and keeps the transposition; the two-wave N = 4096 plan's row leaves in the shadow of the next frame.)
   static constexpr bool DIRECT = (P::N == 32768);
+#ifndef MX_CIRC
+#define MX_CIRC 1
+#endif
+  // the circular window for N = 32768 (T = 512: hops up to 512 — 375- and 512-sample columns): 14.2 -> 13.0 ms and
+  // 10.4 -> 9.7 ms per hour.  N = 16384 measures the same as its direct loads (the three candidate slots' prefetch does
+  // not fit its registers), the two-wave N = 4096 plan loses (1.87 against 1.70 ms), so both keep the direct loads.
+  static constexpr bool CIRC = MX_CIRC && (P::N == 32768);
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
   static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
   // with DEFER: free the image right after the T2 read, so the next T1 scatter can start under pass 1 (+1%)
@@ -81,6 +88,22 @@ bool try_slide(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
     return true;
   } else {
     return false;
+  }
+}
+
+// Uniform hops that do not slide by whole slots but are small against the frame: the circular window (stft_core.h) —
+// one kernel for aligned and unaligned sample buffers (its loads are single dwords).
+template <class P>
+bool try_circ(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
+  if constexpr (!Tune<P>::CIRC) {
+    return false;
+  } else {
+    if (!Circ<P>::ok(b.hop)) return false;
+    constexpr int TRS = Tune<P>::template twreg<true, 0>();
+    hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, Tune<P>::WPE, Tune<P>::NOHOIST, true, TRS, Tune<P>::OUTSEP, Tune<P>::DEFER,
+                                    0, Tune<P>::EARLYBAR, false, Tune<P>::DIRECT, true>),
+                       grid, block, 0, s, b);
+    return true;
   }
 }
 
@@ -105,10 +128,12 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
       // per sample): 256/512 at N = 4096, 512/1024 at N = 16384, 1024 at N = 32768; any other hop loads every
       // frame directly
       if (!(try_slide<P, 256>(b, grid, block, s) || try_slide<P, 512>(b, grid, block, s) ||
-            try_slide<P, 1024>(b, grid, block, s)))
+            try_slide<P, 1024>(b, grid, block, s) || try_circ<P>(b, grid, block, s)))
         hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF, PF, EB, false, DR>), grid, block, 0, s, b);
       break;
-    case kBulkAny: hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF, PF, EB, false, DR>), grid, block, 0, s, b); break;
+    case kBulkAny:
+      if (try_circ<P>(b, grid, block, s)) break;
+      hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF, PF, EB, false, DR>), grid, block, 0, s, b); break;
     case kRanges:
       // texel output (fused colormap) is its own instantiation: the binary64 cos/sin of the middle colour
       // segment must not weigh on the register allocation of the plain kernels
@@ -124,6 +149,15 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
 }  // namespace
 
 int stft_points_per_thread(int N) { return N == 4096 ? kPlan4096E : 32; }
+
+int stft_frames_per_block_cap(int N, int mode, int hop) {
+  // measured (tools/stft_sizes.py with MELONIX_FRAMES_PER_BLOCK): 4096: 32 is 1 % over 16, 48 no better; the circular
+  // window of N = 32768 pays four scattered loads per point for a workgroup's first frame: 8 -> 32 frames is 5 % faster
+  if (N == 32768 && mode != kRanges && Tune<Plan<32768, 32>>::CIRC && !Tune<Plan<32768, 32>>::slides(hop) &&
+      Circ<Plan<32768, 32>>::ok(hop))
+    return 32;
+  return N == 32768 ? 8 : (N == 4096 ? 32 : 16);
+}
 
 hipError_t launch_stft(int N, int mode, const StftArgs &a, hipStream_t s) {
   switch (N) {

@@ -69,11 +69,12 @@ def emu():
     here = os.path.dirname(os.path.abspath(__file__))
     src = os.path.join(here, "emu", "stft_emu.cpp")
     so = os.path.join(here, "emu", "libstft_emu.so")
-    deps = [src] + [os.path.join(ROOT, "melonix_amd", "csrc", f) for f in ("stft_core.h", "stft_tables.h", "stft_consts.inc")]
+    deps = [src] + [os.path.join(ROOT, "melonix_amd", "csrc", f) for f in ("stft_core.h", "pk_math.h", "stft_tables.h", "stft_consts.inc")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", src, "-o", so])
     L = C.CDLL(so)
     fp = C.POINTER(C.c_float)
     L.emu_stft_frame.argtypes = [C.c_int, C.c_int, fp, C.c_long, C.c_int, C.c_int, C.c_int, fp]
     L.emu_stft_slide.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.c_long, C.c_long, C.c_long, fp]
+    L.emu_stft_circ.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.c_long, C.c_long, C.c_long, fp]
     return L

@@ -112,6 +112,38 @@ int run_slide(const float *wav, long n, long first, long count, float *mags) {
   return (int)coll.size();
 }
 
+// Circular sliding window (any small uniform hop): frames first..first+count-1, the first loaded directly in the
+// slot-aligned circular layout, the rest stepped exactly as the kernel does (circ_fetch for the coming frame, circ_step).
+template <class C>
+int run_circ(const float *wav, long n, int hop, long first, long count, float *mags) {
+  constexpr int N = C::N, E = C::E;
+  if (!Circ<C>::ok(hop)) return -2;
+  const int PAD = 32768;
+  std::vector<float> padded((size_t)n + 2 * PAD, 0.0f);
+  std::memcpy(padded.data() + PAD, wav, sizeof(float) * (size_t)n);
+  static const std::vector<float> wext = make_wext(fold_scale(N));
+  const std::vector<float> wtab = make_wtab(N, hop, wext);
+  const float g = hop_decay(hop);
+  std::vector<cpx> Yall((size_t)C::T * E);
+  std::vector<int> coll;
+  for (long f = 0; f < count; ++f) {
+    const long long pe = (long long)(first + f + 1) * hop;
+    const CircGeo<C> geo = circ_geo<C>(pe, hop);
+    for (int t = 0; t < C::T; ++t) {
+      auto &Y = *reinterpret_cast<cpx(*)[E]>(&Yall[(size_t)t * E]);
+      if (f == 0) {
+        circ_load_first<C>(t, Y, padded.data() + PAD + (pe - N), wtab.data(), geo.o);
+      } else {
+        float px[2 * Circ<C>::CS], pw[2 * Circ<C>::CS];
+        circ_fetch<C>(t, padded.data() + PAD + (pe - 2LL * hop), wtab.data() + (N - 2 * hop), geo, px, pw);
+        circ_step<C>(t, Y, g, geo, px, pw);
+      }
+    }
+    emu_from_state<C>(Yall, mags + (size_t)f * (N / 2), &coll);
+  }
+  return (int)coll.size();
+}
+
 template <class C>
 int run(const float *wav, long n, int start, int end, int hop_mode, float *mags) {
   constexpr int N = C::N;
@@ -158,5 +190,13 @@ extern "C" int emu_stft_slide(int N, int E, int hop, const float *wav, long n, l
   if (N == 4096 && E == 16 && hop == 512) return run_slide<Plan<4096, 16>, 512>(wav, n, first, count, mags);
   if (N == 16384 && E == 32 && hop == 1024) return run_slide<Plan<16384, 32>, 1024>(wav, n, first, count, mags);
   if (N == 32768 && E == 32 && hop == 1024) return run_slide<Plan<32768, 32>, 1024>(wav, n, first, count, mags);
+  return -1;
+}
+
+// frames [first, first+count) with the circular sliding window; mags = count x N/2 (-2: hop outside its range)
+extern "C" int emu_stft_circ(int N, int E, int hop, const float *wav, long n, long first, long count, float *mags) {
+  if (N == 4096 && E == 16) return run_circ<Plan<4096, 16>>(wav, n, hop, first, count, mags);
+  if (N == 16384 && E == 32) return run_circ<Plan<16384, 32>>(wav, n, hop, first, count, mags);
+  if (N == 32768 && E == 32) return run_circ<Plan<32768, 32>>(wav, n, hop, first, count, mags);
   return -1;
 }

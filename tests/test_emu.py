@@ -49,3 +49,22 @@ def test_sliding_window(emu, oracle, N, E, hop, first, count):
     err = np.abs(out - ref)
     assert (err <= mag_tol(ref)).all()
     assert (err.max(axis=1) <= 1e-6 * ref.max(axis=1) + 1e-12).all()
+
+
+@pytest.mark.parametrize("N,E,hop,first,count", [(4096, 16, 375, 0, 40), (4096, 16, 375, 360, 25), (4096, 16, 100, 3, 50),
+                                                  (4096, 16, 384, 0, 24), (4096, 16, 257, 11, 24), (4096, 16, 1, 4000, 24),
+                                                  (16384, 32, 375, 0, 50), (16384, 32, 512 - 1, 250, 20),
+                                                  (32768, 32, 375, 0, 24), (32768, 32, 512, 270, 12), (32768, 32, 1000, 5, 10)])
+def test_circular_window(emu, oracle, N, E, hop, first, count):
+    """Uniform hops that do not slide by whole slots: the circular register image (only the newest 2*hop samples
+    fetched per frame, everything older aged by one multiply) stays within 1e-6 of the frame peak of the oracle —
+    including frames that start before the file and end after it."""
+    w = noisy(accum_sweep(3 * SR))
+    fp = C.POINTER(C.c_float)
+    out = np.empty((count, N // 2), np.float32)
+    rc = emu.emu_stft_circ(N, E, hop, w.ctypes.data_as(fp), len(w), first, count, out.ctypes.data_as(fp))
+    assert rc == 0
+    ref = np.stack([oracle.spec_frame(w, N, (first + f) * hop, (first + f + 1) * hop) for f in range(count)])
+    err = np.abs(out - ref)
+    assert (err <= mag_tol(ref)).all()
+    assert (err.max(axis=1) <= 1e-6 * ref.max(axis=1) + 1e-12).all()

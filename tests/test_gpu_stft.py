@@ -139,11 +139,12 @@ def test_linearity_and_silence(gpu_ctx):
 
 
 def test_frames_per_block_invariance(gpu_ctx):
-    """hop 375 has no sliding carry: any workgroup shape gives identical bits; hop 256 slides the
-    register image, which may move results by a few 1e-7 of the frame peak, never more."""
+    """hop 3000 loads every frame directly: any workgroup shape gives identical bits; hops 256 (slot-aligned sliding
+    image) and 375 (circular image) carry products from frame to frame inside a workgroup, which may move results by a
+    few 1e-7 of the frame peak, never more."""
     w = noisy(accum_sweep(2 * SR))
     a = gpu_ctx.upload(w)
-    for hop, exact in ((375, True), (256, False)):
+    for hop, exact in ((3000, True), (375, False), (256, False)):
         ref = None
         for g in (1, 3, 16, 64, 1000):
             gpu_ctx.set_frames_per_block(g)
@@ -262,4 +263,28 @@ def test_device_equals_cpu_emulation(gpu_ctx, emu, N, E):
         assert emu.emu_stft_frame(N, E, w.ctypes.data_as(fp), len(w), s_, e_, 0, out.ctypes.data_as(fp)) == 0
         ulp = np.spacing(np.maximum(np.abs(out), np.float32(1e-30)))
         assert (np.abs(mags[i] - out) <= 2 * ulp).all(), float((np.abs(mags[i] - out) / ulp).max())
+    a.free()
+
+
+@pytest.mark.parametrize("N,E,hop", [(32768, 32, 375), (32768, 32, 512), (32768, 32, 300), (32768, 32, 77)])  # Tune::CIRC
+def test_circular_window_equals_cpu_emulation(gpu_ctx, emu, N, E, hop):
+    """Uniform hops that do not slide by whole slots run, at N = 32768, the circular register image (stft_core.h): the device's
+    frames — every workgroup restarts from a direct load — equal the CPU emulation of the same templates walked over the
+    same workgroup, to the 2 ulp of v_sqrt_f32 vs sqrtf."""
+    import ctypes as C
+    w = noisy(accum_sweep(3 * SR))
+    fp = C.POINTER(C.c_float)
+    a = gpu_ctx.upload(w)
+    g = 7
+    gpu_ctx.set_frames_per_block(g)
+    mags, _ = gpu_ctx.stft_hop(a, N, hop)
+    gpu_ctx.set_frames_per_block(0)
+    F = mags.shape[0]
+    for blk in (0, 3, (F - 1) // g):  # first workgroups (frames that start before the file) and the last, ragged one
+        first, count = blk * g, min(g, F - blk * g)
+        out = np.empty((count, N // 2), np.float32)
+        assert emu.emu_stft_circ(N, E, hop, w.ctypes.data_as(fp), len(w), first, count, out.ctypes.data_as(fp)) == 0
+        ulp = np.spacing(np.maximum(np.abs(out), np.float32(1e-30)))
+        d = np.abs(mags[first:first + count] - out)
+        assert (d <= 2 * ulp).all(), float((d / ulp).max())
     a.free()
