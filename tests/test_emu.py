@@ -54,7 +54,7 @@ def test_sliding_window(emu, oracle, N, E, hop, first, count):
 @pytest.mark.parametrize("N,E,hop,first,count", [(4096, 16, 375, 0, 40), (4096, 16, 375, 360, 25), (4096, 16, 100, 3, 50),
                                                   (4096, 16, 384, 0, 24), (4096, 16, 257, 11, 24), (4096, 16, 1, 4000, 24),
                                                   (16384, 32, 375, 0, 50), (16384, 32, 512 - 1, 250, 20),
-                                                  (32768, 32, 375, 0, 24), (32768, 32, 512, 270, 12), (32768, 32, 1000, 5, 10)])
+                                                  (32768, 32, 375, 0, 24), (32768, 32, 512, 270, 12), (32768, 32, 500, 5, 10)])
 def test_circular_window(emu, oracle, N, E, hop, first, count):
     """Uniform hops that do not slide by whole slots: the circular register image (only the newest 2*hop samples
     fetched per frame, everything older aged by one multiply) stays within 1e-6 of the frame peak of the oracle —
