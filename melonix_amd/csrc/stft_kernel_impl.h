@@ -245,7 +245,13 @@ void stft_kernel(const StftArgs a0) {
     out_bases<P>(t, out_lo, out_hi);
 
     if constexpr (CIRC) {
-      if (f > f0) circ_step<P>(t, Y, a.decay, circ_geo<P>((a.first_frame + f + 1) * (int64_t)a.hop, a.hop), cpx_, cpw_);
+      if (f > f0) {
+        const int64_t pe = (a.first_frame + f + 1) * (int64_t)a.hop;
+        const CircGeo<P> geo = circ_geo<P>(pe, a.hop);
+        if constexpr (!Circ<P>::AHEAD)
+          circ_fetch<P>(t, a.audio + MX_AUDIO_PAD + (pe - 2 * (int64_t)a.hop), a.wtab + zoff + (N - 2 * a.hop), geo, cpx_, cpw_);
+        circ_step<P>(t, Y, a.decay, geo, cpx_, cpw_);
+      }
     } else if constexpr (kSlide) {
       // in-place shift+decay into this frame (Y[e] <- Y[e+D]*g reads ahead of what it writes), then
       // prefetch the next frame's newest hop (1 KiB per wavefront) under this frame's math
@@ -337,7 +343,7 @@ void stft_kernel(const StftArgs a0) {
       }
     }
     if constexpr (CIRC) {
-      if (f + 1 < f1) {  // the transform's registers are free again: request the next frame's newest 2*hop samples
+      if (Circ<P>::AHEAD && f + 1 < f1) {  // the transform's registers are free again: request the next frame's newest 2*hop samples
         const int64_t pe = (a.first_frame + f + 2) * (int64_t)a.hop;
         circ_fetch<P>(t, a.audio + MX_AUDIO_PAD + (pe - 2 * (int64_t)a.hop), a.wtab + zoff + (N - 2 * a.hop),
                       circ_geo<P>(pe, a.hop), cpx_, cpw_);

@@ -66,10 +66,12 @@ struct Tune {
 #ifndef MX_CIRC
 #define MX_CIRC 1
 #endif
-  // the circular window for N = 32768 (T = 512: hops up to 512 — 375- and 512-sample columns): 14.2 -> 13.0 ms and
-  // 10.4 -> 9.7 ms per hour.  N = 16384 measures the same as its direct loads (the three candidate slots' prefetch does
-  // not fit its registers), the two-wave N = 4096 plan loses (1.87 against 1.70 ms), so both keep the direct loads.
-  static constexpr bool CIRC = MX_CIRC && (P::N == 32768);
+
+  // the circular window (stft_core.h) for the 32-points-per-thread plans, hops up to 512 samples that do not slide by
+  // whole slots: N = 32768 at 375- / 512-sample columns 14.2 -> 13.0 and 10.4 -> 9.7 ms per hour, N = 16384 at 375
+  // 6.55 -> 6.15 (samples fetched at the top of their own frame there: a frame ahead, their 12 registers spill).  The
+  // two-wave N = 4096 plan loses (1.87 against 1.70 ms) and keeps its direct loads.
+  static constexpr bool CIRC = MX_CIRC && (P::E == 32);
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
   static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
   // with DEFER: free the image right after the T2 read, so the next T1 scatter can start under pass 1 (+1%)

@@ -266,9 +266,10 @@ def test_device_equals_cpu_emulation(gpu_ctx, emu, N, E):
     a.free()
 
 
-@pytest.mark.parametrize("N,E,hop", [(32768, 32, 375), (32768, 32, 512), (32768, 32, 300), (32768, 32, 77)])  # Tune::CIRC
+@pytest.mark.parametrize("N,E,hop", [(32768, 32, 375), (32768, 32, 512), (32768, 32, 300), (32768, 32, 77), (16384, 32, 375),
+                                     (16384, 32, 500), (16384, 32, 129)])  # Tune::CIRC
 def test_circular_window_equals_cpu_emulation(gpu_ctx, emu, N, E, hop):
-    """Uniform hops that do not slide by whole slots run, at N = 32768, the circular register image (stft_core.h): the device's
+    """Uniform hops that do not slide by whole slots run, at N = 16384 and 32768, the circular register image (stft_core.h): the device's
     frames — every workgroup restarts from a direct load — equal the CPU emulation of the same templates walked over the
     same workgroup, to the 2 ulp of v_sqrt_f32 vs sqrtf."""
     import ctypes as C
