@@ -158,6 +158,20 @@ int mx_stft_ranges_rgb_dev(mx_ctx *ctx, const mx_audio *a, int N, const int32_t 
  * of 4), e.g. to re-colour cached rows after the user changed k (app.cpp:75). */
 int mx_colormap_dev(mx_ctx *ctx, const float *d_mags, int64_t nbins_total, float k, uint8_t *d_rgb);
 
+/* Device-resident magnitude rows — the device-side row cache of a Spec worker (the reference keeps its
+ * rows in host memory, spec.cpp:18-42).  mx_stft_ranges_keep is mx_stft_ranges_rgb_mags whose magnitude rows STAY in HBM
+ * (*rows_out, count rows; release with mx_rows_free) whatever comes back to the host: rgb_out (k != 0) and mags_out
+ * may each be NULL.  mx_rows_fetch copies rows [first, first+count) of a kept batch to the host; mx_rows_colormap returns
+ * their texel rows for a scale k by running the colormap alone (no transform) — what a changed brightness (app.cpp:75)
+ * or a late getSpec of a texel-only column costs instead of a second STFT. */
+typedef struct mx_rows mx_rows;
+int mx_stft_ranges_keep(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *ranges, int64_t count, float k,
+                        float *mags_out, uint8_t *rgb_out, mx_rows **rows_out);
+int64_t mx_rows_count(const mx_rows *rows);
+void mx_rows_free(mx_ctx *ctx, mx_rows *rows);
+int mx_rows_fetch(mx_ctx *ctx, const mx_rows *rows, int64_t first, int64_t count, float *mags_out);
+int mx_rows_colormap(mx_ctx *ctx, const mx_rows *rows, int64_t first, int64_t count, float k, uint8_t *rgb_out);
+
 /* Number of frames of the bulk indexing: ceil(n / hop). */
 int64_t mx_frame_count(int64_t n, int hop);
 

@@ -85,6 +85,32 @@ class Audio:
             pass
 
 
+class KeptRows:
+    """Magnitude rows of one batch that stay on the device (mx_rows): fetch() / colormap() bring spans of them back
+    without another transform."""
+
+    def __init__(self, ctx, handle, N):
+        self.ctx, self.handle, self.N = ctx, handle, N
+
+    def __len__(self):
+        return int(_capi.lib().mx_rows_count(self.handle)) if self.handle else 0
+
+    def fetch(self, first: int, count: int):
+        out = np.empty((count, self.N // 2), dtype=np.float32)
+        _capi.check(_capi.lib().mx_rows_fetch(self.ctx.handle, self.handle, first, count, _ptr(out)))
+        return out
+
+    def colormap(self, first: int, count: int, k: float):
+        out = np.empty((count, self.N // 2, 3), dtype=np.uint8)
+        _capi.check(_capi.lib().mx_rows_colormap(self.ctx.handle, self.handle, first, count, float(k), _ptr(out)))
+        return out
+
+    def free(self):
+        if self.handle:
+            _capi.lib().mx_rows_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+
 class Context:
     """One per GPU / rank (mx_ctx)."""
 
@@ -168,6 +194,18 @@ class Context:
         _capi.check(_capi.lib().mx_stft_ranges_rgb_mags(self.handle, audio.handle, N, _ptr(ranges), len(ranges),
                                                         float(k), _ptr(mags), _ptr(rgb)))
         return rgb, mags
+
+    def stft_ranges_keep(self, audio: Audio, N: int, ranges, k: float = 0.0, want_mags: bool = False):
+        """mx_stft_ranges_keep: the batch's magnitude rows stay in HBM (returns a KeptRows handle), texel rows
+        (k != 0) and / or the magnitude rows come back as well: (rows, rgb | None, mags | None)."""
+        ranges = np.ascontiguousarray(ranges, dtype=np.int32).reshape(-1, 2)
+        rgb = np.empty((len(ranges), N // 2, 3), dtype=np.uint8) if k != 0.0 else None
+        mags = np.empty((len(ranges), N // 2), dtype=np.float32) if want_mags else None
+        h = C.c_void_p()
+        _capi.check(_capi.lib().mx_stft_ranges_keep(self.handle, audio.handle, N, _ptr(ranges), len(ranges), float(k),
+                                                    _ptr(mags) if mags is not None else None,
+                                                    _ptr(rgb) if rgb is not None else None, C.byref(h)))
+        return KeptRows(self, h, N), rgb, mags
 
     # ---- STFT, device-resident outputs (raw device pointers, async on the ctx stream) ----
     def stft_hop_dev(self, audio: Audio, N: int, hop: int, first: int, count: int, d_mags: int | None,

@@ -73,6 +73,11 @@ SIGNATURES = {
     "mx_stft_ranges_rgb_mags": (_i, [_vp, _vp, _i, _vp, _i64, _f, _vp, _vp]),
     "mx_stft_ranges_rgb_dev": (_i, [_vp, _vp, _i, _vp, _i64, _f, _vp, _vp]),
     "mx_colormap_dev": (_i, [_vp, _vp, _i64, _f, _vp]),
+    "mx_stft_ranges_keep": (_i, [_vp, _vp, _i, _vp, _i64, _f, _vp, _vp, C.POINTER(_vp)]),
+    "mx_rows_count": (_i64, [_vp]),
+    "mx_rows_free": (None, [_vp, _vp]),
+    "mx_rows_fetch": (_i, [_vp, _vp, _i64, _i64, _vp]),
+    "mx_rows_colormap": (_i, [_vp, _vp, _i64, _i64, _f, _vp]),
     "mx_frame_count": (_i64, [_i64, _i]),
     "mx_sample2time": (_d, [_vp, _i, _i, _i]),
     "mx_time2sample": (_i, [_vp, _i, _i, _d]),

@@ -5,7 +5,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -67,20 +69,40 @@ struct Spec::Impl {
     }
   };
 
-  // One worker launch lands in one slab; the cached rows are views into it.
+  // Host data of one worker step (a launch, a fetch or a re-colouring): one pooled block; cached rows are views into it.
   struct Slab {
     Pool *pool = nullptr;
     Pool::Block block;
-    float *mags = nullptr;          // rows x N/2, or null: a texel-only batch (nobody asked for magnitudes)
+    float *mags = nullptr;          // rows x N/2, or null
     unsigned char *rgb = nullptr;   // rows x N/2 x 3, or null
     ~Slab() {
       if (pool) pool->release(block);
     }
   };
+  // The device-side row cache: the magnitude rows of a launch stay in HBM for as long as a cached column
+  // refers to them and the budget allows, so that a later getSpec of a column only SpecCache had asked for, or the whole
+  // screen after a brightness change, costs a copy / the colormap alone instead of another transform.  Created, used and
+  // dropped by the worker thread only; `rows` is read by the other threads under Impl::mu.
+  struct DevBatch {
+    mx_ctx *ctx = nullptr;
+    mx_rows *rows = nullptr;  // null once dropped for the budget
+    std::size_t bytes = 0;
+    void drop() {
+      if (rows) mx_rows_free(ctx, rows);
+      rows = nullptr;
+    }
+    ~DevBatch() { drop(); }
+  };
   struct Row {
-    std::shared_ptr<const Slab> slab;  // null = requested, not computed yet
-    std::size_t index = 0;             // row number inside the slab
-    float k = 0.f;                     // the scale the slab's texels were computed with (0: none)
+    std::shared_ptr<const Slab> tex;   // texel row (scale k) ...
+    std::size_t texIndex = 0;
+    float k = 0.f;
+    std::shared_ptr<const Slab> mag;   // ... magnitude row on the host ...
+    std::size_t magIndex = 0;
+    std::shared_ptr<DevBatch> dev;     // ... and the batch whose device rows hold this column's magnitudes
+    std::size_t devIndex = 0;
+    bool onDevice() const { return dev && dev->rows; }
+    bool computed() const { return tex || mag || onDevice(); }
   };
 
   int N;
@@ -97,8 +119,16 @@ struct Spec::Impl {
   std::atomic<float> texScale{0.f};  // 0 = no SpecCache attached: magnitudes only
   std::atomic<int> failures{0};
   std::thread worker;
+  // device rows kept, oldest first (worker thread only), and their budget
+  std::deque<std::weak_ptr<DevBatch>> devBatches;
+  std::size_t devBytes = 0;
+  std::size_t devBudget = std::size_t(1) << 30;
+  // what the worker has done so far (tests, MELONIX_TIMING)
+  std::atomic<std::uint64_t> nLaunchedColumns{0}, nFetchedRows{0}, nRecolouredRows{0};
 
-  explicit Impl(int fft) : N(fft) {}
+  explicit Impl(int fft) : N(fft) {
+    if (const char *e = std::getenv("MELONIX_SPEC_DEVICE_MB")) devBudget = std::size_t(std::strtoull(e, nullptr, 10)) << 20;
+  }
   bool usable() const { return ctx && audio; }
 
   // the miss path of getSpec / requestTexRow (spec.cpp:30-41): a slot without data, the job, LRU eviction
@@ -110,7 +140,41 @@ struct Spec::Impl {
     wake.notify_one();
   }
 
-  // One launch for `keys`: magnitudes and/or texels (k != 0) into one pooled slab.  Returns false on failure.
+  std::shared_ptr<Slab> hostSlab(std::size_t magBytes, std::size_t rgbBytes) {
+    auto slab = std::make_shared<Slab>();
+    slab->block = pool.acquire(magBytes + rgbBytes);
+    if (!slab->block.p) return nullptr;
+    slab->pool = &pool;
+    char *base = static_cast<char *>(slab->block.p);
+    if (magBytes) slab->mags = reinterpret_cast<float *>(base);
+    if (rgbBytes) slab->rgb = reinterpret_cast<unsigned char *>(base + magBytes);
+    return slab;
+  }
+
+  // Makes room for `bytes` more device rows: forgets batches nobody refers to any more, then drops the oldest ones.
+  void reserveDevice(std::size_t bytes) {
+    std::lock_guard<std::mutex> lk(mu);  // `rows` of a batch is read under mu by getSpec / requestTexView
+    for (auto it = devBatches.begin(); it != devBatches.end();) {
+      if (auto b = it->lock(); b && b->rows) {
+        ++it;
+      } else {
+        it = devBatches.erase(it);
+      }
+    }
+    devBytes = 0;
+    for (const auto &w : devBatches)
+      if (auto b = w.lock()) devBytes += b->bytes;
+    while (!devBatches.empty() && devBytes + bytes > devBudget) {
+      if (auto b = devBatches.front().lock()) {
+        devBytes -= b->bytes;
+        b->drop();
+      }
+      devBatches.pop_front();
+    }
+  }
+
+  // One launch for `keys`: magnitudes and/or texels (k != 0) into one pooled slab; the magnitude rows also stay on
+  // the device when the budget has room for them.  Returns false on failure.
   bool compute(const std::vector<Range> &keys, bool wantMags, float k, std::vector<int32_t> &flat) {
     const std::size_t bins = static_cast<std::size_t>(N) / 2, n = keys.size();
     flat.clear();
@@ -119,55 +183,127 @@ struct Spec::Impl {
       flat.push_back(r.second);
     }
     const bool wantRgb = k != 0.f;
-    const std::size_t magBytes = wantMags ? n * bins * sizeof(float) : 0;
-    const std::size_t rgbBytes = wantRgb ? n * bins * 3 : 0;
-    auto slab = std::make_shared<Slab>();
-    slab->block = pool.acquire(magBytes + rgbBytes);
-    if (!slab->block.p) return false;
-    slab->pool = &pool;
-    char *base = static_cast<char *>(slab->block.p);
-    if (wantMags) slab->mags = reinterpret_cast<float *>(base);
-    if (wantRgb) slab->rgb = reinterpret_cast<unsigned char *>(base + magBytes);
+    auto slab = hostSlab(wantMags ? n * bins * sizeof(float) : 0, wantRgb ? n * bins * 3 : 0);
+    if (!slab) return false;
     const auto count = static_cast<int64_t>(n);
+    const std::size_t keepBytes = n * bins * sizeof(float);
+    std::shared_ptr<DevBatch> dev;
     int rc;
-    if (wantRgb) rc = mx_stft_ranges_rgb_mags(ctx, audio, N, flat.data(), count, k, slab->mags, slab->rgb);  // mags may be null
-    else rc = mx_stft_ranges(ctx, audio, N, flat.data(), count, -1, -1, slab->mags, nullptr);
+    if (keepBytes <= devBudget) {
+      reserveDevice(keepBytes);
+      mx_rows *kept = nullptr;
+      rc = mx_stft_ranges_keep(ctx, audio, N, flat.data(), count, k, slab->mags, slab->rgb, &kept);
+      if (rc == MX_OK) {
+        dev = std::make_shared<DevBatch>();
+        dev->ctx = ctx;
+        dev->rows = kept;
+        dev->bytes = keepBytes;
+        devBatches.push_back(dev);
+        devBytes += keepBytes;
+      }
+    } else if (wantRgb) {
+      rc = mx_stft_ranges_rgb_mags(ctx, audio, N, flat.data(), count, k, slab->mags, slab->rgb);  // mags may be null
+    } else {
+      rc = mx_stft_ranges(ctx, audio, N, flat.data(), count, -1, -1, slab->mags, nullptr);
+    }
     if (rc != MX_OK) return false;
+    nLaunchedColumns += n;
     std::lock_guard<std::mutex> lk(mu);
     for (std::size_t i = 0; i < n; ++i)
       if (Row *slot = rows.peek(keys[i])) {  // may have been evicted meanwhile (spec.cpp:91-93)
-        slot->slab = slab;
-        slot->index = i;
-        slot->k = k;
+        if (slab->rgb) {
+          slot->tex = slab;
+          slot->texIndex = i;
+          slot->k = k;
+        }
+        if (slab->mags) {
+          slot->mag = slab;
+          slot->magIndex = i;
+        }
+        slot->dev = dev;
+        slot->devIndex = i;
+      }
+    return true;
+  }
+
+  // Columns whose magnitudes are on the device: bring the magnitudes (texels == false) or the texel rows for scale k
+  // back, one call per run of neighbouring rows of a batch.
+  struct Cached {
+    Range key;
+    std::shared_ptr<DevBatch> dev;
+    std::size_t index;
+  };
+  bool fromDevice(std::vector<Cached> &items, bool texels, float k) {
+    const std::size_t bins = static_cast<std::size_t>(N) / 2, n = items.size();
+    std::sort(items.begin(), items.end(), [](const Cached &a, const Cached &b) {
+      return a.dev.get() != b.dev.get() ? a.dev.get() < b.dev.get() : a.index < b.index;
+    });
+    auto slab = hostSlab(texels ? 0 : n * bins * sizeof(float), texels ? n * bins * 3 : 0);
+    if (!slab) return false;
+    for (std::size_t i = 0; i < n;) {
+      std::size_t j = i + 1;
+      while (j < n && items[j].dev == items[i].dev && items[j].index == items[j - 1].index + 1) ++j;
+      const auto first = static_cast<int64_t>(items[i].index), count = static_cast<int64_t>(j - i);
+      const int rc = texels ? mx_rows_colormap(ctx, items[i].dev->rows, first, count, k, slab->rgb + i * bins * 3)
+                            : mx_rows_fetch(ctx, items[i].dev->rows, first, count, slab->mags + i * bins);
+      if (rc != MX_OK) return false;
+      i = j;
+    }
+    (texels ? nRecolouredRows : nFetchedRows) += n;
+    std::lock_guard<std::mutex> lk(mu);
+    for (std::size_t i = 0; i < n; ++i)
+      if (Row *slot = rows.peek(items[i].key)) {
+        if (texels) {
+          slot->tex = slab;
+          slot->texIndex = i;
+          slot->k = k;
+        } else {
+          slot->mag = slab;
+          slot->magIndex = i;
+        }
       }
     return true;
   }
 
   void drainLoop() {
     std::vector<Range> wantM, wantT;
+    std::vector<Cached> fetchM, recolour;
     std::vector<int32_t> flat;
     while (alive) {
+      float k;
       {
         std::unique_lock<std::mutex> lk(mu);
         // the reference's worker polls every 20 ms (spec.cpp:83); this one is also woken by getSpec
         wake.wait_for(lk, std::chrono::milliseconds(20), [&] { return !pending.empty() || !alive; });
         if (pending.empty()) continue;
+        k = texScale.load();  // (read once the jobs are in: a SpecCache registers its scale before it asks for a column)
         wantM.clear();
         wantT.clear();
-        for (const auto &kv : pending) (kv.second ? wantM : wantT).push_back(kv.first);
+        fetchM.clear();
+        recolour.clear();
+        for (const auto &kv : pending) {
+          // keys only SpecCache asked for leave the device as texel rows alone (3 B per bin instead of 7); with no
+          // colour scale registered there is nothing but magnitudes to compute
+          const bool mags = kv.second || k == 0.f;
+          const Row *row = rows.peek(kv.first);
+          if (row && row->onDevice()) {  // the transform of this column is still on the device
+            if (mags) {
+              if (!row->mag) fetchM.push_back({kv.first, row->dev, row->devIndex});
+            } else if (!row->tex || row->k != k) {
+              recolour.push_back({kv.first, row->dev, row->devIndex});
+            }
+          } else {
+            (mags ? wantM : wantT).push_back(kv.first);
+          }
+        }
         pending.clear();
       }
       if (!usable()) continue;  // no device: every column stays empty (the reference's failure mode)
       const bool trace = std::getenv("MELONIX_TIMING") != nullptr;
       const auto t0 = std::chrono::steady_clock::now();
-      const float k = texScale.load();
-      // keys only SpecCache asked for leave the device as texel rows alone (3 B per bin instead of 7); with no
-      // colour scale registered there is nothing but magnitudes to compute
-      if (k == 0.f) {
-        wantM.insert(wantM.end(), wantT.begin(), wantT.end());
-        wantT.clear();
-      }
       bool ok = true;
+      if (!fetchM.empty()) ok = fromDevice(fetchM, false, 0.f) && ok;
+      if (!recolour.empty()) ok = fromDevice(recolour, true, k) && ok;
       if (!wantT.empty()) ok = compute(wantT, false, k, flat) && ok;
       if (!wantM.empty()) ok = compute(wantM, true, k, flat) && ok;
       if (!ok) {
@@ -180,13 +316,16 @@ struct Spec::Impl {
           for (const std::vector<Range> *v : {&wantT, &wantM})
             for (const Range &r : *v)
               if (const Row *slot = rows.peek(r))
-                if (!slot->slab) rows.erase(r);
+                if (!slot->computed()) rows.erase(r);
         }
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
       if (trace)
-        fprintf(stderr, "Spec worker: %zu texel-only + %zu magnitude columns, %.2f ms\n", wantT.size(), wantM.size(),
+        fprintf(stderr, "Spec worker: %zu texel-only + %zu magnitude columns computed, %zu rows fetched, %zu re-coloured, %.2f ms\n",
+                wantT.size(), wantM.size(), fetchM.size(), recolour.size(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      fetchM.clear();  // (the batches these refer to may be released as soon as their columns are evicted)
+      recolour.clear();
     }
   }
 };
@@ -202,13 +341,16 @@ Spec::Spec(std::span<float> wav, int fftSize, int device) : impl(std::make_uniqu
     // What the reference's constructor spends on fftw_plan_dft_1d(..., FFTW_MEASURE) (spec.cpp:11-15) goes here
     // into: the tables and the kernel's code object (one throw-away column), and a screen's worth (1280 columns)
     // of page-locked landing memory — so that the first cold screen costs what every later one costs.
+    // (two screens: a re-coloured screen lands in a second block while the columns still view the first)
     const std::size_t bins = static_cast<std::size_t>(impl->N) / 2;
     Impl::Pool::Block warm = impl->pool.acquire(std::size_t(1280) * bins * 3);
+    Impl::Pool::Block warm2 = impl->pool.acquire(std::size_t(1280) * bins * 3);
     if (warm.p) {
       const int32_t one[2] = {0, 1};
       mx_stft_ranges_rgb(impl->ctx, impl->audio, impl->N, one, 1, 1.0f, static_cast<uint8_t *>(warm.p));
-      impl->pool.release(warm);
     }
+    impl->pool.release(warm);
+    impl->pool.release(warm2);
   }
   impl->worker = std::thread([p = impl.get()] { p->drainLoop(); });  // started last: all state exists
 }
@@ -230,21 +372,22 @@ auto Spec::getSpec(int start, int end) const -> std::vector<float> {
   const Range key{start, end};
   std::lock_guard<std::mutex> lk(impl->mu);
   if (const Impl::Row *row = impl->rows.touch(key)) {  // a copy; {} while the row is still being computed
-    if (!row->slab) {
+    if (row->mag) {
+      const std::size_t bins = static_cast<std::size_t>(impl->N) / 2;
+      const float *p = row->mag->mags + row->magIndex * bins;
+      return std::vector<float>(p, p + bins);
+    }
+    if (!row->computed()) {
       auto it = impl->pending.find(key);
       if (it != impl->pending.end()) it->second = true;  // still queued: now the magnitudes are wanted too
       return {};
     }
-    if (!row->slab->mags) {
-      // only the texel row of this column was brought back so far (SpecCache was its only consumer): fetch the
-      // magnitudes now, answering {} until they are there — getSpec never blocks on compute (spec.cpp:28,41)
-      impl->pending[key] = true;
-      impl->wake.notify_one();
-      return {};
-    }
-    const std::size_t bins = static_cast<std::size_t>(impl->N) / 2;
-    const float *p = row->slab->mags + row->index * bins;
-    return std::vector<float>(p, p + bins);
+    // only the texel row of this column was brought back so far (SpecCache was its only consumer): the worker copies
+    // the magnitudes from the device row (or computes them again if that was released), answering {} until they are
+    // there — getSpec never blocks on the device (spec.cpp:28,41)
+    impl->pending[key] = true;
+    impl->wake.notify_one();
+    return {};
   }
   impl->enqueueLocked(key, true);
   return {};
@@ -255,9 +398,9 @@ void Spec::setTexScale(float k) { impl->texScale = k; }
 bool Spec::getTexRow(int start, int end, float k, std::vector<unsigned char> &rgb) const {
   std::lock_guard<std::mutex> lk(impl->mu);
   const Impl::Row *row = impl->rows.peek(Range{start, end});
-  if (!row || !row->slab || !row->slab->rgb || row->k != k) return false;
+  if (!row || !row->tex || row->k != k) return false;
   const std::size_t nb = static_cast<std::size_t>(impl->N) / 2 * 3;
-  const unsigned char *p = row->slab->rgb + row->index * nb;
+  const unsigned char *p = row->tex->rgb + row->texIndex * nb;
   rgb.assign(p, p + nb);
   return true;
 }
@@ -273,10 +416,11 @@ int Spec::requestTexView(int start, int end, float k, TexView &view) const {
   const Range key{start, end};
   std::lock_guard<std::mutex> lk(impl->mu);
   if (const Impl::Row *row = impl->rows.touch(key)) {
-    if (!row->slab) return 0;
-    if (!row->slab->rgb || row->k != k) {
-      if (row->slab->mags) return 2;  // the caller colours the getSpec row itself, as the reference does
-      // texels of another scale and no magnitudes on the host: compute this column's texels again with k
+    if (!row->computed()) return 0;
+    if (!row->tex || row->k != k) {
+      if (row->mag) return 2;  // the caller colours the getSpec row itself, as the reference does
+      // texels of another scale and no magnitudes on the host: the worker re-colours the device row with k (or
+      // computes the column again if that was released)
       if (impl->pending.find(key) == impl->pending.end()) {
         impl->pending[key] = false;
         impl->wake.notify_one();
@@ -284,9 +428,9 @@ int Spec::requestTexView(int start, int end, float k, TexView &view) const {
       return 0;
     }
     const std::size_t nb = static_cast<std::size_t>(impl->N) / 2 * 3;
-    view.data = row->slab->rgb + row->index * nb;
+    view.data = row->tex->rgb + row->texIndex * nb;
     view.bytes = nb;
-    view.keep = row->slab;  // the bytes stay valid for as long as the caller holds this
+    view.keep = row->tex;  // the bytes stay valid for as long as the caller holds this
     return 1;
   }
   impl->enqueueLocked(key, false);  // the same bookkeeping as getSpec's miss path (spec.cpp:30-41)
@@ -296,4 +440,8 @@ int Spec::requestTexView(int start, int end, float k, TexView &view) const {
 std::size_t Spec::cachedRows() const {
   std::lock_guard<std::mutex> lk(impl->mu);
   return impl->rows.size();
+}
+
+Spec::Stats Spec::stats() const {
+  return {impl->nLaunchedColumns.load(), impl->nFetchedRows.load(), impl->nRecolouredRows.load()};
 }

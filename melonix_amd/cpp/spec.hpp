@@ -11,8 +11,10 @@
 // Observable difference: one GPU launch drains the WHOLE pending set (the reference computes one
 // column per worker iteration, spec.cpp:68-97), so a cold 1280-column view fills within a vsync or
 // two instead of ~0.5 s.  Columns that only SpecCache has asked for come back from the device as
-// RGB8 texel rows alone (3 bytes per bin instead of 4 + 3); their magnitudes are computed on the
-// first getSpec of that key, which answers {} until they are there — the same contract as a first touch.  Without a usable MI355X the object still constructs and every column
+// RGB8 texel rows alone (3 bytes per bin instead of 4 + 3); the magnitude rows of every launch stay in HBM
+// (a device-side row cache under a byte budget, MELONIX_SPEC_DEVICE_MB, default 1024), so the first getSpec of such a
+// key is a device-to-host copy and a changed colour scale re-colours the cached rows without another transform; getSpec
+// answers {} until the row is there — the same contract as a first touch.  Without a usable MI355X the object still constructs and every column
 // simply stays empty — the reference's own failure mode (black columns), there is no CPU path.
 #pragma once
 #include <cstddef>
@@ -54,6 +56,12 @@ public:
   };
   int requestTexView(int start, int end, float k, TexView &view) const;
   std::size_t cachedRows() const;  // keys currently held (<= MaxRanges), computed or not
+  // What the worker has done so far: columns that went through the transform, magnitude rows copied back from the
+  // device-side row cache, texel rows re-coloured from it (no transform for the last two).
+  struct Stats {
+    unsigned long long computedColumns, fetchedRows, recolouredRows;
+  };
+  Stats stats() const;
 
   int fftSize() const;
   bool ok() const;  // false when no MI355X context / upload failed

@@ -107,6 +107,10 @@ int main(int argc, char **argv) {
     }
     dump(out + "/tex.u8", texels);
     dump(out + "/texrows.f32", texrows);
+    // the four texel-only columns' magnitudes came out of the device-side row cache: copies, not second transforms
+    const Spec::Stats st = spec.stats();
+    check(st.computedColumns == keys.size() + 4, "each column went through the transform once");
+    check(st.fetchedRows == 4, "late getSpec of texel-only columns = device-to-host copies of the cached rows");
     const int before = g_live;
     cache.clear();
     check(g_live == before - 4, "clear() releases the textures");
@@ -129,6 +133,39 @@ int main(int argc, char **argv) {
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     check(filled == 1280, "cold screen fills");
     printf("cold_screen: N=%d 1280 columns filled after %d draw passes, %.1f ms\n", N, frames, ms);
+    // the user turns the brightness (app.cpp:75: a new SpecCache with another k, app.cpp:881-884): the columns'
+    // magnitude rows are still on the device, so the screen is re-coloured without a single transform
+    const Spec::Stats before = spec.stats();
+    SpecCache brighter(spec, 512.f * 128, 1280, 10.0, [&](double v) { return (int)(v * sr); });
+    const auto t1 = std::chrono::steady_clock::now();
+    for (frames = 0, filled = 0; frames < 1000 && filled < 1280; ++frames) {
+      filled = 0;
+      for (int x = 0; x < 1280; ++x) {
+        const GLuint name = brighter.getTex((x + 0.5) * 10.0 / 1280);
+        filled += g_tex[name].size() == (size_t)N / 2 * 3;
+      }
+      if (filled < 1280) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    const double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    const Spec::Stats after = spec.stats();
+    check(filled == 1280, "re-coloured screen fills");
+    check(after.computedColumns == before.computedColumns, "a changed brightness costs no transform");
+    check(after.recolouredRows - before.recolouredRows == 1280, "every column re-coloured from its cached device row");
+    printf("recolour_screen: N=%d 1280 columns after %d draw passes, %.1f ms\n", N, frames, ms2);
+    {  // one of them against the reference's UI-thread colormap of its magnitudes (fetched from the device row)
+      const double left = 640 * 10.0 / 1280;
+      const int s0 = (int)(left * sr), e0 = (int)((left + 10.0 / 1280) * sr);
+      std::vector<float> r;
+      for (int spin = 0; spin < 2000 && r.empty(); ++spin) {
+        r = spec.getSpec(s0, e0);
+        if (r.empty()) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
+      check(r.size() == (size_t)N / 2, "magnitudes of a re-coloured column arrive");
+      std::vector<unsigned char> hostc(r.size() * 3), fused;
+      melonixColormap(r.data(), r.size(), 512.f * 128, hostc.data());
+      check(spec.getTexRow(s0, e0, 512.f * 128, fused) && fused == hostc, "re-coloured texels == colormap of the row");
+      check(spec.stats().computedColumns == before.computedColumns, "... still without a transform");
+    }
   }
 
   if (N == 4096) {  // LRU eviction at MaxRanges in both caches (range.hpp:4, spec.cpp:33-40, spec-cache.cpp:26-49)

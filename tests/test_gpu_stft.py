@@ -289,3 +289,30 @@ def test_circular_window_equals_cpu_emulation(gpu_ctx, emu, N, E, hop):
         d = np.abs(mags[first:first + count] - out)
         assert (d <= 2 * ulp).all(), float((d / ulp).max())
     a.free()
+
+
+@pytest.mark.parametrize("N", [4096, 32768])
+def test_kept_rows(gpu_ctx, oracle, mxlib, N):
+    """mx_stft_ranges_keep / mx_rows_*: the rows that stay on the device are the plain ranges call's bit for bit, a span
+    fetched later equals them, and re-colouring a span with another scale equals the oracle's colormap of those rows."""
+    w = noisy(accum_sweep(3 * SR))
+    a = gpu_ctx.upload(w)
+    cols = np.array([(i * 375, (i + 1) * 375) for i in range(0, 300, 3)] + [(-500, -100), (5000, 4000)], dtype=np.int32)
+    ref = gpu_ctx.stft_ranges(a, N, cols)[0]
+    rows, rgb, mags = gpu_ctx.stft_ranges_keep(a, N, cols, k=2.0 ** 14, want_mags=True)
+    assert len(rows) == len(cols)
+    assert np.array_equal(mags, ref)
+    assert np.array_equal(rgb, gpu_ctx.stft_ranges_rgb(a, N, cols, 2.0 ** 14))
+    assert np.array_equal(rows.fetch(0, len(cols)), ref)
+    assert np.array_equal(rows.fetch(17, 5), ref[17:22])
+    again = rows.colormap(40, 9, 2.0 ** 16)
+    assert np.array_equal(again, np.stack([oracle.colormap(ref[i], 2.0 ** 16) for i in range(40, 49)]))
+    rows2, rgb2, mags2 = gpu_ctx.stft_ranges_keep(a, N, cols[:7])  # nothing comes back: rows only
+    assert rgb2 is None and mags2 is None and np.array_equal(rows2.fetch(0, 7), ref[:7])
+    with pytest.raises(mxlib.MxError):
+        rows.fetch(len(cols) - 1, 2)
+    with pytest.raises(mxlib.MxError):
+        rows.colormap(-1, 1, 1.0)
+    rows.free()
+    rows2.free()
+    a.free()
