@@ -17,6 +17,23 @@ MX_AUDIO_PAD = 32768
 FRAME_ALIGN = 32
 
 
+def frame_align(N: int, hop: int) -> int:
+    """Frames a shard boundary must be a multiple of for the shard's rows to be the unsharded run's bit for bit: the run
+    length above and, for the circular-window kernels (N = 16384 / 32768, hops up to 512 samples that are not a multiple of
+    one slot = N/32 samples), a whole number of slots — their register image starts at the last slot boundary at or before
+    the frame, counted from the image's first sample, so a shard has to start on one for its rotations (hence its
+    roundings) to be the unsharded run's."""
+    from math import gcd
+
+    a = FRAME_ALIGN
+    if N in (16384, 32768) and 1 <= hop <= 512:
+        slot = N // 32
+        if hop % slot:
+            per = slot // gcd(hop, slot)  # frames after which the frame start is back on a slot boundary
+            a = a * per // gcd(a, per)
+    return a
+
+
 @dataclass(frozen=True)
 class FrameShard:
     rank: int
@@ -36,9 +53,11 @@ def frame_count(n: int, hop: int) -> int:
     return (n + hop - 1) // hop
 
 
-def shard_frames(n: int, N: int, hop: int, rank: int, world: int, align: int = FRAME_ALIGN) -> FrameShard:
-    """Contiguous frame ranges, equal up to the alignment: every boundary is a multiple of `align` frames (the last
-    rank takes what is left, at most world*align frames less than the others)."""
+def shard_frames(n: int, N: int, hop: int, rank: int, world: int, align: int | None = None) -> FrameShard:
+    """Contiguous frame ranges, equal up to the alignment: every boundary is a multiple of `align` frames (default:
+    frame_align(N, hop); the last rank takes what is left, at most world*align frames less than the others)."""
+    if align is None:
+        align = frame_align(N, hop)
     F = frame_count(n, hop)
     per = -(-F // world)            # ceil(F / world)
     per = -(-per // align) * align  # rounded up to the kernel's run length

@@ -92,16 +92,21 @@ def test_two_rank_shards_equal_unsharded(oracle, N, hop, n):
 def test_shard_arithmetic():
     from melonix_amd import shard as sh
 
-    for n, N, hop in ((172_800_000, 4096, 256), (1000, 4096, 256), (480_000, 32768, 375), (7, 4096, 3)):
+    assert sh.frame_align(4096, 375) == 32 and sh.frame_align(32768, 1024) == 32 and sh.frame_align(32768, 600) == 32
+    assert sh.frame_align(32768, 375) == 1024 and sh.frame_align(32768, 512) == 32 and sh.frame_align(16384, 375) == 512
+    assert (sh.frame_align(32768, 375) * 375) % 1024 == 0 and (sh.frame_align(16384, 100) * 100) % 512 == 0
+    for n, N, hop in ((172_800_000, 4096, 256), (1000, 4096, 256), (480_000, 32768, 375), (7, 4096, 3),
+                      (172_800_000, 32768, 375), (20_000_000, 16384, 375)):
         F = sh.frame_count(n, hop)
+        AL = sh.frame_align(N, hop)
         for world in (1, 2, 3, 4, 8):
             parts = [sh.shard_frames(n, N, hop, r, world) for r in range(world)]
             assert parts[0].lo == 0 and parts[-1].hi == F
             assert all(a.hi == b.lo for a, b in zip(parts, parts[1:]))
             # boundaries on multiples of the kernel's run length (bit-identical rows sharded or not), near-equal sizes
-            assert all(p.lo % sh.FRAME_ALIGN == 0 or p.lo == F for p in parts) and sum(p.frames for p in parts) == F
-            if F >= world * world * sh.FRAME_ALIGN:
-                assert max(p.frames for p in parts) - min(p.frames for p in parts) <= world * sh.FRAME_ALIGN
+            assert all(p.lo % AL == 0 or p.lo == F for p in parts) and sum(p.frames for p in parts) == F
+            if F >= world * world * AL:
+                assert max(p.frames for p in parts) - min(p.frames for p in parts) <= world * AL
             assert all(p.sample_lo == p.lo * hop and p.halo_left == min(N - hop, p.sample_lo) for p in parts)
     for nsteps in (0, 1, 7, 137_000):
         for world in (1, 2, 8):

@@ -222,6 +222,23 @@ def test_eight_shards_on_one_device_equal_unsharded_8h():
     assert "shard8_check ok" in r.stdout
 
 
+@pytest.mark.parametrize("N,hop,world,hours", [(32768, 375, 2, 0.3), (16384, 375, 3, 0.25), (32768, 512, 2, 0.4)])
+def test_shards_of_circular_window_kernels_equal_unsharded(N, hop, world, hours):
+    """The circular-window kernels round by where a frame starts inside a slot of the device image: `shard_frames` puts
+    shard boundaries on whole slots (frame_align), so shards run on their own images are still the unsharded run bit for
+    bit — every row and the pitch track (same checker as the 8 h test, its own process for the same reason).  (Sizes: every
+    shard long enough for full-length runs — 2048 workgroups of 32 / 16 frames — as in any real sharded job.)"""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "tools", "shard8_check.py"), str(hours), str(N), str(hop), str(world)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "shard8_check ok" in r.stdout
+
+
 def test_pv_more_than_2M_frames(gpu_ctx, hour):
     """+24 semitones over the hour is 2.7 M analysis frames: the boundary fix-up kernel used to put one block row per
     32 frames on gridDim.y (capped at 65 535, i.e. 2.1 M frames) and the call failed after all the work was done."""

@@ -25,9 +25,8 @@ from oracle import pyoracle as O  # noqa: E402
 SR = 48000
 
 
-def main(hours: float = 8.0):
+def main(hours: float = 8.0, N: int = 4096, HOP: int = 256, world: int = 8):
     dev = torch.device("cuda", 0)
-    N, HOP, world = 4096, 256, 8
     n = int(hours * 60 * 60 * SR)
     pad = mx.MX_AUDIO_PAD
     F = mx.frame_count(n, HOP)
@@ -41,7 +40,7 @@ def main(hours: float = 8.0):
     ctx.stft_hop_dev(whole, N, HOP, 0, F, mags.data_ptr(), pitch.data_ptr(), band=band)
     torch.cuda.synchronize()
     parts = [sh.shard_frames(n, N, HOP, r, world) for r in range(world)]
-    assert parts[0].lo == 0 and parts[-1].hi == F and all(p.lo % sh.FRAME_ALIGN == 0 for p in parts)
+    assert parts[0].lo == 0 and parts[-1].hi == F and all(p.lo % sh.frame_align(N, HOP) == 0 or p.lo == F for p in parts)
     track = []
     smags = torch.empty((max(p.frames for p in parts), N // 2), dtype=torch.float32, device=dev)
     for p in parts:
@@ -50,6 +49,8 @@ def main(hours: float = 8.0):
         g0 = p.sample_lo - pad
         lo_s, hi_s = max(g0, 0), min(p.sample_hi + pad, n)
         img[lo_s - g0: hi_s - g0] = whole_t[pad + lo_s: pad + hi_s]       # neighbours in the pads, zeros beyond the signal
+        if p.frames == 0:
+            continue
         assert p.rank == 0 or p.halo_left == N - HOP
         a = ctx.wrap_device(img.data_ptr(), own, keepalive=img)
         sp = torch.empty((p.frames, 2), dtype=torch.int32, device=dev)
@@ -61,7 +62,7 @@ def main(hours: float = 8.0):
         a.free()
         del img
     assert torch.equal(torch.cat(track), pitch), "concatenated pitch track differs"
-    pick = sorted({0, 1, 17, F - 1, F // 3} | {p.lo for p in parts[1:]} | {p.lo - 1 for p in parts[1:]})
+    pick = sorted({0, 1, 17, F - 1, F // 3} | {p.lo for p in parts[1:] if p.frames} | {p.lo - 1 for p in parts[1:] if p.frames})
     got = mags[torch.tensor(pick, device=dev)].cpu().numpy()
     worst = 0.0
     for i, f in enumerate(pick):
@@ -80,4 +81,4 @@ def main(hours: float = 8.0):
 
 
 if __name__ == "__main__":
-    main(float(sys.argv[1]) if len(sys.argv) > 1 else 8.0)
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 8.0, *(int(v) for v in sys.argv[2:5]))
