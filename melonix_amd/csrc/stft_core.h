@@ -434,9 +434,6 @@ template <class P>
 struct Circ {
   static constexpr int W = 2 * P::T;                 // samples per slot
   static constexpr int CS = (P::T == 128) ? 4 : (P::T == 256) ? 3 : 2;  // slots the newest 2*hop samples can touch (incl. slot 0)
-  // whether the coming frame's samples are requested a frame ahead (after pass 3, landing under the output phase) or at
-  // the top of the frame they belong to (N = 16384: 12 more live registers across the output phase would spill)
-  static constexpr bool AHEAD = (P::T != 256);
   static MX_HD bool ok(int hop) { return hop >= 1 && hop <= (CS - 1) * P::T && hop <= 2 * W; }
   static constexpr int slot(int k) { return (P::E - (CS - 1) + k) & (P::E - 1); }  // k = 0..CS-1; the last one is slot 0
 };

@@ -69,7 +69,7 @@ struct Tune {
 
   // the circular window (stft_core.h) for the 32-points-per-thread plans, hops up to 512 samples that do not slide by
   // whole slots: N = 32768 at 375- / 512-sample columns 14.2 -> 13.0 and 10.4 -> 9.7 ms per hour, N = 16384 at 375
-  // 6.55 -> 6.15 (samples fetched at the top of their own frame there: a frame ahead, their 12 registers spill).  The
+  // 6.55 -> 6.15.  The
   // two-wave N = 4096 plan loses (1.87 against 1.70 ms) and keeps its direct loads.
   static constexpr bool CIRC = MX_CIRC && (P::E == 32);
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
