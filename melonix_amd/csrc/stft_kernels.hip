@@ -71,7 +71,7 @@ struct Tune {
   // whole slots: N = 32768 at 375- / 512-sample columns 14.2 -> 13.0 and 10.4 -> 9.7 ms per hour, N = 16384 at 375
   // 6.55 -> 6.15.  The
   // two-wave N = 4096 plan loses (1.87 against 1.70 ms) and keeps its direct loads.
-  static constexpr bool CIRC = MX_CIRC && (P::E == 32);
+  static constexpr bool CIRC = MX_CIRC && (P::N >= 16384);
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
   static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
   // with DEFER: free the image right after the T2 read, so the next T1 scatter can start under pass 1 (+1%)
