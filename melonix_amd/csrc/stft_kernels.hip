@@ -63,15 +63,10 @@ struct Tune {
   // frame: 15.4 -> 14.8 ms per hour at 375-sample columns, 5.03 -> 4.89 ms at hop 1024.  (N = 16384 measures the
   // same either way and keeps the transposition; the two-wave N = 4096 plan's row leaves in the shadow of the next frame.)
   static constexpr bool DIRECT = (P::N == 32768);
-#ifndef MX_CIRC
-#define MX_CIRC 1
-#endif
-
-  // the circular window (stft_core.h) for the 32-points-per-thread plans, hops up to 512 samples that do not slide by
-  // whole slots: N = 32768 at 375- / 512-sample columns 14.2 -> 13.0 and 10.4 -> 9.7 ms per hour, N = 16384 at 375
-  // 6.55 -> 6.15.  The
-  // two-wave N = 4096 plan loses (1.87 against 1.70 ms) and keeps its direct loads.
-  static constexpr bool CIRC = MX_CIRC && (P::N >= 16384);
+  // The circular window (stft_core.h) for N = 16384 / 32768, hops up to 512 samples that do not slide by whole slots:
+  // N = 32768 at 375- / 512-sample columns 14.2 -> 12.8 and 10.4 -> 9.5 ms per hour, N = 16384 at 375 6.55 -> 6.0.
+  // The two-wave N = 4096 plan loses with it (1.87 against 1.70 ms) and keeps its direct loads.
+  static constexpr bool CIRC = (P::N >= 16384);
   static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
   static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
   // with DEFER: free the image right after the T2 read, so the next T1 scatter can start under pass 1 (+1%)
