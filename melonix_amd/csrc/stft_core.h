@@ -504,8 +504,6 @@ MX_HD void circ_step(int t, cpx (&Y)[P::E], float decay, const CircGeo<P> &g, co
   else circ_age<P, 2>(Y, gg);
 #pragma unroll
   for (int k = 0; k < Circ<P>::CS; ++k) {
-    constexpr int dummy = 0;
-    (void)dummy;
     const int e = Circ<P>::slot(k);
     const int c2 = 2 * (t + P::T * e);
     const int d0 = (c2 - g.cr) & (P::N - 1), d1 = (c2 + 1 - g.cr) & (P::N - 1);
