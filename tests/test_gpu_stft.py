@@ -110,12 +110,16 @@ def test_hop_vs_oracle(gpu_ctx, oracle, N, hop):
     a.free()
 
 
-def test_pitch_only_and_mags_only(gpu_ctx, oracle):
+@pytest.mark.parametrize("N,hop", [(4096, 256), (32768, 375), (32768, 1024), (16384, 375), (32768, 3000)])
+def test_pitch_only_and_mags_only(gpu_ctx, oracle, N, hop):
+    """Either output alone is the same launch with the other store left out — for the sliding, circular-window,
+    register-stored-row and direct-load kernels alike."""
     w = accum_sweep(2 * SR)
     a = gpu_ctx.upload(w)
-    m, p = gpu_ctx.stft_hop(a, 4096, 256)
-    m2, none = gpu_ctx.stft_hop(a, 4096, 256, want_pitch=False)
-    none2, p2 = gpu_ctx.stft_hop(a, 4096, 256, want_mags=False)
+    band = oracle.pitch_band(N, SR)
+    m, p = gpu_ctx.stft_hop(a, N, hop, band=band)
+    m2, none = gpu_ctx.stft_hop(a, N, hop, want_pitch=False, band=band)
+    none2, p2 = gpu_ctx.stft_hop(a, N, hop, want_mags=False, band=band)
     assert none is None and none2 is None
     assert np.array_equal(m, m2) and np.array_equal(p, p2)
     a.free()
