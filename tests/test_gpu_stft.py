@@ -125,19 +125,21 @@ def test_pitch_only_and_mags_only(gpu_ctx, oracle, N, hop):
     a.free()
 
 
-def test_linearity_and_silence(gpu_ctx):
-    """Size-independent properties: |STFT(c*x)| = c*|STFT(x)| for a power-of-two c (exact in fp32),
-    silence -> zeros and pitch bin = kmin."""
+@pytest.mark.parametrize("N,hop", [(4096, 256), (32768, 375), (16384, 375), (32768, 1024)])
+def test_linearity_and_silence(gpu_ctx, oracle, N, hop):
+    """Size-independent properties: |STFT(c*x)| = c*|STFT(x)| for a power-of-two c (exact in fp32, also through the
+    multiply chains of the sliding and circular-window kernels), silence -> zeros and pitch bin = kmin."""
     w = noisy(accum_sweep(3 * SR))
     a = gpu_ctx.upload(w)
     b = gpu_ctx.upload(w * 0.25)
     z = gpu_ctx.upload(np.zeros(3 * SR, np.float32))
-    ma, pa = gpu_ctx.stft_hop(a, 4096, 256)
-    mb, pb = gpu_ctx.stft_hop(b, 4096, 256)
-    mz, pz = gpu_ctx.stft_hop(z, 4096, 256)
+    band = oracle.pitch_band(N, SR)
+    ma, pa = gpu_ctx.stft_hop(a, N, hop, band=band)
+    mb, pb = gpu_ctx.stft_hop(b, N, hop, band=band)
+    mz, pz = gpu_ctx.stft_hop(z, N, hop, band=band)
     assert np.array_equal(ma * 0.25, mb)
     assert np.array_equal(pa["bin"], pb["bin"])
-    assert not mz.any() and (pz["bin"] == 5).all() and not pz["mag"].any()
+    assert not mz.any() and (pz["bin"] == band[0]).all() and not pz["mag"].any()
     for x in (a, b, z):
         x.free()
 
