@@ -57,6 +57,153 @@ def gen_shard(torch, dev, rank: int, world: int, n: int, pad: int):
     return out
 
 
+PCG_MULT = 6364136223846793005
+M64 = (1 << 64) - 1
+
+
+def _i64(v: int) -> int:
+    v &= M64
+    return v - (1 << 64) if v >> 63 else v
+
+
+def pcg32_uniform(torch, dev, i0: int, m: int, seed: int = 0x6D656C6F, seq: int = 1):
+    """U(-1,1) doubles number i0 .. i0+m-1 of the PCG32 (XSH-RR 64/32, O'Neill's pcg32_srandom_r(seed, seq)) stream,
+    generated on the device: the LCG state of draw i is an affine function of the seed state, so a block of 2k states
+    is the block of k states times A^k plus C_k (int64 products wrap mod 2^64).  SURVEY.md §8d's noise variant."""
+    inc = ((seq << 1) | 1) & M64
+    st = ((0 * PCG_MULT + inc) + seed) & M64
+    st = (st * PCG_MULT + inc) & M64  # state before draw 0
+    a_k, c_k, k, acc_a, acc_c = PCG_MULT, inc, i0, 1, 0  # jump ahead by i0 draws
+    while k:
+        if k & 1:
+            acc_a, acc_c = (acc_a * a_k) & M64, (acc_c * a_k + c_k) & M64
+        c_k, a_k, k = (c_k * (a_k + 1)) & M64, (a_k * a_k) & M64, k >> 1
+    st = (st * acc_a + acc_c) & M64
+    S = torch.empty(m, dtype=torch.int64, device=dev)
+    S[0] = _i64(st)
+    have, a_k, c_k = 1, PCG_MULT, inc
+    while have < m:
+        take = min(have, m - have)
+        S[have:have + take] = S[:take] * _i64(a_k) + _i64(c_k)
+        c_k, a_k, have = (c_k * (a_k + 1)) & M64, (a_k * a_k) & M64, have + take
+    lsr = lambda v, b: (v >> b) & ((1 << (64 - b)) - 1)
+    x = lsr(lsr(S, 18) ^ S, 27) & 0xFFFFFFFF
+    rot = lsr(S, 59)
+    del S
+    r = ((x >> rot) | (x << ((32 - rot) & 31))) & 0xFFFFFFFF
+    return r.to(torch.float64) * (1.0 / 2147483648.0) - 1.0
+
+
+def add_noise(torch, dev, audio_t, rank: int, world: int, n: int, pad: int, level: float = 1e-3):
+    """audio_t (gen_shard's padded image, f32) += level * U(-1,1) from pcg32_uniform, draw i for sample i of the whole
+    signal; samples outside the signal stay zero."""
+    total = world * n
+    lo = max(0, rank * n - pad)
+    hi = min(total, rank * n + n + pad)
+    u = pcg32_uniform(torch, dev, lo, hi - lo)
+    off = lo - (rank * n - pad)
+    audio_t[off:off + (hi - lo)] = (audio_t[off:off + (hi - lo)].to(torch.float64) + level * u).to(torch.float32)
+
+
+class PowerSampler:
+    """Package power (W) and shader clock (MHz) of GPU 0 sampled from a thread while a load runs: amdgpu's hwmon files
+    when they exist (a read is microseconds), else `rocm-smi --showpower --showclocks --csv` (~0.1 s per sample)."""
+
+    def __init__(self, index: int = 0):
+        import glob
+
+        self.samples = []
+        self._stop = False
+        self._th = None
+        self.source = None
+        self._cands = []  # (power file, clock file) per amdgpu hwmon directory
+        want = None
+        try:  # the hwmon directory of THIS device, by PCI address (a node has eight of them)
+            import torch
+
+            pr = torch.cuda.get_device_properties(index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+        except Exception:
+            want = None
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            pw = next((os.path.join(h, nm) for nm in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, nm))), None)
+            ck = os.path.join(h, "freq1_input")
+            if pw and os.path.exists(ck):
+                real = os.path.realpath(os.path.join(h, "..", ".."))
+                self._cands.append((pw, ck, os.path.basename(real)))
+        if want:
+            hit = [c for c in self._cands if c[2].startswith(want)]
+            if hit:
+                self._cands = hit
+        if self._cands:
+            self.source = "hwmon"
+        else:
+            import shutil
+
+            self.source = "rocm-smi" if shutil.which("rocm-smi") else None
+
+    def cap_watts(self):
+        """The package power limit the driver enforces (hwmon power1_cap), None when it cannot be read."""
+        try:
+            return float(open(os.path.join(os.path.dirname(self._cands[0][0]), "power1_cap")).read()) * 1e-6
+        except Exception:
+            return None
+
+    def _read(self, c):
+        return float(open(c[0]).read()) * 1e-6, float(open(c[1]).read()) * 1e-6
+
+    def _one(self):
+        if self.source == "hwmon":
+            try:
+                if len(self._cands) > 1:  # PCI address unknown: the device under load is the one drawing the most
+                    rd = [self._read(c) for c in self._cands]
+                    return max(rd)
+                return self._read(self._cands[0])
+            except Exception:
+                return None
+        import subprocess
+
+        try:
+            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True,
+                                 timeout=10).stdout
+            rows = [l.split(",") for l in out.strip().split("\n") if l.startswith(("device", "card0"))]
+            d = dict(zip(rows[0], rows[1]))
+            pw = [float(v) for k, v in d.items() if "Power" in k and v not in ("", "N/A")]
+            ck = [v for k, v in d.items() if k.startswith("sclk clock speed")]
+            return pw[0], float(ck[0].strip("()Mhz"))
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop:
+            s = self._one()
+            if s is not None:
+                self.samples.append(s)
+            if self.source == "hwmon":
+                time.sleep(0.005)
+
+    def __enter__(self):
+        if self.source:
+            import threading
+
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th:
+            self._th.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        q = len(self.samples) // 4
+        mid = self.samples[q:len(self.samples) - q] or self.samples
+        return {"watts": float(np.median([p for p, _ in mid])), "sclk_mhz": float(np.median([c for _, c in mid])),
+                "watts_max": float(max(p for p, _ in self.samples)), "samples": len(self.samples), "source": self.source}
+
+
 def kernel_source_hash() -> str:
     """sha1 over the STFT kernel's sources: ties a PMC traffic figure under profiles/ to the kernel it was measured on."""
     import hashlib
@@ -157,6 +304,8 @@ def main() -> None:
     ap.add_argument("--no-resynth", action="store_true",
                     help="STFT+pitch only in the timed step (configs[1] alone) and no supplementary measurements")
     ap.add_argument("--no-supplementary", action="store_true", help="skip the end-to-end and phase-vocoder extras")
+    ap.add_argument("--no-noise-secondary", action="store_true", help="skip the noise-input secondary")
+    ap.add_argument("--no-limiter-probe", action="store_true", help="skip the power / clock sample behind roofline.limiter")
     args = ap.parse_args()
 
     import torch
@@ -249,10 +398,40 @@ def main() -> None:
         works.append(dist.all_gather_into_tensor(gathered[k & 1], pitch_t[k & 1], async_op=True)
                      if use_dist else None)
 
-    # Device conditioning (setup, like the schedule build above): a fresh box needs some tens of milliseconds of the
+    def timed_region(steps: int, warmup: int):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize pairs; HIP events (torch events on
+        the stream the kernels are launched on) around each launch.  Returns (seconds max over ranks, STFT ms, resynth ms)."""
+        works = []
+        for k in range(warmup):
+            step(k, works)
+        for wk in works[-2:]:
+            if wk is not None:
+                wk.wait()
+        barrier()
+        ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(steps)]
+        works = []
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k, works, ev[k])
+        for wk in works[-2:]:
+            if wk is not None:
+                wk.wait()
+        barrier()
+        el = time.perf_counter() - t0
+        k_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        r_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if rs is not None else 0.0
+        red = torch.tensor([el, k_ms, r_ms], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        return float(red[0].item()), float(red[1].item()), float(red[2].item())
+
+    # (1) the contract as written, on the box as it comes: W warm-up steps, K timed steps -> `value_no_conditioning`
+    elapsed_nc, kern_ms_nc, res_ms_nc = timed_region(args.steps, args.warmup)
+
+    # (2) Device conditioning (setup, like the schedule build above): a fresh box needs some tens of milliseconds of the
     # actual load before its memory / fabric clocks and the power manager settle — the first ~25 launches of this step
-    # run 2-10 % slower than the steady state a sustained job sees (measured: 2.03 vs 1.98 ms per step with 5 against 40
-    # steps in front of the timed region).  These steps are untimed and come BEFORE the W warm-up steps of the contract.
+    # run 2-10 % slower than the steady state a sustained job sees.  These steps are untimed; the W warm-up steps and the
+    # K timed steps of the contract follow them -> `value` (both figures are in the line).
     works = []
     for k in range(args.conditioning):
         step(k, works)
@@ -260,45 +439,24 @@ def main() -> None:
         if wk is not None:
             wk.wait()
     barrier()
-
-    works = []
-    for k in range(args.warmup):
-        step(k, works)
-    for wk in works[-2:]:
-        if wk is not None:
-            wk.wait()
-    barrier()
-
-    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
-    works = []
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, works, ev[k])
-    for wk in works[-2:]:
-        if wk is not None:
-            wk.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    res_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if rs is not None else 0.0
-    k_max = torch.tensor([kern_ms, res_ms], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
-    kern_ms, res_ms = float(k_max[0].item()), float(k_max[1].item())
+    elapsed, kern_ms, res_ms = timed_region(args.steps, args.warmup)
 
     # sanity: the last step produced a plausible pitch track (guards against a silently skipped kernel)
-    bins = pitch_t[(args.steps - 1) & 1][:, 0]
+    bins = pitch_t[(args.steps - 1) & 1][:, 0].clone()
     ok = bool(((bins >= band[0]) & (bins <= band[1])).all().item())
+    exchange = None
     if use_dist:  # the gathered whole-signal track must contain this rank's shard, bit for bit
         g = gathered[(args.steps - 1) & 1]
-        ok = ok and bool(torch.equal(g[rank * F:(rank + 1) * F], pitch_t[(args.steps - 1) & 1]))
-        okt = torch.tensor([1 if ok else 0], device=dev)
+        g_ok = bool(torch.equal(g[rank * F:(rank + 1) * F], pitch_t[(args.steps - 1) & 1]))
+        ok = ok and g_ok
+        okt = torch.tensor([1 if ok else 0, 1 if g_ok else 0], device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok = bool(okt.item())
+        ok, g_ok = bool(okt[0].item()), bool(okt[1].item())
+        exchange = {"backend": dist.get_backend(), "collective": "all_gather_into_tensor", "async_op": True,
+                    "bytes_per_rank": int(pitch_t[0].numel() * 4), "world_size": world,
+                    "gathered_equals_local": g_ok,
+                    "note": "per-rank pitch tracks (8 B/frame) stitched into the whole-signal track on RCCL's stream, "
+                            "double-buffered against the next step's kernels"}
 
     if rs is not None:  # the resynthesis leg produced a plausible PCM stream (guards against a skipped kernel)
         tail_ok = not bool(rs["pcm"][-1500:].any().item())
@@ -353,6 +511,53 @@ def main() -> None:
         except Exception as exc:  # never let a supplementary figure take the headline line down
             pv = {"error": str(exc)}
 
+    # the limiter evidence behind `roofline.frac`: package power and shader clock sampled while the very same step runs
+    # back to back for about a second (the K timed steps alone are over in tens of milliseconds)
+    limiter = None
+    if not args.no_limiter_probe:
+        reps = int(min(2000, max(50, np.ceil(1.2 / max(elapsed / args.steps, 1e-5)))))
+        with PowerSampler(local_rank) as ps:
+            works = []
+            for k in range(reps):
+                step(k, works)
+            for wk in works[-2:]:
+                if wk is not None:
+                    wk.wait()
+            barrier()
+        sm = ps.summary()
+        if sm is not None:
+            cap = ps.cap_watts() or 1400.0
+            limiter = {"kind": "package_power" if sm["watts"] >= 0.95 * cap else "not_power",
+                       "watts": sm["watts"], "watts_max": sm["watts_max"], "cap_watts": cap, "sclk_mhz": sm["sclk_mhz"],
+                       "sclk_nominal_mhz": 2400.0, "samples": sm["samples"], "source": sm["source"],
+                       "load": f"{reps} more steps of the timed workload, back to back, sampled from a host thread"}
+
+    # labelled secondary (SURVEY 8d's optional variant): the same step on sweep + 1e-3 * U(-1,1) from PCG32 — a kernel at
+    # the package power limit takes longer on data that toggles more wires; the grain table and the schedule are rebuilt
+    # for the noisy signal, the timed region is the same W + K steps
+    noise = None
+    if not args.no_noise_secondary:
+        try:
+            add_noise(torch, dev, audio_t, rank, world, n, pad)
+            torch.cuda.synchronize()
+            if rs is not None:
+                gs, gl, gf = ctx.grain_table_dev(audio)
+                mk = [(1, 0, 0, 3.0), (n - 1, 0, 0, 3.0)]
+                steps_arr, total, _ = mx.schedule_build_table(n, SR, gs, gl, gf, mk)
+                rs["steps"], rs["total"] = steps_arr, int(total)
+                rs["d_steps"] = torch.from_numpy(steps_arr.view(np.uint8).copy()).to(dev)
+                rs["pcm"] = torch.empty(total, dtype=torch.int16, device=dev)
+            el_n, k_n, r_n = timed_region(args.steps, args.warmup)
+            nb = pitch_t[(args.steps - 1) & 1][:, 0]
+            noise = {"value": world * F * args.steps / el_n, "ms_per_step": el_n / args.steps * 1e3, "stft_kernel_ms": k_n,
+                     "resynth_kernel_ms": r_n, "stft_frac": b_alg(N, hop, mags=not args.pitch_only) * F / (k_n * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "pitch_bins_equal_clean": float((nb == bins).float().mean().item()),
+                     "process_steps": int(len(rs["steps"])) if rs is not None else None,
+                     "input": "the workload sweep + 1e-3 * U(-1,1), PCG32 XSH-RR (pcg32_srandom_r(0x6d656c6f, 1)), draw i for sample i",
+                     "vs_clean": (world * F * args.steps / el_n) / (world * F * args.steps / elapsed)}
+        except Exception as exc:
+            noise = {"error": str(exc)}
+
     if rank == 0:
         balg = b_alg(N, hop, mags=not args.pitch_only)
         achieved = balg * F / (kern_ms * 1e-3) / 1e9
@@ -390,6 +595,9 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "conditioning_steps": args.conditioning,
+            # the same W + K region on the box as it came, before the conditioning steps (the contract with nothing added)
+            "value_no_conditioning": world * F * args.steps / elapsed_nc,
+            "ms_per_step_no_conditioning": elapsed_nc / args.steps * 1e3,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
@@ -417,6 +625,8 @@ def main() -> None:
                 "kernel": f"stft_kernel<{N}>",
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_frame": balg,
+                # why the fraction is what it is: what the package drew and where the shader clock sat under this load
+                "limiter": limiter,
             },
             "kernels": kernels,
             # labelled secondary: BASELINE configs[1] alone (what round 1 quoted as `value`)
@@ -427,6 +637,10 @@ def main() -> None:
             line["resynth_setup"] = {"grain_scan_s": rs["grain_scan_s"], "grain_scan_warm_s": rs["grain_scan_warm_s"],
                                      "schedule_host_s": rs["schedule_host_s"],
                                      "note": "once per (audio, markers), before the timed region"}
+        if exchange is not None:
+            line["exchange"] = exchange
+        if noise is not None:
+            line["noise_input_secondary"] = noise
         if pv is not None:
             line["phase_vocoder_supplementary"] = pv
         if e2e is not None:
