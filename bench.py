@@ -347,6 +347,10 @@ def main() -> None:
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.frames_per_block:
         ctx.set_frames_per_block(args.frames_per_block)
+    elif world > 1:
+        from melonix_amd import shard as _sh
+
+        _sh.pin_run_length(ctx, N, hop, world * F)  # the runs of the unsharded signal: rows independent of the shard size
     audio = ctx.wrap_device(audio_t.data_ptr(), n, keepalive=audio_t)
     band = mx.pitch_band(N, SR)
 

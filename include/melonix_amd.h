@@ -77,7 +77,14 @@ int mx_ctx_synchronize(mx_ctx *ctx);
  * vocoder's arena — tens of GB for an hour of audio —, the host landing zone of mx_grains_dev); this releases them.
  * mx_ctx_destroy does so too. */
 int mx_ctx_release_scratch(mx_ctx *ctx);
-/* Tuning knob: consecutive frames one workgroup walks (0 = per-N default). */
+/* Run length: consecutive frames one workgroup of a bulk (uniform-hop) launch walks.  The sliding-window kernels
+ * restart their window from the exact weights at the head of every run, so a row's last bits depend on where the runs
+ * start.  The default is a function of the launch's frame count (a power of two, at most 32; short launches use short
+ * runs so that every CU gets work): mx_stft_run_length returns it (> 0; < 0 = error code).  A job that computes one
+ * signal in several launches — the frame shards of a multi-GPU run — gets the rows of the single launch bit for bit by
+ * starting every launch on a multiple of 32 frames and pinning its run length to the whole signal's:
+ * mx_ctx_set_frames_per_block(ctx, mx_stft_run_length(N, hop, total_frames)) (0 = back to the default). */
+int mx_stft_run_length(int N, int hop, int64_t count);
 int mx_ctx_set_frames_per_block(mx_ctx *ctx, int frames);
 /* Page-locked host memory for the buffers the host-pointer entry points fill (magnitude / texel rows, PCM): a
  * device->host copy into it is a direct DMA at PCIe rate, a copy into fresh pageable memory is several times slower

@@ -54,6 +54,7 @@ SIGNATURES = {
     "mx_ctx_synchronize": (_i, [_vp]),
     "mx_ctx_release_scratch": (_i, [_vp]),
     "mx_ctx_set_frames_per_block": (_i, [_vp, _i]),
+    "mx_stft_run_length": (_i, [_i, _i, _i64]),
     "mx_pinned_alloc": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "mx_pinned_free": (None, [_vp, _vp]),
     "mx_last_error": (C.c_char_p, []),

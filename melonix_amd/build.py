@@ -24,9 +24,9 @@ CXX = os.environ.get("CXX") or shutil.which("g++") or "g++"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 # (source, compiler, extra flags)
 UNITS = [
-    # packed f32 VALU has no rate advantage on gfx950 (measured: 69 vs 57 T lane-ops/s) and the SLP
-    # vectoriser's v_pk_* forms cost ~200 register-pairing moves per frame: keep the butterflies scalar
-    # -ffp-contract=off: the core spells out every FMA, so all kernel instantiations round alike
+    # the butterflies are hand-written packed arithmetic (pk_math.h: inline v_pk_fma/add/mul_f32 with op_sel / neg
+    # modifiers); the SLP vectoriser's own v_pk_* forms on the remaining scalar code cost register-pairing moves, so
+    # it stays off.  -ffp-contract=off: the core spells out every FMA, so all kernel instantiations round alike
     ("stft_kernels.hip", "hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
     # bit-exact PCM: no FMA contraction in the resampler
     ("resynth_kernels.hip", "hip", ["-ffp-contract=off"]),
@@ -38,7 +38,8 @@ UNITS = [
     # pure host logic: plain g++, no contraction, no -march (SURVEY §7 "Bit-exact schedule")
     ("host_logic.cpp", "cxx", ["-ffp-contract=off"]),
 ]
-HEADERS = ["kernels.h", "colormap_core.h", "stft_kernel_impl.h", "stft_core.h", "stft_tables.h", "stft_consts.inc", "host_logic.h",
+HEADERS = ["kernels.h", "colormap_core.h", "stft_kernel_impl.h", "stft_core.h", "pk_math.h", "stft_tables.h", "stft_consts.inc",
+           "host_logic.h",
            os.path.join("..", "..", "include", "melonix_amd.h")]
 
 

@@ -103,8 +103,14 @@ int default_frames_per_block(int N, int mode, int hop, int64_t count) {
   }
   const int cap = stft_frames_per_block_cap(N, mode, hop);
   const int64_t want_blocks = 2048;
-  const int64_t g = count / want_blocks;
-  return (int)std::max<int64_t>(1, std::min<int64_t>(cap, g));
+  const int64_t want = std::max<int64_t>(1, std::min<int64_t>(cap, count / want_blocks));
+  // a power of two: the sliding / circular-window kernels restart their decay chains at the head of every run, so
+  // rows are a function of where the runs start; with run lengths 1, 2, 4 .. cap (a power of two itself) a launch
+  // that starts on a multiple of `cap` frames is cut on the same run heads as any longer launch with the same run
+  // length (mx_stft_run_length + mx_ctx_set_frames_per_block pin that length for the shards of a multi-GPU job)
+  int g = 1;
+  while (2 * g <= want) g *= 2;
+  return g;
 }
 
 template <class P>
@@ -177,7 +183,7 @@ int check_common(mx_ctx *ctx, const mx_audio *a, int N, int64_t count, int &kmin
 
 int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_t first_frame,
                 const int32_t *d_ranges, int64_t count, int kmin, int kmax, float *d_mags,
-                mx_pitch *d_pitch, uint8_t *d_rgb, float cmap_k) {
+                mx_pitch *d_pitch, uint8_t *d_rgb, float cmap_k, int run_length = 0) {
   // HIP's current device is per thread: the tables below must land on the context's GPU whichever
   // thread makes the first call
   HIP_TRY(hipSetDevice(ctx->device));
@@ -202,7 +208,9 @@ int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_
   s.pitch = d_pitch;
   s.rgb = d_rgb;
   s.cmap_k = cmap_k;
-  s.frames_per_block = ctx->frames_per_block > 0 ? ctx->frames_per_block : default_frames_per_block(N, mode, hop, count);
+  s.frames_per_block = ctx->frames_per_block > 0 ? ctx->frames_per_block
+                       : run_length > 0         ? run_length
+                                                : default_frames_per_block(N, mode, hop, count);
   if (mode != kRanges) {
     rc = get_wtab(ctx, N, hop, t, &s.wtab);
     if (rc) return rc;
@@ -356,6 +364,11 @@ void mx_pinned_free(mx_ctx *ctx, void *p) {
   hipHostFree(p);
 }
 
+int mx_stft_run_length(int N, int hop, int64_t count) {
+  if ((N != 4096 && N != 16384 && N != 32768) || hop <= 0 || count < 0) return fail(MX_ERR_INVALID, "bad argument");
+  return default_frames_per_block(N, (hop & 1) ? kBulkAny : kBulkAligned, hop, count);
+}
+
 int mx_ctx_set_frames_per_block(mx_ctx *ctx, int g) {  // tuning knob (bench sweeps)
   if (!ctx || g < 0) return fail(MX_ERR_INVALID, "bad argument");
   ctx->frames_per_block = g;
@@ -437,8 +450,8 @@ double mx_note_bin(double note, int N, int sampleRate) {
 
 int64_t mx_frame_count(int64_t n, int hop) { return hop > 0 && n >= 0 ? (n + hop - 1) / hop : -1; }
 
-int mx_stft_hop_dev(mx_ctx *ctx, const mx_audio *a, int N, int hop, int64_t first_frame, int64_t count,
-                    int kmin, int kmax, float *d_mags, mx_pitch *d_pitch) {
+static int stft_hop_dev_run(mx_ctx *ctx, const mx_audio *a, int N, int hop, int64_t first_frame, int64_t count,
+                            int kmin, int kmax, float *d_mags, mx_pitch *d_pitch, int run_length) {
   int rc = check_common(ctx, a, N, count, kmin, kmax);
   if (rc) return rc;
   if (hop <= 0 || hop > MX_AUDIO_PAD) return fail(MX_ERR_INVALID, "hop %d out of range [1,%d]", hop, MX_AUDIO_PAD);
@@ -446,7 +459,12 @@ int mx_stft_hop_dev(mx_ctx *ctx, const mx_audio *a, int N, int hop, int64_t firs
     return fail(MX_ERR_INVALID, "frames [%lld,%lld) exceed ceil(n/hop)", (long long)first_frame,
                 (long long)(first_frame + count));
   return stft_launch(ctx, a, N, (hop % 2 == 0) ? kBulkAligned : kBulkAny, hop, first_frame, nullptr, count, kmin,
-                     kmax, d_mags, d_pitch, nullptr, 0.f);
+                     kmax, d_mags, d_pitch, nullptr, 0.f, run_length);
+}
+
+int mx_stft_hop_dev(mx_ctx *ctx, const mx_audio *a, int N, int hop, int64_t first_frame, int64_t count,
+                    int kmin, int kmax, float *d_mags, mx_pitch *d_pitch) {
+  return stft_hop_dev_run(ctx, a, N, hop, first_frame, count, kmin, kmax, d_mags, d_pitch, 0);
 }
 
 int mx_stft_ranges_dev(mx_ctx *ctx, const mx_audio *a, int N, const int32_t *d_ranges, int64_t count, int kmin,
@@ -476,6 +494,9 @@ static int stft_host_common(mx_ctx *ctx, const mx_audio *a, int N, bool ranges_m
   if (e == hipSuccess && ranges_mode) e = stage_get(ctx, 2, (size_t)chunk * 2 * sizeof(int32_t), (void **)&d_ranges);
   if (e != hipSuccess) return fail(MX_ERR_NOMEM, "device staging buffers: %s", hipGetErrorString(e));
   rc = MX_OK;
+  // one run length for the whole call, whatever its staging chunks are (chunks are multiples of 32 frames): the rows
+  // are those of a single launch of `count` frames
+  const int run = ranges_mode ? 0 : default_frames_per_block(N, (hop % 2 == 0) ? kBulkAligned : kBulkAny, hop, count);
   for (int64_t done = 0; done < count && rc == MX_OK; done += chunk) {
     const int64_t c = std::min(chunk, count - done);
     if (ranges_mode) {
@@ -484,7 +505,7 @@ static int stft_host_common(mx_ctx *ctx, const mx_audio *a, int N, bool ranges_m
       if (e != hipSuccess) { rc = fail(MX_ERR_DEVICE, "ranges upload: %s", hipGetErrorString(e)); break; }
       rc = mx_stft_ranges_dev(ctx, a, N, d_ranges, c, kmin, kmax, d_mags, d_pitch);
     } else {
-      rc = mx_stft_hop_dev(ctx, a, N, hop, first_frame + done, c, kmin, kmax, d_mags, d_pitch);
+      rc = stft_hop_dev_run(ctx, a, N, hop, first_frame + done, c, kmin, kmax, d_mags, d_pitch, run);
     }
     if (rc) break;
     if (mags_out)

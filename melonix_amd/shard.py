@@ -11,10 +11,31 @@ from __future__ import annotations
 from dataclasses import dataclass
 
 MX_AUDIO_PAD = 32768
-# Shard boundaries sit on multiples of this many frames: the bulk STFT kernel walks runs of 32 consecutive frames per
-# workgroup (its sliding window restarts from the exact weights at the head of every run), so a shard whose first
-# frame is a multiple of 32 is cut into the same runs as the unsharded signal and its rows come out bit-identical.
+# Shard boundaries sit on multiples of this many frames: the bulk STFT kernel walks runs of consecutive frames per
+# workgroup (its sliding window restarts from the exact weights at the head of every run), run lengths are powers of
+# two up to 32, so a shard whose first frame is a multiple of 32 is cut on the same run heads as the unsharded signal —
+# PROVIDED both use the same run length.  The default run length depends on a launch's frame count (short launches get
+# short runs): a rank therefore pins its context to the whole signal's value with pin_run_length() below; then its
+# rows are the unsharded run's bit for bit whatever the shard sizes are.
 FRAME_ALIGN = 32
+
+
+def run_length(N: int, hop: int, total_frames: int) -> int:
+    """Run length of an unsharded bulk launch over `total_frames` frames (mx_stft_run_length)."""
+    from . import _capi
+
+    g = _capi.lib().mx_stft_run_length(N, hop, int(total_frames))
+    if g <= 0:
+        raise ValueError(f"mx_stft_run_length({N}, {hop}, {total_frames}) -> {g}")
+    return g
+
+
+def pin_run_length(ctx, N: int, hop: int, total_frames: int) -> int:
+    """Make `ctx` cut its bulk launches at (N, hop) into the runs an unsharded launch over the WHOLE signal's
+    `total_frames` frames uses.  Every rank of a sharded job calls this before its launches."""
+    g = run_length(N, hop, total_frames)
+    ctx.set_frames_per_block(g)
+    return g
 
 
 def frame_align(N: int, hop: int) -> int:
@@ -55,7 +76,9 @@ def frame_count(n: int, hop: int) -> int:
 
 def shard_frames(n: int, N: int, hop: int, rank: int, world: int, align: int | None = None) -> FrameShard:
     """Contiguous frame ranges, equal up to the alignment: every boundary is a multiple of `align` frames (default:
-    frame_align(N, hop); the last rank takes what is left, at most world*align frames less than the others)."""
+    frame_align(N, hop); the last rank takes what is left, at most world*align frames less than the others).
+    Rows equal the unsharded run's bit for bit when the rank's context has the whole signal's run length
+    (pin_run_length(ctx, N, hop, frame_count(n, hop)))."""
     if align is None:
         align = frame_align(N, hop)
     F = frame_count(n, hop)

@@ -113,6 +113,115 @@ def test_stft_full_size_other_plans(gpu_ctx, oracle, hour, N2, HOP2):
     a.free()
 
 
+def _host_threads():
+    """Threads the oracle may use: the affinity mask cut to the cgroup CPU quota (as bench.py's cpu_baseline does)."""
+    import os
+
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, -(-int(q) // int(p)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def _whole_config_vs_oracle(gpu_ctx, oracle, w, N2, hop, chunk, every):
+    """The WHOLE configuration against the oracle (spec.cpp:44-66 restated, binary64 DFT, all host cores): every pitch
+    record of the full run, and the magnitude rows of every `every`-th chunk of `chunk` frames (every = 1: all rows) plus
+    both ends, each row within 2e-5 of its oracle peak.  The device rows are pulled back chunk by chunk from
+    launches that start on run heads with the full run's run length pinned, i.e. they are the full run's rows bit for bit
+    (test_shards_of_circular_window_kernels_equal_unsharded / the 8 h shard test establish that)."""
+    import os
+    import time
+
+    from melonix_amd import shard as sh
+
+    n = len(w)
+    F = (n + hop - 1) // hop
+    T = _host_threads()
+    band = oracle.pitch_band(N2, SR)
+    a = gpu_ctx.upload(w)
+    assert chunk % sh.frame_align(N2, hop) == 0
+    g = sh.pin_run_length(gpu_ctx, N2, hop, F)
+    try:
+        t0 = time.time()
+        _, pitch = gpu_ctx.stft_hop(a, N2, hop, band=band, want_mags=False)
+        _, ob, om = oracle.stft_hop(w, N2, hop, band=band, want_mags=False, nthreads=T)
+        t_pitch = time.time() - t0
+        assert len(pitch) == F == len(ob)
+        # every record: the same bin, or a near-tie — the oracle's magnitude at the device's bin within twice the row
+        # tolerance of the oracle's maximum (the rule of test_gpu_stft._check_pitch)
+        diff = np.nonzero(pitch["bin"] != ob)[0]
+        assert len(diff) <= 500, f"{len(diff)} of {F} pitch bins differ from the oracle's"
+        for f in diff:
+            ref = oracle.spec_frame(w, N2, int(f) * hop, (int(f) + 1) * hop)
+            b = int(pitch["bin"][f])
+            assert band[0] <= b <= band[1]
+            assert ref[ob[f]] - ref[b] <= 2 * (2e-5 * ref.max() + 1e-9), (int(f), b, int(ob[f]))
+        # every record's magnitude (in-band peak <= frame peak, so this is the row tolerance or tighter; the few frames
+        # where it is tighter than the device manages are re-checked against the frame's real peak)
+        same = pitch["bin"] == ob
+        over = np.nonzero(same & (np.abs(pitch["mag"] - om) > 2e-5 * om + 1e-9))[0]
+        assert len(over) <= 500, len(over)
+        for f in over:
+            ref = oracle.spec_frame(w, N2, int(f) * hop, (int(f) + 1) * hop)
+            assert abs(float(pitch["mag"][f]) - float(ref[ob[f]])) <= 2e-5 * ref.max() + 1e-9, int(f)
+        # magnitude rows
+        starts = list(range(0, F, chunk))
+        take = sorted(set(starts[::every]) | {starts[0], starts[-1]})
+        rows, worst = 0, 0.0
+        t0 = time.time()
+        for c in take:
+            cnt = min(chunk, F - c)
+            gm, gp = gpu_ctx.stft_hop(a, N2, hop, first=c, count=cnt, band=band)
+            rm, _, _ = oracle.stft_hop(w, N2, hop, first=c, count=cnt, band=band, nthreads=T)
+            tol = 2e-5 * rm.max(axis=1) + 1e-9
+            np.subtract(gm, rm, out=rm)
+            np.abs(rm, out=rm)
+            err = rm.max(axis=1)
+            bad = np.nonzero(err > tol)[0]
+            assert len(bad) == 0, (c + int(bad[0]), float(err[bad[0]]), float(tol[bad[0]]))
+            # the chunk's pitch records are the full run's (same runs), and each is its row's own value
+            assert np.array_equal(gp["bin"], pitch["bin"][c:c + cnt]) and np.array_equal(gp["mag"], pitch["mag"][c:c + cnt])
+            assert np.array_equal(gp["mag"], gm[np.arange(cnt), gp["bin"]])
+            worst = max(worst, float((err / tol).max()))
+            rows += cnt
+        t_rows = time.time() - t0
+    finally:
+        gpu_ctx.set_frames_per_block(0)
+        a.free()
+    msg = (f"whole-config vs oracle N={N2} hop={hop}: {F} of {F} pitch records ({len(diff)} near-ties, {len(over)} re-checked "
+           f"magnitudes) in {t_pitch:.1f} s; {rows} of {F} magnitude rows ({len(take)} chunks of {chunk}) in {t_rows:.1f} s, "
+           f"worst row error {worst:.3f} of the 2e-5*peak tolerance; run length {g}, {T} oracle threads")
+    print(msg)
+    log = os.environ.get("MX_PARITY_LOG")
+    if log:
+        with open(log, "a") as fh:
+            fh.write(msg + "\n")
+    return F, rows
+
+
+def test_config1_whole_hour_every_record_and_row_vs_oracle(gpu_ctx, oracle, hour):
+    """BASELINE configs[1] in full: all 675 000 pitch records and all 675 000 magnitude rows (5.5 GB) of the hour."""
+    F, rows = _whole_config_vs_oracle(gpu_ctx, oracle, hour, N, HOP, chunk=16384, every=1)
+    assert F == 675000 and rows == F
+
+
+def test_config4_whole_hour_vs_oracle(gpu_ctx, oracle, hour):
+    """BASELINE configs[4] (N = 16384, hop 512) in full: all 337 500 pitch records, all magnitude rows (11 GB)."""
+    F, rows = _whole_config_vs_oracle(gpu_ctx, oracle, hour, 16384, 512, chunk=4096, every=1)
+    assert F == 337500 and rows == F
+
+
+def test_reference_size_whole_hour_vs_oracle(gpu_ctx, oracle, hour):
+    """The reference's own transform (N = 32768, spec.cpp:8) at its default column width (375 samples) over the hour: all
+    460 800 pitch records; every 8th chunk of 1024 rows plus both ends (>= 57 000 rows, 3.8 GB)."""
+    F, rows = _whole_config_vs_oracle(gpu_ctx, oracle, hour, 32768, 375, chunk=1024, every=8)
+    assert F == 460800 and rows >= 57000
+
+
 def test_resynth_full_size_properties(gpu_ctx, mxlib, hour):
     w = hour
     n = len(w)
@@ -222,12 +331,18 @@ def test_eight_shards_on_one_device_equal_unsharded_8h():
     assert "shard8_check ok" in r.stdout
 
 
-@pytest.mark.parametrize("N,hop,world,hours", [(32768, 375, 2, 0.3), (16384, 375, 3, 0.25), (32768, 512, 2, 0.4)])
+@pytest.mark.parametrize("N,hop,world,hours", [(32768, 375, 2, 0.3), (16384, 375, 3, 0.25), (32768, 512, 2, 0.4),
+                                               # shards too short for the unsharded run length on their own (10 min at
+                                               # 4096/256: 112 500 frames -> runs of 32, a 2-rank shard alone would pick
+                                               # 16; an hour at 32768/375 over 8 ranks: 32 against 16) — pinned by
+                                               # shard.pin_run_length
+                                               (4096, 256, 2, 1 / 6), (4096, 256, 5, 1 / 6), (32768, 375, 8, 1.0),
+                                               (16384, 512, 7, 0.1)])
 def test_shards_of_circular_window_kernels_equal_unsharded(N, hop, world, hours):
     """The circular-window kernels round by where a frame starts inside a slot of the device image: `shard_frames` puts
     shard boundaries on whole slots (frame_align), so shards run on their own images are still the unsharded run bit for
-    bit — every row and the pitch track (same checker as the 8 h test, its own process for the same reason).  (Sizes: every
-    shard long enough for full-length runs — 2048 workgroups of 32 / 16 frames — as in any real sharded job.)"""
+    bit — every row and the pitch track (same checker as the 8 h test, its own process for the same reason).  The run
+    length of every shard is pinned to the whole signal's (shard.pin_run_length): shard sizes are free."""
     import os
     import subprocess
     import sys

@@ -40,6 +40,7 @@ def main(hours: float = 8.0, N: int = 4096, HOP: int = 256, world: int = 8):
     ctx.stft_hop_dev(whole, N, HOP, 0, F, mags.data_ptr(), pitch.data_ptr(), band=band)
     torch.cuda.synchronize()
     parts = [sh.shard_frames(n, N, HOP, r, world) for r in range(world)]
+    g = sh.pin_run_length(ctx, N, HOP, F)  # what every rank of a sharded job does: the whole signal's run length
     assert parts[0].lo == 0 and parts[-1].hi == F and all(p.lo % sh.frame_align(N, HOP) == 0 or p.lo == F for p in parts)
     track = []
     smags = torch.empty((max(p.frames for p in parts), N // 2), dtype=torch.float32, device=dev)
@@ -76,7 +77,7 @@ def main(hours: float = 8.0, N: int = 4096, HOP: int = 256, world: int = 8):
         worst = max(worst, err / tol)
     whole.free()
     ctx.close()
-    print(f"shard8_check ok: {F} frames, {world} shards of {parts[0].frames} frames, {len(pick)} rows vs the oracle "
+    print(f"shard8_check ok: {F} frames, {world} shards of {parts[0].frames} frames (run length {g}), {len(pick)} rows vs the oracle "
           f"(worst {worst:.3f} of the tolerance)")
 
 

@@ -10,7 +10,7 @@ OUT=gpurun_out
 # The profiled command is the default bench step (STFT+pitch launch + resynthesis launch) without the CPU baseline and the
 # supplementary extras.  PROF_KERNEL=<substring> picks the kernel whose PMC rows are summarised (default stft_kernel;
 # PROF_RESYNTH=1 = resynth_kernel_v).
-NORES="--no-supplementary"; [ "${PROF_RESYNTH:-0}" = "1" ] && export PROF_KERNEL=${PROF_KERNEL:-resynth_kernel_v}
+NORES="--no-supplementary --no-noise-secondary --no-limiter-probe"; [ "${PROF_RESYNTH:-0}" = "1" ] && export PROF_KERNEL=${PROF_KERNEL:-resynth_kernel_v}
 BENCH="python bench.py --steps 50 --warmup 10 --no-cpu-baseline $NORES $*"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o stft -- $BENCH > $OUT/prof_${TAG}_bench.log 2>&1

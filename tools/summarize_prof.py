@@ -68,8 +68,20 @@ if stft and "WRITE_SIZE" in p and "FETCH_SIZE" in p:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     try:
         from bench import kernel_source_hash
-        latest = {"fft": int(os.environ.get("PROF_FFT", 4096)), "hop": int(os.environ.get("PROF_HOP", 256)),
-                  "frames": int(os.environ.get("PROF_FRAMES", 675000)),
+        # the workload of THIS run: fft / hop / frames from the JSON line the profiled bench command printed
+        cfg = None
+        for lg in [os.path.join(OUT, f"prof_{tag}_bench.log")] + find(f"pmc_{tag}_*.log"):
+            try:
+                for ln in open(lg):
+                    if ln.startswith("{") and '"config"' in ln:
+                        cfg = json.loads(ln)["config"]
+            except Exception:
+                pass
+            if cfg:
+                break
+        if cfg is None:
+            raise RuntimeError(f"no bench line found in {OUT}/prof_{tag}_bench.log: workload of the run unknown")
+        latest = {"fft": int(cfg["fft"]), "hop": int(cfg["hop"]), "frames": int(cfg["frames_per_gpu"]),
                   "hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "fetch_bytes_raw": res["fetch_bytes_raw"],
                   "fetch_bytes_corrected": res["fetch_bytes_corrected"], "write_bytes": res["write_bytes"],
                   "note": res["hbm_bytes_note"], "kernel": stft[0]["Name"], "kernel_source_sha1": kernel_source_hash(),
