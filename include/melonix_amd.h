@@ -236,8 +236,13 @@ void mx_free(void *p);
  * may be NULL).  Bit-exact vs the reference arithmetic (no FMA contraction). */
 int mx_resynth(mx_ctx *ctx, const mx_audio *a, const mx_step *steps, int64_t nsteps,
                int64_t nsamples, float *pcm_f32_out, int16_t *pcm_i16_out);
-/* Device-resident variant: d_steps / outputs in HBM, asynchronous.  Every one of the nsamples outputs is written:
- * the samples past the last step's run (the zeros of the terminating process() calls) are cleared on the device. */
+/* Device-resident variant: d_steps / outputs in HBM, asynchronous.
+ * PRECONDITION (not checked on the device — mx_resynth, the host-pointer entry point, does check it): the steps are
+ * in output order and contiguous, out_offset[0] == 0 and out_offset[i+1] == out_offset[i] + sz[i], as every
+ * mx_schedule_build* call produces them (a rank's slice of a schedule rebased to its own buffer, shard_schedule in
+ * melonix_amd/shard.py, qualifies).  Then every one of the nsamples outputs is written: step i fills its sz[i]
+ * samples, and the samples past the LAST step record's run (the zeros of the terminating process() calls,
+ * app.cpp:303-309) are cleared on the device.  With gaps or reordered records the gaps keep their previous contents. */
 int mx_resynth_dev(mx_ctx *ctx, const mx_audio *a, const mx_step *d_steps, int64_t nsteps,
                    int64_t nsamples, float *d_pcm_f32, int16_t *d_pcm_i16);
 

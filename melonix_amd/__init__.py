@@ -110,6 +110,19 @@ class KeptRows:
             _capi.lib().mx_rows_free(self.ctx.handle, self.handle)
             self.handle = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def __del__(self):  # the rows are a device allocation: do not leave them to the end of the process
+        try:
+            if self.ctx.handle:
+                self.free()
+        except Exception:
+            pass
+
 
 class Context:
     """One per GPU / rank (mx_ctx)."""

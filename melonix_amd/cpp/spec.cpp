@@ -123,6 +123,7 @@ struct Spec::Impl {
   std::deque<std::weak_ptr<DevBatch>> devBatches;
   std::size_t devBytes = 0;
   std::size_t devBudget = std::size_t(1) << 30;
+  int devBudgetWarned = 0;
   // what the worker has done so far (tests, MELONIX_TIMING)
   std::atomic<std::uint64_t> nLaunchedColumns{0}, nFetchedRows{0}, nRecolouredRows{0};
 
@@ -131,13 +132,31 @@ struct Spec::Impl {
   }
   bool usable() const { return ctx && audio; }
 
+  // Rows evicted on a caller's thread.  Dropping a Row can drop the last reference to its batch's device rows
+  // (mx_rows_free: hipFree, an implicit device synchronisation) or to a pinned slab (hipHostFree): that must happen
+  // neither on the UI thread nor under `mu` — getSpec never blocks on the device (spec.cpp:28,41).  Evicted rows
+  // are parked here (under mu) and released by the worker outside the lock.
+  std::vector<Row> graveyard;
+
   // the miss path of getSpec / requestTexRow (spec.cpp:30-41): a slot without data, the job, LRU eviction
   void enqueueLocked(const Range &key, bool wantMags) {
     rows.insert(key, {});
     pending[key] = wantMags;
     if (rows.size() > static_cast<std::size_t>(MaxRanges))
-      if (auto old = rows.evictOldest()) pending.erase(old->first);
+      if (auto old = rows.evictOldest()) {
+        pending.erase(old->first);
+        graveyard.push_back(std::move(old->second));
+      }
     wake.notify_one();
+  }
+  // worker thread, mu NOT held: let go of what the callers' evictions parked
+  void buryEvicted() {
+    std::vector<Row> dead;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      dead.swap(graveyard);
+    }
+    dead.clear();  // the destructors (device / pinned frees) run here
   }
 
   std::shared_ptr<Slab> hostSlab(std::size_t magBytes, std::size_t rgbBytes) {
@@ -153,24 +172,29 @@ struct Spec::Impl {
 
   // Makes room for `bytes` more device rows: forgets batches nobody refers to any more, then drops the oldest ones.
   void reserveDevice(std::size_t bytes) {
-    std::lock_guard<std::mutex> lk(mu);  // `rows` of a batch is read under mu by getSpec / requestTexView
-    for (auto it = devBatches.begin(); it != devBatches.end();) {
-      if (auto b = it->lock(); b && b->rows) {
-        ++it;
-      } else {
-        it = devBatches.erase(it);
+    std::vector<mx_rows *> dropped;  // freed after the lock: hipFree synchronises the device
+    {
+      std::lock_guard<std::mutex> lk(mu);  // `rows` of a batch is read under mu by getSpec / requestTexView
+      for (auto it = devBatches.begin(); it != devBatches.end();) {
+        if (auto b = it->lock(); b && b->rows) {
+          ++it;
+        } else {
+          it = devBatches.erase(it);
+        }
+      }
+      devBytes = 0;
+      for (const auto &w : devBatches)
+        if (auto b = w.lock()) devBytes += b->bytes;
+      while (!devBatches.empty() && devBytes + bytes > devBudget) {
+        if (auto b = devBatches.front().lock()) {
+          devBytes -= b->bytes;
+          dropped.push_back(b->rows);
+          b->rows = nullptr;
+        }
+        devBatches.pop_front();
       }
     }
-    devBytes = 0;
-    for (const auto &w : devBatches)
-      if (auto b = w.lock()) devBytes += b->bytes;
-    while (!devBatches.empty() && devBytes + bytes > devBudget) {
-      if (auto b = devBatches.front().lock()) {
-        devBytes -= b->bytes;
-        b->drop();
-      }
-      devBatches.pop_front();
-    }
+    for (mx_rows *r : dropped) mx_rows_free(ctx, r);
   }
 
   // One launch for `keys`: magnitudes and/or texels (k != 0) into one pooled slab; the magnitude rows also stay on
@@ -188,7 +212,7 @@ struct Spec::Impl {
     const auto count = static_cast<int64_t>(n);
     const std::size_t keepBytes = n * bins * sizeof(float);
     std::shared_ptr<DevBatch> dev;
-    int rc;
+    int rc = MX_ERR_NOMEM;
     if (keepBytes <= devBudget) {
       reserveDevice(keepBytes);
       mx_rows *kept = nullptr;
@@ -200,29 +224,43 @@ struct Spec::Impl {
         dev->bytes = keepBytes;
         devBatches.push_back(dev);
         devBytes += keepBytes;
+      } else if (rc == MX_ERR_NOMEM) {
+        // no room for kept rows next to whatever else lives on the device (a phase-vocoder arena, say): the columns
+        // still get computed through the staging-only path below, and the row cache asks for half as much from now on
+        reserveDevice(devBudget);  // (drops every batch still held)
+        devBudget /= 2;
+        if (devBudgetWarned++ == 0)
+          fprintf(stderr, "melonix_amd Spec worker: no device memory for the row cache (%s); budget now %zu MiB\n",
+                  mx_last_error(), devBudget >> 20);
       }
-    } else if (wantRgb) {
-      rc = mx_stft_ranges_rgb_mags(ctx, audio, N, flat.data(), count, k, slab->mags, slab->rgb);  // mags may be null
-    } else {
-      rc = mx_stft_ranges(ctx, audio, N, flat.data(), count, -1, -1, slab->mags, nullptr);
+    }
+    if (rc == MX_ERR_NOMEM) {  // over the budget, or the keep call could not allocate: rows leave through staging only
+      if (wantRgb) rc = mx_stft_ranges_rgb_mags(ctx, audio, N, flat.data(), count, k, slab->mags, slab->rgb);  // mags may be null
+      else rc = mx_stft_ranges(ctx, audio, N, flat.data(), count, -1, -1, slab->mags, nullptr);
     }
     if (rc != MX_OK) return false;
     nLaunchedColumns += n;
-    std::lock_guard<std::mutex> lk(mu);
-    for (std::size_t i = 0; i < n; ++i)
-      if (Row *slot = rows.peek(keys[i])) {  // may have been evicted meanwhile (spec.cpp:91-93)
-        if (slab->rgb) {
-          slot->tex = slab;
-          slot->texIndex = i;
-          slot->k = k;
+    std::vector<std::shared_ptr<const void>> replaced;  // what the slots held before: released after the lock
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (std::size_t i = 0; i < n; ++i)
+        if (Row *slot = rows.peek(keys[i])) {  // may have been evicted meanwhile (spec.cpp:91-93)
+          if (slab->rgb) {
+            replaced.push_back(std::move(slot->tex));
+            slot->tex = slab;
+            slot->texIndex = i;
+            slot->k = k;
+          }
+          if (slab->mags) {
+            replaced.push_back(std::move(slot->mag));
+            slot->mag = slab;
+            slot->magIndex = i;
+          }
+          replaced.push_back(std::move(slot->dev));
+          slot->dev = dev;
+          slot->devIndex = i;
         }
-        if (slab->mags) {
-          slot->mag = slab;
-          slot->magIndex = i;
-        }
-        slot->dev = dev;
-        slot->devIndex = i;
-      }
+    }
     return true;
   }
 
@@ -250,18 +288,23 @@ struct Spec::Impl {
       i = j;
     }
     (texels ? nRecolouredRows : nFetchedRows) += n;
-    std::lock_guard<std::mutex> lk(mu);
-    for (std::size_t i = 0; i < n; ++i)
-      if (Row *slot = rows.peek(items[i].key)) {
-        if (texels) {
-          slot->tex = slab;
-          slot->texIndex = i;
-          slot->k = k;
-        } else {
-          slot->mag = slab;
-          slot->magIndex = i;
+    std::vector<std::shared_ptr<const void>> replaced;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (std::size_t i = 0; i < n; ++i)
+        if (Row *slot = rows.peek(items[i].key)) {
+          if (texels) {
+            replaced.push_back(std::move(slot->tex));
+            slot->tex = slab;
+            slot->texIndex = i;
+            slot->k = k;
+          } else {
+            replaced.push_back(std::move(slot->mag));
+            slot->mag = slab;
+            slot->magIndex = i;
+          }
         }
-      }
+    }
     return true;
   }
 
@@ -270,6 +313,7 @@ struct Spec::Impl {
     std::vector<Cached> fetchM, recolour;
     std::vector<int32_t> flat;
     while (alive) {
+      buryEvicted();
       float k;
       {
         std::unique_lock<std::mutex> lk(mu);
@@ -316,7 +360,7 @@ struct Spec::Impl {
           for (const std::vector<Range> *v : {&wantT, &wantM})
             for (const Range &r : *v)
               if (const Row *slot = rows.peek(r))
-                if (!slot->computed()) rows.erase(r);
+                if (!slot->computed()) rows.erase(r);  // (empty slots: nothing to free)
         }
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
@@ -359,6 +403,7 @@ Spec::~Spec() {
   impl->alive = false;
   impl->wake.notify_all();
   if (impl->worker.joinable()) impl->worker.join();
+  impl->graveyard.clear();
   impl->rows.clear();  // the rows' slabs return their blocks to the pool ...
   impl->pool.clear();  // ... which gives them back before the context goes
   if (impl->audio) mx_audio_free(impl->ctx, impl->audio);

@@ -37,10 +37,7 @@ struct StftArgs {
 
 hipError_t launch_stft(int N, int mode, const StftArgs &a, hipStream_t s);
 // Points per thread of the plan launch_stft uses for N (selects the twiddle tables to upload).
-#ifndef MX_PLAN_4096_E
-#define MX_PLAN_4096_E 16
-#endif
-constexpr int kPlan4096E = MX_PLAN_4096_E;
+constexpr int kPlan4096E = 16;
 int stft_points_per_thread(int N);
 // Longest run of consecutive frames worth giving one workgroup for (N, mode, hop): the kernels that carry a register
 // image from frame to frame amortise their first frame's direct load over the run.

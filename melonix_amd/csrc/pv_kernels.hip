@@ -79,10 +79,10 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   // the M-point image + the pass-2 twiddle table (2 KiB, shared by both waves); this thread's pass-3 twiddles stay
   // in registers for the whole walk: no twiddle loads per frame (stft_kernel's TWREG = 2 arrangement)
   constexpr int kTw2 = ((P::TW2 + 1) / 2) * 2;
-  __shared__ __attribute__((aligned(16))) float2 lds[P::M + kTw2];
+  __shared__ __attribute__((aligned(16))) float2 lds[t1_size<P>() + kTw2];  // (image incl. the T1 padding, stft_core.h)
   __shared__ float red[2];
   __shared__ uint32_t pkbits[P::M / 32];
-  float2 *const ltw2 = lds + P::M;
+  float2 *const ltw2 = lds + t1_size<P>();
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;
   cpx u[P::R3];
@@ -432,7 +432,7 @@ __host__ __device__ constexpr int64_t pv_blocks(int64_t frames) {
 
 __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) void pv_synthesis(const PvArgs a) {
   using P = PV;
-  __shared__ __attribute__((aligned(16))) float2 lds[P::M];
+  __shared__ __attribute__((aligned(16))) float2 lds[t1_size<P>()];
   __shared__ __attribute__((aligned(16))) float ring[P::N];  // overlap-add accumulator, stretched time mod N
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;

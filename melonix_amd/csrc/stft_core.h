@@ -18,8 +18,9 @@
 //           (k, M-k) pair the real-FFT split needs, so the split, the
 //           magnitude and the pitch pick never leave registers.
 // Plans (Plan<N, E>):
-//   N = 4096,  E = 32: R = 8,16,16   T = 64   one wavefront per frame
-//   N = 4096,  E = 16: R = 16,16,8   T = 128  two wavefronts per frame, half the registers
+//   N = 4096,  E = 16: R = 16,16,8   T = 128  two wavefronts per frame
+//       (a one-wavefront plan, E = 32 / R = 8,16,16, was measured again under the package power limit in round 3 —
+//        2.00 against 1.87 ms per hour, profiles/variants_r03_plan4096E.log — and removed)
 //   N = 16384, E = 32: R = 32,16,16  T = 256
 //   N = 32768, E = 32: R = 32,32,16  T = 512  (the reference's SpectrSize)
 #pragma once
@@ -177,7 +178,7 @@ struct Plan {
   static constexpr int E = E_;      // points per thread
   static constexpr int T = M / E;   // threads per frame
   static constexpr int R3 = E / 2;  // last pass: one butterfly pair per thread
-  static constexpr int R1 = (N == 4096) ? (E == 32 ? 8 : 16) : 32;
+  static constexpr int R1 = (N == 4096) ? 16 : 32;
   static constexpr int R2 = M / (R1 * R3);
   static constexpr int NS3 = R1 * R2;  // finished sub-transform size entering pass 3 (= M/R3)
   static constexpr int NB1 = E / R1;   // butterflies per thread in pass 1
@@ -186,22 +187,30 @@ struct Plan {
   static constexpr int TW3 = (R3 - 1) * NS3;  // entries of the pass-3 twiddle table
   static constexpr int L1 = ilog2(R1);
   static_assert(N == 4096 || N == 16384 || N == 32768, "supported FFT sizes");
-  static_assert(E == 32 || (E == 16 && N == 4096), "supported points per thread");
+  static_assert((N == 4096) ? E == 16 : E == 32, "supported points per thread");
   static_assert(R1 * R2 * R3 == M && R2 <= E && R1 <= E && T % 64 == 0, "radix plan must cover M");
 };
 
-// XOR swizzles of the complex index (8-byte granules) inside the LDS image.
-// T1 is written with lane stride R1 (pass-1 outputs) and read contiguously;
-// T2 is written in runs of R1 and read contiguously.  Both keep every aligned
-// block of 32 complex points a permutation of itself, so contiguous reads stay
-// conflict-free while the strided writes spread over all banks
-// (SQ_LDS_BANK_CONFLICT = 0 in profiles/).
+// Layout of the LDS image during the first transposition (T1).  Pass-1 outputs are written with lane stride R1
+// (thread t owns the R1 consecutive points t*R1 .. t*R1 + R1 - 1) and read back contiguously; T2 is written in runs
+// of R1 and read contiguously and needs nothing.  Two layouts keep the strided T1 writes off each other's banks:
+//  * R1 = 32 (N = 16384 / 32768) — PADDED: one complex point of padding after every 32, logical index i lives at
+//    i + (i >> 5).  A lane group of 16 writes dwords 66*t + {0,1}: every bank once; the contiguous reads skip one
+//    point per 32 and stay conflict-free; and EVERY address is "per-thread base + compile-time offset".  The XOR
+//    swizzle it replaced (round 3) cost one v_xor per stored point, 32 per thread and frame: N = 32768 12.58 ->
+//    12.40 ms per hour at 375-sample columns, 4.63 -> 4.54 at hop 1024 (profiles/variants_r03_t1pad.log).  The image
+//    grows by M/32 points (132 KiB at N = 32768: fits).
+//  * R1 = 16 (N = 4096) — XOR: i ^ ((i >> 4) & 15), every aligned block of 32 points a permutation of itself, image
+//    of exactly M points.  Padding measured 5 % SLOWER here (1.79 -> 1.89 ms): one point per 32 leaves two lanes of a
+//    write group on one bank pair, one per 16 costs the sixth workgroup per CU its LDS.
 template <class P>
-MX_HD int swz1(int i) { return i ^ ((i >> P::L1) & 15); }
+MX_HD constexpr bool t1_padded() { return P::R1 == 32; }
 template <class P>
-MX_HD int swz2(int i) {
-  if constexpr (P::R1 == 8) return i ^ (((i >> 7) & 1) << 3);
-  else return i;
+MX_HD constexpr int t1_size() { return t1_padded<P>() ? P::M + P::M / 32 : P::M; }
+template <class P>
+MX_HD int t1_index(int i) {
+  if constexpr (t1_padded<P>()) return i + (i >> 5);
+  else return i ^ ((i >> P::L1) & 15);
 }
 
 // ---- the windowed frame -----------------------------------------------------
@@ -520,18 +529,18 @@ MX_HD void circ_step(int t, cpx (&Y)[P::E], float decay, const CircGeo<P> &g, co
 // third of the kernel's LDS time, so on the device they are issued as plain ds_read_b64 by
 // hand; a single s_waitcnt closes the batch, and the values are threaded through that
 // statement so nothing that consumes them can be scheduled above it.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MX_NO_LDS_ASM)
-#define MX_LDS_ASM 1
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MX_LDS_ASM 1  // the device pass; the host pass (tests/emu) takes the plain C++ forms of the same reads
 typedef float mx_f2v __attribute__((ext_vector_type(2)));
 template <int OFF>
 __device__ __forceinline__ mx_f2v lds_rd64(uint32_t addr) {
-  static_assert(OFF >= 0 && OFF < 131072, "LDS image is at most 128 KiB");
+  static_assert(OFF >= 0 && OFF < 163840, "LDS is 160 KiB");
   mx_f2v r;
   if constexpr (OFF < 65536) {  // the ds offset field is 16 bits
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
   } else {
-    const uint32_t hi = addr + 65536u;  // one add per base, shared by the upper half's reads
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(hi), "n"(OFF - 65536) : "memory");
+    const uint32_t hi = addr + (uint32_t)(OFF & ~65535);  // one add per base and 64 KiB window, shared by that window's reads
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(hi), "n"(OFF & 65535) : "memory");
   }
   return r;
 }
@@ -547,62 +556,84 @@ __device__ __forceinline__ void lds_wait(mx_f2v (&q)[N]) {
     asm volatile("" : "+v"(q[i]), "+v"(q[i + 1]), "+v"(q[i + 2]), "+v"(q[i + 3]), "+v"(q[i + 4]),
                  "+v"(q[i + 5]), "+v"(q[i + 6]), "+v"(q[i + 7]));
 }
+#endif
+// f(integral_constant<int, I>) for I = I0 .. N-1: a loop whose index is a constant expression in the body
 template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
+MX_HD void static_for(F &&f) {
   if constexpr (I < N) {
     f(std::integral_constant<int, I>{});
     static_for<I + 1, N>(f);
   }
 }
-#endif
 
 // ---- LDS transpositions -------------------------------------------------------
 // Every access below is "per-thread base + compile-time offset" (or base ^ constant for
 // the T1 store), so a frame needs a dozen address registers instead of one per access;
 // the closed forms are the swizzles above evaluated symbolically (tests/emu checks them
-// against swz1/swz2 for every thread).
+// against t1_index/swz2 for every thread).
 template <class P>
 MX_HD void store_t1(int t, const cpx (&v)[P::E], cpx *lds) {
-  // swz1((t + T*b)*R1 + r) = (((t*R1) ^ (t & 15)) ^ r) + b*T*R1   (T is a multiple of 16)
-  // (in bytes, so that each of the R1 scatter addresses is ONE xor with a constant — the shift by 3 is done once)
-  const unsigned B8 = (unsigned)((t * P::R1) ^ (t & 15)) << 3;
-  char *const base = reinterpret_cast<char *>(lds);
+  if constexpr (t1_padded<P>()) {
+    // t1_index((t + T*b)*R1 + r) = (t*R1 + (t*R1 >> 5)) + b*(T*R1 + T*R1/32) + r:  r < R1 <= 32 never carries into the
+    // pad term (t*R1 has its low log2(R1) bits clear) and T*R1 is a multiple of 32
+    static_assert(P::R1 <= 32 && (P::T * P::R1) % 32 == 0, "T1 padding is one point per 32");
+    cpx *const p = lds + (t * P::R1 + ((t * P::R1) >> 5));
 #pragma unroll
-  for (int r = 0; r < P::R1; ++r) {
-    cpx *p = reinterpret_cast<cpx *>(base + (B8 ^ ((unsigned)r << 3)));
+    for (int b = 0; b < P::NB1; ++b) {
 #pragma unroll
-    for (int b = 0; b < P::NB1; ++b) p[b * P::T * P::R1] = v[b * P::R1 + r];
+      for (int r = 0; r < P::R1; ++r) p[b * (P::T * P::R1 + P::T * P::R1 / 32) + r] = v[b * P::R1 + r];
+    }
+  } else {
+    // t1_index((t + T*b)*R1 + r) = (((t*R1) ^ (t & 15)) ^ r) + b*T*R1   (T is a multiple of 16)
+    // (in bytes, so that each of the R1 scatter addresses is ONE xor with a constant — the shift by 3 is done once)
+    const unsigned B8 = (unsigned)((t * P::R1) ^ (t & 15)) << 3;
+    char *const base = reinterpret_cast<char *>(lds);
+#pragma unroll
+    for (int r = 0; r < P::R1; ++r) {
+      cpx *p = reinterpret_cast<cpx *>(base + (B8 ^ ((unsigned)r << 3)));
+#pragma unroll
+      for (int b = 0; b < P::NB1; ++b) p[b * P::T * P::R1] = v[b * P::R1 + r];
+    }
   }
 }
 
+// The T1 read of thread t: point (t + T*b) + r*S, S = M/R2, is at base[(r & 1) ? 1 : 0] + b*TP + r*SP.
+//   padded: t1_index(j + r*S) = (j + (j >> 5)) + r*(S + S/32), one base (T and S are multiples of 32);
+//   XOR:    t1_index(j + r*S) = (t1_index(j) ^ c_r) + r*S with c_r = (r * (S >> L1)) & 15: the stride only reaches the
+//           swizzle's source field through its top bit (c_r in {0, 8}) or not at all — an alternate base for odd r.
+template <class P>
+struct T1Read {
+  static constexpr int S = P::M / P::R2;
+  static constexpr int SP = t1_padded<P>() ? S + S / 32 : S;
+  static constexpr int TP = t1_padded<P>() ? P::T + P::T / 32 : P::T;
+  static constexpr int step = t1_padded<P>() ? 0 : ((S >> P::L1) & 15);
+  static_assert(S % 32 == 0 && P::T % 32 == 0 && (step == 0 || step == 8), "T1 read is base(+alt base) + offset");
+  static_assert(t1_padded<P>() || P::NB2 == 1, "the XOR layout's bases are written for one pass-2 butterfly per thread");
+};
+
 template <class P>
 MX_HD void load_t1(int t, cpx (&v)[P::E], const cpx *lds) {
-  // swz1(j + r*S) = (swz1(j) ^ c_r) + r*S with c_r = (r * (S >> L1)) & 15: the stride S = M/R2
-  // only reaches the swizzle's source field [L1, L1+4) through its top bit (c_r in {0, 8}) or not at all
-  constexpr int S = P::M / P::R2;
-  constexpr int step = (S >> P::L1) & 15;
-  static_assert(step == 0 || step == 8, "T1 read is base(+alt base) + offset");
+  using R = T1Read<P>;
+  const int s1 = t1_index<P>(t);
 #ifdef MX_LDS_ASM
   mx_f2v q[P::E];
+  const uint32_t ae = lds_addr(lds + s1), ao = lds_addr(lds + (s1 ^ R::step));
   static_for<0, P::NB2>([&](auto bb) {
     constexpr int b = decltype(bb)::value;
-    const int s1 = swz1<P>(t + P::T * b);
-    const uint32_t ae = lds_addr(lds + s1), ao = lds_addr(lds + (s1 ^ step));
     static_for<0, P::R2>([&](auto rr) {
       constexpr int r = decltype(rr)::value;
-      q[b * P::R2 + r] = lds_rd64<r * S * 8>((r & 1) ? ao : ae);
+      q[b * P::R2 + r] = lds_rd64<(b * R::TP + r * R::SP) * 8>((r & 1) ? ao : ae);
     });
   });
   lds_wait(q);
 #pragma unroll
   for (int i = 0; i < P::E; ++i) v[i] = mk(q[i].x, q[i].y);
 #else
+  const cpx *pe = lds + s1, *po = lds + (s1 ^ R::step);
 #pragma unroll
   for (int b = 0; b < P::NB2; ++b) {
-    const int s1 = swz1<P>(t + P::T * b);
-    const cpx *pe = lds + s1, *po = lds + (s1 ^ step);
 #pragma unroll
-    for (int r = 0; r < P::R2; ++r) v[b * P::R2 + r] = ((r & 1) ? po : pe)[r * S];
+    for (int r = 0; r < P::R2; ++r) v[b * P::R2 + r] = ((r & 1) ? po : pe)[b * R::TP + r * R::SP];
   }
 #endif
 }
@@ -615,16 +646,14 @@ template <class P>
 __device__ __forceinline__ void load_t1_tw2(int t, cpx (&v)[P::E], const cpx *lds, const cpx *ltw2,
                                             cpx (&w)[1][P::R2 - 1]) {
   static_assert(P::NB2 == 1 && P::E == P::R2 && P::E % 8 == 0, "one pass-2 butterfly per thread");
-  constexpr int S = P::M / P::R2;
-  constexpr int step = (S >> P::L1) & 15;
-  static_assert(step == 0 || step == 8, "T1 read is base(+alt base) + offset");
-  const int s1 = swz1<P>(t);
-  const uint32_t ae = lds_addr(lds + s1), ao = lds_addr(lds + (s1 ^ step));
+  using R = T1Read<P>;
+  const int s1 = t1_index<P>(t);
+  const uint32_t ae = lds_addr(lds + s1), ao = lds_addr(lds + (s1 ^ R::step));
   const uint32_t aw = lds_addr(ltw2 + (t & (P::R1 - 1)));
   mx_f2v q[2 * P::E];
   static_for<0, P::R2>([&](auto rr) {
     constexpr int r = decltype(rr)::value;
-    q[r] = lds_rd64<r * S * 8>((r & 1) ? ao : ae);
+    q[r] = lds_rd64<r * R::SP * 8>((r & 1) ? ao : ae);
   });
   static_for<1, P::R2>([&](auto rr) {
     constexpr int r = decltype(rr)::value;
@@ -721,17 +750,9 @@ MX_HD void store_t2(int t, const cpx (&v)[P::E], cpx *lds) {
     const int j = t + P::T * b;
     const int k = j & (P::R1 - 1);
     const int base = (j - k) * P::R2 + k;  // (j / R1) * R1 * R2 + k
-    if constexpr (P::R1 == 8) {
-      // swz2 flips bit 3 (= r & 1 here) by bit 7 (= (j >> 3) & 1): even r go to +8f, odd r to -8f
-      const int f8 = ((j >> 3) & 1) << 3;
-      cpx *pe = lds + base + f8, *po = lds + base - f8;
+    cpx *p = lds + base;
 #pragma unroll
-      for (int r = 0; r < P::R2; ++r) ((r & 1) ? po : pe)[r * P::R1] = v[b * P::R2 + r];
-    } else {
-      cpx *p = lds + base;
-#pragma unroll
-      for (int r = 0; r < P::R2; ++r) p[r * P::R1] = v[b * P::R2 + r];
-    }
+    for (int r = 0; r < P::R2; ++r) p[r * P::R1] = v[b * P::R2 + r];
   }
 }
 
@@ -747,37 +768,25 @@ MX_HD void load_t2(int t, cpx (&v)[P::E], const cpx *lds) {
   const int p = k0p<P>(t), q = k0q<P>(t);
 #ifdef MX_LDS_ASM
   {
-    constexpr int fl = (P::R1 == 8) ? 8 : 0;  // see the R1 == 8 note below
-    const uint32_t pe = lds_addr(lds + p), po = lds_addr(lds + (p ^ fl));
-    const uint32_t qe = lds_addr(lds + q), qo = lds_addr(lds + (q ^ fl));
+    const uint32_t pa = lds_addr(lds + p), qa = lds_addr(lds + q);
     mx_f2v w[P::E];
     static_for<0, P::R3>([&](auto rr) {
       constexpr int r = decltype(rr)::value;
-      w[r] = lds_rd64<P::NS3 * r * 8>((r & 1) ? po : pe);
-      w[P::R3 + r] = lds_rd64<P::NS3 * r * 8>((r & 1) ? qo : qe);
+      w[r] = lds_rd64<P::NS3 * r * 8>(pa);
+      w[P::R3 + r] = lds_rd64<P::NS3 * r * 8>(qa);
     });
     lds_wait(w);
 #pragma unroll
     for (int i = 0; i < P::E; ++i) v[i] = mk(w[i].x, w[i].y);
-    return;
+  }
+#else
+  const cpx *pp = lds + p, *qq = lds + q;
+#pragma unroll
+  for (int r = 0; r < P::R3; ++r) {
+    v[r] = pp[P::NS3 * r];
+    v[P::R3 + r] = qq[P::NS3 * r];
   }
 #endif
-  if constexpr (P::R1 == 8) {
-    // NS3 = 128: bit 7 of (k0 + 128 r) is r & 1 (k0 < 128), so odd r read from k0 ^ 8
-    const cpx *pe = lds + p, *po = lds + (p ^ 8), *qe = lds + q, *qo = lds + (q ^ 8);
-#pragma unroll
-    for (int r = 0; r < P::R3; ++r) {
-      v[r] = ((r & 1) ? po : pe)[P::NS3 * r];
-      v[P::R3 + r] = ((r & 1) ? qo : qe)[P::NS3 * r];
-    }
-  } else {
-    const cpx *pp = lds + p, *qq = lds + q;
-#pragma unroll
-    for (int r = 0; r < P::R3; ++r) {
-      v[r] = pp[P::NS3 * r];
-      v[P::R3 + r] = qq[P::NS3 * r];
-    }
-  }
 }
 
 // ---- pass 3 ----------------------------------------------------------------

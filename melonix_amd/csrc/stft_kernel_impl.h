@@ -49,6 +49,16 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
   return ((unsigned long long)mhi << 32) | mlo;
 }
 
+// One dword of a magnitude row: *(float *)((char *)base + off + IMM) = x, streaming (nt), with `base` wave-uniform
+// (an SGPR pair), `off` a 32-bit lane offset and IMM the instruction's 13-bit signed immediate.
+template <int IMM>
+__device__ __forceinline__ void st_row_nt(const float *base, unsigned off, float x) {
+  static_assert(IMM >= -4096 && IMM <= 4095, "global_store immediate offset");
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(off), "v"(x), "s"(base), "n"(IMM) : "memory");
+#endif
+}
+
 // WPE: waves per SIMD the register allocator must leave room for (amdgpu_waves_per_eu);
 // NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
 // and window loads are not hoisted out of the frame loop into hundreds of registers.
@@ -91,16 +101,18 @@ void stft_kernel(const StftArgs a0) {
   // CIRC (uniform hop, not a multiple of 2T samples): the register image holds the windowed samples by absolute
   // position and only the newest 2*hop of them are fetched per frame (stft_core.h, circular sliding window)
   static_assert(!CIRC || (MODE != kRanges && HOP == 0 && PREFETCH == 0 && !CMAP), "circular window: bulk modes");
-  __shared__ __attribute__((aligned(16))) float2 lds[C::M + kRed + (OUTSEP ? C::M / 2 : 0) + kTw2];
-  float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + C::M + kRed : lds);
-  float2 *const ltw2 = lds + C::M + kRed + (OUTSEP ? C::M / 2 : 0);
+  constexpr int IMG = t1_size<C>();  // the image with the first transposition's padding
+  __shared__ __attribute__((aligned(16))) float2 lds[IMG + kRed + (OUTSEP ? C::M / 2 : 0) + kTw2];
+  float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + IMG + kRed : lds);
+  float2 *const ltw2 = lds + IMG + kRed + (OUTSEP ? C::M / 2 : 0);
 
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;  // wave-uniform
   cpx u[kPostFly ? 1 : P::R3];  // post-split twiddles: E registers that replace R3 complex multiplies per frame
-  cpx ulo, uhi;
+  cpx ulo;  // (thread 0's second base, (-1, 0), is re-selected per frame in the one wavefront that holds thread 0)
   if constexpr (kPostFly) {
-    post_bases<P>(t_, a.ubase, ulo, uhi);
+    cpx uhi_unused;
+    post_bases<P>(t_, a.ubase, ulo, uhi_unused);
   } else {
     post_twiddles<P>(t_, a.ubase, *reinterpret_cast<cpx(*)[P::R3]>(&u));
   }
@@ -149,7 +161,7 @@ void stft_kernel(const StftArgs a0) {
   // during frame f+1 — scatter at the end of f, LDS read + global stores after f+1's T1 barrier —
   // so no barrier and no LDS round trip sits in the output path.
   static_assert(!DEFER || OUTSEP, "deferred output needs its own LDS region");
-  unsigned long long *const red = reinterpret_cast<unsigned long long *>(lds + C::M);
+  unsigned long long *const red = reinterpret_cast<unsigned long long *>(lds + IMG);
   auto flush_pitch = [&](int64_t fr, int tt) {  // after a barrier that follows red[] of frame fr
     if (a.pitch && tt == 0) {
       unsigned long long b = red[0];
@@ -325,13 +337,13 @@ void stft_kernel(const StftArgs a0) {
       if constexpr (kTw3Bases) pass3_bases<P, true>(t, v, w3base);
       else if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, true>(t, v, w3r);
       else pass3<P, true>(t, v, tw3);
-      if constexpr (kPostFly) post_fly<P, true>(t, v, ulo, uhi, mg);
+      if constexpr (kPostFly) post_fly<P, true>(t, v, ulo, csel(t == 0, mk(-1.0f, 0.0f), ulo), mg);
       else post<P, true>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
     } else {
       if constexpr (kTw3Bases) pass3_bases<P, false>(t, v, w3base);
       else if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, false>(t, v, w3r);
       else pass3<P, false>(t, v, tw3);
-      if constexpr (kPostFly) post_fly<P, false>(t, v, ulo, uhi, mg);
+      if constexpr (kPostFly) post_fly<P, false>(t, v, ulo, ulo, mg);
       else post<P, false>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
     }
 
@@ -390,19 +402,29 @@ void stft_kernel(const StftArgs a0) {
     // dword stores with one stray element each (thread 0's self-paired bins).
     if constexpr (DIRECT) {
       if (want_rows) {
-        // (wave-uniform row base + 32-bit lane offsets: the stores take the SGPR-base form, one v_add per store)
-        char *row = reinterpret_cast<char *>(a.mags + (size_t)f * (size_t)(N / 2));
-        const unsigned blo = 4u * (unsigned)out_lo, bhi = 4u * (unsigned)(out_hi + C::NS3 * (C::R3 / 2));
-        const unsigned nlo = 4u * (unsigned)(C::M - out_lo), nhi = 4u * (unsigned)(C::M - out_hi - C::NS3 * (C::R3 / 2));
-#pragma unroll
-        for (int s = 0; s < C::R3; ++s) {
-          constexpr int H = C::R3 / 2;
-          const unsigned o0 = s < H ? blo + 4u * (unsigned)(C::NS3 * s) : bhi + 4u * (unsigned)(C::NS3 * (s - H));
-          unsigned o1 = s < H ? nlo - 4u * (unsigned)(C::NS3 * s) : nhi - 4u * (unsigned)(C::NS3 * (s - H));
-          if (s == H) o1 = (t == 0) ? 4u * (unsigned)(C::M / 2) : o1;
-          __builtin_nontemporal_store(mg[2 * s], reinterpret_cast<float *>(row + (size_t)o0));
-          __builtin_nontemporal_store(mg[2 * s + 1], reinterpret_cast<float *>(row + (size_t)o1));
-        }
+        // Wave-uniform row base (SGPR pair) + 32-bit lane offset + 13-bit immediate.  Slot s sits 4*NS3 bytes above slot
+        // s - 1 (below, in the mirrored half): with 4*NS3 = 4096 two neighbouring slots share one lane offset, the second
+        // through the immediate (-4096), so a frame's 32 stores need 16 offset additions instead of 32.  The compiler's
+        // own address matching does not find this form (it falls back to 64-bit per-lane addresses): the store is
+        // spelled out.
+        const float *row = a.mags + (size_t)f * (size_t)(N / 2);
+        constexpr int H = C::R3 / 2;
+        constexpr int STEP = 4 * C::NS3;  // bytes between a thread's consecutive slots
+        static_assert(STEP == 4096, "slot pairs share an offset through the store's immediate");
+        const unsigned blo = 4u * (unsigned)out_lo, bhi = 4u * (unsigned)(out_hi + C::NS3 * H);
+        const unsigned nlo = 4u * (unsigned)(C::M - out_lo), nhi = 4u * (unsigned)(C::M - out_hi - C::NS3 * H);
+        static_for<0, C::R3>([&](auto ss) {
+          constexpr int s = decltype(ss)::value;
+          constexpr int sl = s < H ? s : s - H;
+          constexpr int su = sl | 1, sd = sl & ~1;  // the slot of the pair that carries the lane offset (going up / down)
+          const unsigned o0 = (s < H ? blo : bhi) + (unsigned)(su * STEP);
+          unsigned o1 = (s < H ? nlo : nhi) - (unsigned)(sd * STEP);
+          if constexpr (s == H) {  // thread 0's second slot of this pair is bin M/2 instead of the Nyquist bin
+            o1 = (t == 0) ? (unsigned)(4 * (C::M / 2)) + (unsigned)((sl - sd) * STEP) : o1;
+          }
+          st_row_nt<(sl - su) * STEP>(row, o0, mg[2 * s]);
+          st_row_nt<-(sl - sd) * STEP>(row, o1, mg[2 * s + 1]);
+        });
       }
     } else if (want_rows) {
       float *plo = lout + out_lo, *phi = lout + out_hi;

@@ -21,9 +21,9 @@ void emu_from_state(std::vector<cpx> &Yall, float *mags, std::vector<int> *colli
   static const std::vector<cpx_h> tw2 = make_tw2<C>();
   static const std::vector<cpx_h> tw3 = make_tw3<C>();
   static const std::vector<cpx_h> ub = make_ubase<C>();
-  std::vector<cpx> lds((size_t)C::M);
+  std::vector<cpx> lds((size_t)t1_size<C>());
   std::vector<cpx> regs((size_t)C::T * E);
-  std::vector<char> written((size_t)C::M);
+  std::vector<char> written((size_t)t1_size<C>());
   auto V = [&](int t) -> cpx(&)[E] { return *reinterpret_cast<cpx(*)[E]>(&regs[(size_t)t * E]); };
   auto Y = [&](int t) -> cpx(&)[E] { return *reinterpret_cast<cpx(*)[E]>(&Yall[(size_t)t * E]); };
 
@@ -31,10 +31,10 @@ void emu_from_state(std::vector<cpx> &Yall, float *mags, std::vector<int> *colli
   std::fill(written.begin(), written.end(), 0);
   for (int t = 0; t < C::T; ++t) {
     store_t1<C>(t, V(t), lds.data());
-    // the closed-form addresses of store_t1 must be the swizzle swz1 of the logical index
+    // the closed-form addresses of store_t1 must be the padded layout t1_index of the logical index
     for (int b = 0; b < C::NB1; ++b)
       for (int r = 0; r < C::R1; ++r) {
-        const int a = swz1<C>((t + C::T * b) * C::R1 + r);
+        const int a = t1_index<C>((t + C::T * b) * C::R1 + r);
         const cpx got = lds[(size_t)a], want = V(t)[b * C::R1 + r];
         if ((got.x != want.x || got.y != want.y) && collisions) collisions->push_back(-a - 1);
         if (written[(size_t)a]++ && collisions) collisions->push_back(a);
@@ -175,7 +175,6 @@ int run(const float *wav, long n, int start, int end, int hop_mode, float *mags)
 // returns the number of LDS index collisions (must be 0), or <0 on bad N
 extern "C" int emu_stft_frame(int N, int E, const float *wav, long n, int start, int end, int hop_mode,
                               float *mags) {
-  if (N == 4096 && E == 32) return run<Plan<4096, 32>>(wav, n, start, end, hop_mode, mags);
   if (N == 4096 && E == 16) return run<Plan<4096, 16>>(wav, n, start, end, hop_mode, mags);
   if (N == 16384 && E == 32) return run<Plan<16384, 32>>(wav, n, start, end, hop_mode, mags);
   if (N == 32768 && E == 32) return run<Plan<32768, 32>>(wav, n, start, end, hop_mode, mags);
@@ -184,7 +183,6 @@ extern "C" int emu_stft_frame(int N, int E, const float *wav, long n, int start,
 
 // frames [first, first+count) with the sliding register image; mags = count x N/2
 extern "C" int emu_stft_slide(int N, int E, int hop, const float *wav, long n, long first, long count, float *mags) {
-  if (N == 4096 && E == 32 && hop == 256) return run_slide<Plan<4096, 32>, 256>(wav, n, first, count, mags);
   if (N == 4096 && E == 16 && hop == 256) return run_slide<Plan<4096, 16>, 256>(wav, n, first, count, mags);
   if (N == 16384 && E == 32 && hop == 512) return run_slide<Plan<16384, 32>, 512>(wav, n, first, count, mags);
   if (N == 4096 && E == 16 && hop == 512) return run_slide<Plan<4096, 16>, 512>(wav, n, first, count, mags);

@@ -87,14 +87,9 @@ def test_stft_kernels_do_not_spill():
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
     vgprs = [int(x) for x in re.findall(r"\bVGPRs: (\d+)", out.stderr)]
     assert len(names) == len(scratch) == len(vgprs) and len(names) >= 9
-    # known exceptions: the two-slot sliding kernel of N = 16384 / hop 1024 parks five dwords, the sliding kernel of
-    # N = 32768 / hop 1024 two (with its row stores straight from the registers) — each is still the faster way to run
-    # its hop (stft_kernels.hip, Tune::slides / Tune::DIRECT)
-    # ... and so does the circular-window kernel of N = 32768 (template flags ... DIRECT, CIRC = true, true)
-    allowed = {"PlanILi16384ELi32EEELi0ELi1024E": 24, "PlanILi32768ELi32EEELi0ELi1024E": 12,
-               "PlanILi32768ELi32EEELi1ELi0ELi2ELb1ELb1ELi6ELb0ELb0ELi0ELb0ELb0ELb1ELb1EEE": 12}
-    bad = [(n, s) for n, s in zip(names, scratch)
-           if "stft_kernel" in n and s > max([v for k, v in allowed.items() if k in n] or [0])]
+    # no exceptions (round 3: the three kernels that parked 12-24 bytes per lane lost thread 0's second post-split base
+    # register — it is re-selected per frame in the one wavefront that holds thread 0 — and are scratch-free as well)
+    bad = [(n, sc) for n, sc in zip(names, scratch) if "stft_kernel" in n and sc != 0]
     assert not bad, bad
     assert max(vgprs) <= 256
 

@@ -217,9 +217,9 @@ def test_config4_whole_hour_vs_oracle(gpu_ctx, oracle, hour):
 
 def test_reference_size_whole_hour_vs_oracle(gpu_ctx, oracle, hour):
     """The reference's own transform (N = 32768, spec.cpp:8) at its default column width (375 samples) over the hour: all
-    460 800 pitch records; every 8th chunk of 1024 rows plus both ends (>= 57 000 rows, 3.8 GB)."""
-    F, rows = _whole_config_vs_oracle(gpu_ctx, oracle, hour, 32768, 375, chunk=1024, every=8)
-    assert F == 460800 and rows >= 57000
+    460 800 pitch records and all 460 800 magnitude rows (30.2 GB, pulled back in chunks of 1024 rows)."""
+    F, rows = _whole_config_vs_oracle(gpu_ctx, oracle, hour, 32768, 375, chunk=1024, every=1)
+    assert F == 460800 and rows == F
 
 
 def test_resynth_full_size_properties(gpu_ctx, mxlib, hour):

@@ -12,7 +12,7 @@ import melonix_amd as mx  # noqa: E402
 
 if os.environ.get("MX_AB_LIB"):  # A/B against another build of the library (tools/ab_prev.sh)
     mx._capi.LIB_PATH = os.environ["MX_AB_LIB"]
-from bench import SR, b_alg, gen_shard  # noqa: E402
+from bench import SR, PowerSampler, b_alg, gen_shard  # noqa: E402
 
 dev = torch.device("cuda", 0)
 sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(32768, 375), (32768, 1024), (16384, 512)]
@@ -27,16 +27,22 @@ for N, hop in sizes:
     pitch = torch.empty((F, 2), dtype=torch.int32, device=dev)
     band = mx.pitch_band(N, SR)
     fn = lambda: ctx.stft_hop_dev(audio, N, hop, 0, F, mags.data_ptr(), pitch.data_ptr(), band=band)  # noqa: E731
-    for _ in range(6):  # (fresh output buffers fault their pages in, and a fresh box ramps for a few launches)
+    # (fresh output buffers fault their pages in, and a fresh box ramps for ~25 launches before the power manager settles)
+    WARM, REPS = int(os.environ.get("MX_WARM", 40)), int(os.environ.get("MX_REPS", 150))
+    for _ in range(WARM):
         fn()
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(5):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / 5
-    print(N, hop, round(ms, 3), round(b_alg(N, hop) * F / ms / 1e6 / 8000, 3), flush=True)
+    with PowerSampler(0) as ps:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(REPS):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / REPS
+    sm = ps.summary() or {}
+    w, mhz = sm.get("watts"), sm.get("sclk_mhz")
+    print(N, hop, round(ms, 4), round(b_alg(N, hop) * F / ms / 1e6 / 8000, 4),
+          f"{w:.0f} W {mhz:.0f} MHz {w * ms * 1e-3 / F * 1e6:.3f} uJ/frame {ms * 1e-3 * mhz:.1f} Mcycles" if w else "", flush=True)
     del mags, pitch
     torch.cuda.empty_cache()
