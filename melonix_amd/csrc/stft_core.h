@@ -237,6 +237,11 @@ MX_HD cpx ld_pair(const float *base, int i) {
   }
 }
 
+// one float at element index i (a 32-bit, non-negative offset) from a wave-uniform base
+MX_HD float ld_one(const float *base, int i) {
+  return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)(4u * (unsigned)i));
+}
+
 template <class P, int WSTEP, bool ALIGNED8>
 MX_HD void load_frame(int t, cpx (&Y)[P::E], const float *x, const float *w) {
 #pragma unroll
@@ -485,10 +490,11 @@ MX_HD void circ_fetch(int t, const float *xs, const float *wt, const CircGeo<P> 
     int d0 = (c2 - g.cr) & (P::N - 1), d1 = (c2 + 1 - g.cr) & (P::N - 1);
     d0 = d0 < g.len ? d0 : g.len - 1;
     d1 = d1 < g.len ? d1 : g.len - 1;
-    px[2 * k] = xs[d0];
-    px[2 * k + 1] = xs[d1];
-    pw[2 * k] = wt[d0];
-    pw[2 * k + 1] = wt[d1];
+    // (wave-uniform bases + non-negative 32-bit lane offsets: SGPR-base loads, no 64-bit address arithmetic per load)
+    px[2 * k] = ld_one(xs, d0);
+    px[2 * k + 1] = ld_one(xs, d1);
+    pw[2 * k] = ld_one(wt, d0);
+    pw[2 * k + 1] = ld_one(wt, d1);
   }
 }
 template <class P, int S>

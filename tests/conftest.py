@@ -56,6 +56,19 @@ def gpu_ctx(mxlib):
     ctx.close()
 
 
+def loaded_hip():
+    """ctypes handle of the HIP runtime THIS process already runs on — the one libmelonix_amd.so resolved.  (torch, if
+    an earlier test imported it, carries its own copy; opening a second runtime by name would see no device.)"""
+    import ctypes as C
+    path = "libamdhip64.so"
+    with open("/proc/self/maps") as maps:
+        for line in maps:
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                break
+    return C.CDLL(path)
+
+
 def mag_tol(ref_rows):
     """max_k |g-r| <= 2e-5 * max_k r + 1e-9 per frame (fp32 LDS FFT vs the f64 path)."""
     return 2e-5 * ref_rows.max(axis=-1, keepdims=True) + 1e-9

@@ -274,7 +274,8 @@ def test_resynth_dev_writes_every_sample_of_a_refill(gpu_ctx, oracle, mxlib):
     from melonix_amd import _capi
     L = _capi.lib()
     dp, df, di = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    hip = C.CDLL("libamdhip64.so")
+    from conftest import loaded_hip
+    hip = loaded_hip()
     assert hip.hipMalloc(C.byref(dp), st.nbytes) == 0 and hip.hipMalloc(C.byref(df), total * 4) == 0 and hip.hipMalloc(C.byref(di), total * 2) == 0
     hip.hipMemset(df, 0x7F, total * 4)
     hip.hipMemset(di, 0x7F, total * 2)

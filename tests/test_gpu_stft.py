@@ -202,7 +202,8 @@ def test_errors_newer_entry_points(gpu_ctx, mxlib):
         mxlib.pv_shard_frames(50000, 0.0, 3, 2)
     a2.free()
     c2.close()
-    hip = C.CDLL("libamdhip64.so")  # the runtime the library itself uses (no torch: one HIP runtime per process)
+    from conftest import loaded_hip
+    hip = loaded_hip()  # the runtime the library itself uses (one HIP runtime per process)
     buf = C.c_void_p()
     assert hip.hipMalloc(C.byref(buf), C.c_size_t(4 * (50000 + 2 * mxlib.MX_AUDIO_PAD) + 64)) == 0
     out = C.c_void_p()
