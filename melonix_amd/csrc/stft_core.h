@@ -341,14 +341,6 @@ MX_HD void load_raw(int t, cpx (&xr)[P::E], const float *x) {
     xr[e] = ld_pair<ALIGNED8>(x, 2 * (t + P::T * e));
   }
 }
-// slots [E0, E1) only (a prefetch issued in two halves keeps fewer registers in flight at a time)
-template <class P, bool ALIGNED8, int E0, int E1>
-MX_HD void load_raw_part(int t, cpx (&xr)[P::E], const float *x) {
-#pragma unroll
-  for (int e = E0; e < E1; ++e) {
-    xr[e] = ld_pair<ALIGNED8>(x, 2 * (t + P::T * e));
-  }
-}
 template <class P, int WSTEP, bool ALIGNED8>
 MX_HD void apply_window(int t, cpx (&Y)[P::E], const cpx (&xr)[P::E], const float *w) {
 #pragma unroll
@@ -696,43 +688,6 @@ MX_HD void pass2(int t, cpx (&v)[P::E], const cpx *tw2) {
   }
 }
 
-// Twiddles of a thread are frame-invariant: with registers to spare (the two-wave plan) they
-// are fetched once per workgroup instead of once per frame.
-template <class P>
-MX_HD void fetch_tw2(int t, const cpx *tw2, cpx (&w)[P::NB2][P::R2 - 1]) {
-#pragma unroll
-  for (int b = 0; b < P::NB2; ++b) {
-    const int k = (t + P::T * b) & (P::R1 - 1);
-#pragma unroll
-    for (int r = 1; r < P::R2; ++r) w[b][r - 1] = tw2[(r - 1) * P::R1 + k];
-  }
-}
-// Two-level pass-2 twiddles (one butterfly per thread, R2 = 16): w_r = beta^r with beta = exp(-2*pi*i*k/(R1*R2)) this
-// thread's base.  Six powers stay in registers (beta^1..3 and beta^4, 8, 12); the other nine are one complex product
-// each per frame — 18 packed instructions instead of 15 LDS reads (an LDS read costs ~10x the energy of a packed op).
-template <class P>
-MX_HD void fetch_tw2_bases(int t, const cpx *tw2, cpx (&wb)[6]) {
-  static_assert(P::NB2 == 1 && P::R2 == 16, "two-level twiddles are written for one radix-16 butterfly per thread");
-  const int k = t & (P::R1 - 1);
-  constexpr int rr[6] = {1, 2, 3, 4, 8, 12};
-#pragma unroll
-  for (int i = 0; i < 6; ++i) wb[i] = tw2[(rr[i] - 1) * P::R1 + k];
-}
-template <class P>
-MX_HD void pass2_reg(cpx (&v)[P::E], const cpx (&w)[P::NB2][P::R2 - 1]);
-template <class P>
-MX_HD void pass2_bases(cpx (&v)[P::E], const cpx (&wb)[6]) {
-  cpx w[1][P::R2 - 1];
-#pragma unroll
-  for (int r = 1; r < P::R2; ++r) {
-    const int hi = r >> 2, lo = r & 3;  // beta^r = beta^(4*hi) * beta^lo
-    if (hi == 0) w[0][r - 1] = wb[lo - 1];
-    else if (lo == 0) w[0][r - 1] = wb[2 + hi];
-    else w[0][r - 1] = pk_cmul2(wb[2 + hi], wb[lo - 1]);
-  }
-  pass2_reg<P>(v, w);
-}
-
 template <class P>
 MX_HD void pass2_reg(cpx (&v)[P::E], const cpx (&w)[P::NB2][P::R2 - 1]) {
 #pragma unroll
@@ -805,33 +760,7 @@ MX_HD void load_t2(int t, cpx (&v)[P::E], const cpx *lds) {
 template <class P>
 MX_HD constexpr int q_index(int r) { return P::R3 + ((r + 1) & (P::R3 - 1)); }
 
-// MAY0 = false: the caller knows thread 0 is not in this wavefront, all thread-0 selects fold away.
-template <class P, bool MAY0 = true>
-MX_HD void pass3(int t, cpx (&v)[P::E], const cpx *tw3) {
-  constexpr int R = P::R3;
-  const int col = (MAY0 && t == 0) ? P::NS3 / 2 : t;
-  const bool t0 = MAY0 && (t == 0);
-  cpx inp[R], inq[R], wp[R], wq[R], out[R];
-  wp[0] = wq[0] = mk(1.0f, 0.0f);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    inp[r] = v[r];
-    inq[r] = v[R + r];
-  }
-#pragma unroll
-  for (int r = 1; r < R; ++r) {
-    const cpx w = tw3[(r - 1) * P::NS3 + col];
-    wp[r] = csel(t0, mk(1.0f, 0.0f), w);
-    wq[r] = w;
-  }
-  DftTw<R, 1, 0, false>::run(inp, wp, out);
-#pragma unroll
-  for (int r = 0; r < R; ++r) v[r] = out[r];
-  DftTw<R, 1, 0, true>::run(inq, wq, out);
-#pragma unroll
-  for (int r = 0; r < R; ++r) v[R + r] = out[r];
-}
-
+// (MAY0 = false below: the caller knows thread 0 is not in this wavefront, all thread-0 selects fold away)
 template <class P>
 MX_HD void fetch_tw3(int t, const cpx *tw3, cpx (&w)[P::R3 - 1]) {
   const int col = t ? t : P::NS3 / 2;

@@ -59,62 +59,58 @@ __device__ __forceinline__ void st_row_nt(const float *base, unsigned off, float
 #endif
 }
 
-// WPE: waves per SIMD the register allocator must leave room for (amdgpu_waves_per_eu);
-// NOHOIST: re-materialise the table pointers every frame so the (frame-invariant) twiddle
-// and window loads are not hoisted out of the frame loop into hundreds of registers.
-template <class P, int MODE, int HOP, int WPE, bool NOHOIST, bool XCDMAP = true, int TWREG = 0, bool OUTSEP = false,
-          bool DEFER = false, int PREFETCH = 0, bool EARLYBAR = false, bool CMAP = false, bool DIRECT = false, bool CIRC = false>
+// Template parameters (every combination that is instantiated ships: stft_kernels.hip):
+//   MODE / HOP   kBulkAligned with HOP > 0: the sliding window for that hop; HOP = 0: direct loads (or CIRC)
+//   WPE          waves per SIMD the register allocator must leave room for (amdgpu_waves_per_eu)
+//   DEFER        (the two-wave N = 4096 plan) the magnitude row and the pitch record of frame f leave the workgroup
+//                during frame f+1 through an LDS region of their own; the barrier that frees the image sits right
+//                after the T2 read, so the next T1 scatter can be issued while pass 1 is still computing
+//   PREFETCH     (direct modes) the next frame's raw samples are requested once pass 3 has freed the transform's registers
+//   CMAP         RGB8 texel output (the fused colormap of SpecCache::populateTex)
+//   DIRECT       (N = 32768) the row leaves straight from the registers, one dword per lane and slot
+//   CIRC         the circular sliding window (stft_core.h)
+// Twiddle placement follows from the plan: the pass-2 table always lives in LDS (shared by the workgroup's waves); with
+// R3 = 8 (N = 4096) a thread's seven pass-3 twiddles and its post-split twiddles stay in registers for the whole
+// workgroup; with R3 = 16 (N = 16384 / 32768) six pass-3 base powers stay in registers, the other nine twiddles are one
+// packed complex product each per frame and the post-split twiddles are rebuilt from their base per frame (12 + 2
+// registers instead of 30 + 32) — nothing comes from L2 per frame.
+// (Everything that depends only on the thread index is frame-invariant; left alone, LICM hoists ~150 addresses, masks
+// and table values out of the frame loop and the kernel spills.  The thread index is therefore re-materialised per
+// frame — an empty asm — which keeps the invariants as a handful of cheap VALU ops inside the loop.)
+template <class P, int MODE, int HOP, int WPE, bool DEFER = false, bool PREFETCH = false, bool CMAP = false, bool DIRECT = false,
+          bool CIRC = false>
 __global__ __launch_bounds__(P::T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void stft_kernel(const StftArgs a0) {
   const StftArgs &a = a0;
   using C = P;
   constexpr int N = P::N;
   constexpr int NW = C::T / 64;  // wavefronts per frame
-  // one LDS object: the M-point image, then NW 8-byte reduction slots
-  // one LDS object: the M-point image, NW 8-byte reduction slots (padded to 16 B), and — OUTSEP — a
-  // separate M-float region for the magnitude transposition, so that the image can be refilled by
-  // the next frame without an extra barrier
+  // one LDS object: the image (with the first transposition's padding), NW 8-byte reduction slots (padded to 16 B),
+  // — DEFER — a separate M-float region for the magnitude transposition, so that the image can be refilled by the next
+  // frame without an extra barrier, and the pass-2 twiddle table
   constexpr int kRed = (NW > 1) ? ((NW + 1) / 2) * 2 : 0;
-  // TWREG == 2: the (small) pass-2 twiddle table lives in LDS, shared by the workgroup's waves
-  // TWREG == 3: tw2 in LDS, tw3 from L2;  TWREG == 4: nothing in LDS — six pass-2 base powers + the pass-3 twiddles
-  // in registers, the post-split twiddles rebuilt per frame (post_fly)
-  constexpr bool kTwoLevel = (TWREG == 4);
-  // PREFETCH (direct modes): 1 = the next frame's raw samples are requested once pass 3 has freed the transform's
-  // registers; 2 = right after pass 2 (into the registers its twiddles held), so that the load — bound by the ~15 B/clk
-  // a CU can have in flight from L2: 8 800 cycles for the 128 KiB of an N = 32768 frame — runs under the second
-  // transposition, pass 3 and the output instead of in front of pass 1.  With 2 the post-split twiddles are rebuilt per frame (post_fly): the
-  // registers they occupied hold samples in flight.
-  // TWREG == 5: placement 2 + post_fly;  TWREG == 6: pass-2 table in LDS, six pass-3 base powers in registers (the rest
-  // rebuilt per frame), post_fly — the 32-points-per-thread plans with a sliding frame image
-  constexpr bool kTw3Bases = (TWREG == 6);
-  constexpr bool kPostFly = kTwoLevel || (PREFETCH == 2) || (TWREG == 5) || kTw3Bases;
-  constexpr int kTw2 = (TWREG == 2 || TWREG == 3 || TWREG == 5 || TWREG == 6) ? ((C::TW2 + 1) / 2) * 2 : 0;
-  // EARLYBAR (needs DEFER): the barrier that frees the image for the next frame sits right after
-  // the T2 read instead of in front of the next T1 scatter, so that scatter can be issued while
-  // pass 1 is still computing (same number of barriers per frame).
-  static_assert(!EARLYBAR || DEFER, "the early barrier is written for the deferred-output schedule");
-  // DIRECT: the magnitude row leaves straight from the registers, one dword per lane and slot (a wavefront's 64
-  // lanes hold 64 consecutive bins of every slot: 256 contiguous bytes per store instruction), instead of being
-  // transposed through LDS into 16-byte stores: no LDS round trip and no barrier in the output path, and the pitch
-  // record of frame f is written after frame f+1's first barrier.
-  static_assert(!DIRECT || (NW > 1 && !DEFER && !OUTSEP && !CMAP), "direct row stores: multi-wave, non-deferred plans");
-  // CIRC (uniform hop, not a multiple of 2T samples): the register image holds the windowed samples by absolute
-  // position and only the newest 2*hop of them are fetched per frame (stft_core.h, circular sliding window)
-  static_assert(!CIRC || (MODE != kRanges && HOP == 0 && PREFETCH == 0 && !CMAP), "circular window: bulk modes");
-  constexpr int IMG = t1_size<C>();  // the image with the first transposition's padding
-  __shared__ __attribute__((aligned(16))) float2 lds[IMG + kRed + (OUTSEP ? C::M / 2 : 0) + kTw2];
-  float *const lout = reinterpret_cast<float *>(OUTSEP ? lds + IMG + kRed : lds);
-  float2 *const ltw2 = lds + IMG + kRed + (OUTSEP ? C::M / 2 : 0);
+  constexpr bool kTw3Bases = (P::R3 == 16);
+  constexpr int kTw2 = ((C::TW2 + 1) / 2) * 2;
+  static_assert(P::R3 == 16 || P::R3 == 8, "twiddle placement per plan");
+  static_assert(!DIRECT || (NW > 1 && !DEFER && !CMAP), "direct row stores: multi-wave, non-deferred plans");
+  static_assert(!CIRC || (MODE != kRanges && HOP == 0 && !PREFETCH && !CMAP), "circular window: bulk modes");
+  constexpr int IMG = t1_size<C>();
+  __shared__ __attribute__((aligned(16))) float2 lds[IMG + kRed + (DEFER ? C::M / 2 : 0) + kTw2];
+  float *const lout = reinterpret_cast<float *>(DEFER ? lds + IMG + kRed : lds);
+  float2 *const ltw2 = lds + IMG + kRed + (DEFER ? C::M / 2 : 0);
 
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;  // wave-uniform
-  cpx u[kPostFly ? 1 : P::R3];  // post-split twiddles: E registers that replace R3 complex multiplies per frame
+  cpx u[kTw3Bases ? 1 : P::R3];  // post-split twiddles (R3 = 8: registers that replace R3 complex multiplies per frame)
   cpx ulo;  // (thread 0's second base, (-1, 0), is re-selected per frame in the one wavefront that holds thread 0)
-  if constexpr (kPostFly) {
+  cpx w3r[kTw3Bases ? 1 : P::R3 - 1], w3base[6];
+  if constexpr (kTw3Bases) {
     cpx uhi_unused;
     post_bases<P>(t_, a.ubase, ulo, uhi_unused);
+    fetch_tw3_bases<P>(t_, a.tw3, w3base);
   } else {
     post_twiddles<P>(t_, a.ubase, *reinterpret_cast<cpx(*)[P::R3]>(&u));
+    fetch_tw3<P>(t_, a.tw3, *reinterpret_cast<cpx(*)[P::R3 - 1]>(&w3r));
   }
   const uint32_t bmask_ = band_mask<P>(t_, a.kmin, a.kmax);
   // output slots some lane of this wavefront needs for the pitch pick (wave-uniform)
@@ -125,24 +121,15 @@ void stft_kernel(const StftArgs a0) {
   constexpr bool kSlide = (MODE == kBulkAligned) && (HOP > 0) && Slide<P, (HOP > 0 ? HOP : 2)>::ok;
   constexpr int SD = Slide<P, (HOP > 0 ? HOP : 2)>::D;
   constexpr float kSc = 0.5f / (float)N;
-  // TWREG: this thread's pass-2/pass-3 twiddles live in registers for the whole workgroup
-  cpx w2r[TWREG == 1 ? P::NB2 : 1][P::R2 - 1], w3r[P::R3 - 1];
-  cpx w2base[6], w3base[6];
-  if constexpr (TWREG == 6) fetch_tw3_bases<P>(t_, a.tw3, w3base);
-  if constexpr (kTwoLevel) fetch_tw2_bases<P>(t_, a.tw2, w2base);
-  if constexpr (TWREG == 1) fetch_tw2<P>(t_, a.tw2, w2r);
-  if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) fetch_tw3<P>(t_, a.tw3, w3r);
-  if constexpr (TWREG == 2 || TWREG == 3 || TWREG == 5 || TWREG == 6) {
-    for (int i = t_; i < C::TW2; i += C::T) ltw2[i] = a.tw2[i];
-    MX_BARRIER();
-  }
+  for (int i = t_; i < C::TW2; i += C::T) ltw2[i] = a.tw2[i];
+  MX_BARRIER();
 
   // XCD-aware block -> frame-range map: the dispatcher places block b on XCD b % 8 and each
   // XCD has a private L2, so hand every XCD one contiguous eighth of the frame range: the
   // 15/16 overlap between neighbouring frame blocks is then an L2 hit instead of a second
   // fetch over the fabric.  (Bijective for any grid size; a different placement only costs speed.)
   unsigned lb = blockIdx.x;
-  if constexpr (XCDMAP) {
+  {
     const unsigned nb = gridDim.x, xcd = lb & 7u, q = nb >> 3, r = nb & 7u;
     lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lb >> 3);
   }
@@ -157,10 +144,9 @@ void stft_kernel(const StftArgs a0) {
     slide_edge<P, HOP>(t_, a.wtab, 2.0f * (float)N, edge);
   }
 
-  // DEFER (needs OUTSEP): the magnitude row and the pitch record of frame f leave the workgroup
-  // during frame f+1 — scatter at the end of f, LDS read + global stores after f+1's T1 barrier —
-  // so no barrier and no LDS round trip sits in the output path.
-  static_assert(!DEFER || OUTSEP, "deferred output needs its own LDS region");
+  // DEFER: the magnitude row and the pitch record of frame f leave the workgroup during frame f+1 — scatter at the
+  // end of f, LDS read + global stores after f+1's T1 barrier — so no barrier and no LDS round trip sits in the
+  // output path.
   unsigned long long *const red = reinterpret_cast<unsigned long long *>(lds + IMG);
   auto flush_pitch = [&](int64_t fr, int tt) {  // after a barrier that follows red[] of frame fr
     if (a.pitch && tt == 0) {
@@ -249,10 +235,7 @@ void stft_kernel(const StftArgs a0) {
     int t = t_;
     unsigned bmask = bmask_;
     int zoff = 0;
-    if constexpr (NOHOIST) {
-      asm volatile("" : "+v"(t), "+v"(bmask), "+s"(zoff));
-    }
-    const float2 *tw2 = a.tw2 + zoff, *tw3 = a.tw3 + zoff;
+    asm volatile("" : "+v"(t), "+v"(bmask), "+s"(zoff));
     int out_lo, out_hi;
     out_bases<P>(t, out_lo, out_hi);
 
@@ -289,18 +272,14 @@ void stft_kernel(const StftArgs a0) {
     cpx v[P::E];
     pass1<P>(Y, v);
 #if defined(MX_LDS_ASM)
-    constexpr bool kTw2Batch = (TWREG == 2 || TWREG == 3 || TWREG == 5 || TWREG == 6) && (P::NB2 == 1);  // twiddles ride with the T1 read
+    constexpr bool kTw2Batch = (P::NB2 == 1);  // one pass-2 butterfly per thread: its twiddles ride with the T1 read
 #else
-    constexpr bool kTw2Batch = false;
+    constexpr bool kTw2Batch = false;  // (host pass of this translation unit: the batch is hand-issued ds_read_b64)
 #endif
     cpx w2b[1][P::R2 - 1];
-    if constexpr (DEFER && !EARLYBAR) {
-      MX_BARRIER();  // every wave is past load_t2 / scatter / red[] of the previous frame
-      if (f > f0) flush_pitch(f - 1, t);
-    }
     store_t1<P>(t, v, lds);
     MX_BARRIER();
-    if constexpr (EARLYBAR || DIRECT) {
+    if constexpr (DEFER || DIRECT) {
       if (f > f0) flush_pitch(f - 1, t);
     }
     if constexpr (kTw2Batch) {
@@ -314,49 +293,32 @@ void stft_kernel(const StftArgs a0) {
       if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
     }
     MX_BARRIER();
-    if constexpr (kTwoLevel) pass2_bases<P>(v, w2base);
-    else if constexpr (TWREG == 1) pass2_reg<P>(v, w2r);
-    else if constexpr (kTw2Batch) pass2_reg<P>(v, w2b);
-    else if constexpr (TWREG >= 2) pass2<P>(t, v, ltw2);
-    else pass2<P>(t, v, tw2);
-    if constexpr (PREFETCH == 2 && !kSlide) {
-      if (f + 1 < f1) {  // the pass-2 twiddles are dead: their registers take the first half of the next frame's samples
-        const float *xn;
-        const float *wn;
-        frame_ptrs(f + 1, zoff, xn, wn);
-        asm volatile("" ::: "memory");  // (keeps the scheduler from hoisting these loads into pass 2's register peak)
-        load_raw_part<P, (MODE == kBulkAligned), 0, P::E / 2>(t, xr, xn);
-      }
-    }
+    if constexpr (kTw2Batch) pass2_reg<P>(v, w2b);
+    else pass2<P>(t, v, ltw2);
     store_t2<P>(t, v, lds);
     MX_BARRIER();
     load_t2<P>(t, v, lds);
-    if constexpr (!OUTSEP || EARLYBAR) MX_BARRIER();  // image free (for the magnitude scatter / the next T1 scatter)
+    MX_BARRIER();  // image free (for the magnitude scatter / — DEFER — the next T1 scatter)
     float mg[P::E];
     if (NW == 1 || wave0) {  // wave-uniform: only the first wavefront contains thread 0
-      if constexpr (kTw3Bases) pass3_bases<P, true>(t, v, w3base);
-      else if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, true>(t, v, w3r);
-      else pass3<P, true>(t, v, tw3);
-      if constexpr (kPostFly) post_fly<P, true>(t, v, ulo, csel(t == 0, mk(-1.0f, 0.0f), ulo), mg);
-      else post<P, true>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
+      if constexpr (kTw3Bases) {
+        pass3_bases<P, true>(t, v, w3base);
+        post_fly<P, true>(t, v, ulo, csel(t == 0, mk(-1.0f, 0.0f), ulo), mg);
+      } else {
+        pass3_reg<P, true>(t, v, *reinterpret_cast<cpx(*)[P::R3 - 1]>(&w3r));
+        post<P, true>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
+      }
     } else {
-      if constexpr (kTw3Bases) pass3_bases<P, false>(t, v, w3base);
-      else if constexpr (TWREG == 1 || TWREG == 2 || TWREG == 5 || kTwoLevel) pass3_reg<P, false>(t, v, w3r);
-      else pass3<P, false>(t, v, tw3);
-      if constexpr (kPostFly) post_fly<P, false>(t, v, ulo, ulo, mg);
-      else post<P, false>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
-    }
-
-    if constexpr (PREFETCH == 2 && !kSlide) {
-      if (f + 1 < f1) {  // ... and the transform's own registers the second half
-        const float *xn;
-        const float *wn;
-        frame_ptrs(f + 1, zoff, xn, wn);
-        asm volatile("" ::: "memory");
-        load_raw_part<P, (MODE == kBulkAligned), P::E / 2, P::E>(t, xr, xn);
+      if constexpr (kTw3Bases) {
+        pass3_bases<P, false>(t, v, w3base);
+        post_fly<P, false>(t, v, ulo, ulo, mg);
+      } else {
+        pass3_reg<P, false>(t, v, *reinterpret_cast<cpx(*)[P::R3 - 1]>(&w3r));
+        post<P, false>(t, v, *reinterpret_cast<cpx(*)[P::R3]>(&u), mg);
       }
     }
-    if constexpr (PREFETCH == 1 && !kSlide) {
+
+    if constexpr (PREFETCH && !kSlide) {
       // the transform's registers are free again: request the next frame's samples now, so that they
       // arrive under the pitch pick, the magnitude transposition and the row's stores
       if (f + 1 < f1) {
@@ -390,7 +352,7 @@ void stft_kernel(const StftArgs a0) {
         best = k1 > best ? k1 : best;
       }
       best = wave_max_u64(best);
-      if constexpr (NW > 1 || DEFER) {
+      if constexpr (NW > 1) {
         if ((t & 63) == 0) red[t >> 6] = best;  // published by the next barrier
       }
     }
@@ -441,9 +403,9 @@ void stft_kernel(const StftArgs a0) {
       if (want_rows) {
         MX_BARRIER();  // (also: every wave is past load_t2, so the image may be refilled)
         flush_row(f, t);
-        if constexpr (!OUTSEP) MX_BARRIER();  // image free again
+        MX_BARRIER();  // image free again
       } else {
-        if constexpr (NW > 1 || !OUTSEP) MX_BARRIER();
+        MX_BARRIER();
       }
       if constexpr (NW > 1) {
         flush_pitch(f, t);  // red[] is rewritten only after the next frame's T1/T2 barriers

@@ -18,59 +18,34 @@ namespace mx {
 namespace {
 
 // Register/occupancy policy per plan (measured on MI355X, profiles/).
-// One-wave plan (E = 32): LDS admits 160 KiB / (M*8 B) workgroups per CU = 2.5 / 2 / 2 waves per SIMD.
-// Two-wave plan for N = 4096 (E = 16): half the registers per thread, twice the resident waves.
+// N = 4096 (E = 16, two wavefronts per frame): 3 waves per SIMD; the 32-points-per-thread plans of N = 16384 / 32768:
+// LDS admits 2 / 1 workgroups per CU = 2 waves per SIMD.
+// Twiddle placement follows from the plan (stft_kernel_impl.h): every kernel of a plan does the same arithmetic, so the
+// rows of a one-frame bulk run are bit-identical to ranges mode.
 template <class P>
 struct Tune {
   static constexpr bool TWO_WAVE = (P::E == 16);
   static constexpr int WPE = TWO_WAVE ? 3 : 2;
-  static constexpr bool NOHOIST = true;
-  // Twiddle placement (measured, profiles/variants_*):
-  //   2 = this thread's pass-3 twiddles in registers for the whole workgroup + the pass-2 table in LDS
-  //       (no global twiddle loads at all);
-  //   3 = only the pass-2 table in LDS (1.9 / 3.8 / 7.9 KiB), pass-3 twiddles from L2 — for the sliding
-  //       N >= 16384 kernels, whose register image of the frame leaves no room for 30 more VGPRs;
-  //   (1 = all in registers: spills; 0 = both from L2 every frame.)
-  //   4 = (one radix-16 pass-2 butterfly per thread, i.e. N = 4096) no twiddle in LDS at all: six pass-2 base powers
-  //       and the pass-3 twiddles in registers, the other nine pass-2 twiddles and the post-split twiddles rebuilt
-  //       per frame (32 packed instructions instead of 15 LDS reads).  Measured: 1.89 ms either way at N = 4096 —
-  //       the twiddle reads are broadcasts (16 distinct words per wave instruction) and cost far less than the
-  //       transposition traffic — so 2 stays the default.
-  //   6 = (R3 = 16: the 32-points-per-thread plans) pass-2 table in LDS, SIX pass-3 base powers in registers (the
-  //       other nine twiddles are one packed complex product each per frame) and the post-split twiddles rebuilt per
-  //       frame: 12 + 4 registers instead of 30 + 32, so nothing comes from L2 per frame any more.  Measured
-  //       (tools/timeline_lab.hip, 60 min): N = 16384 / hop 512 4.38 -> 4.23 ms, N = 32768 / hop 1024 5.18 -> 5.01 ms,
-  //       N = 32768 / 375-sample columns (with the prefetch below) 16.07 -> 15.55 ms.
-  template <bool SLIDING, int HOP = 0>
-  static constexpr int twreg() {
-    // (every kernel of a plan does the same arithmetic: the rows of a one-frame run are bit-identical to ranges mode)
-    if constexpr (P::R3 == 16) return 6;
-    return 2;
-  }
   // Direct modes of the 32-points-per-thread plans: the next frame's samples are requested as soon as pass 3 has freed
-  // the transform's registers (PREFETCH = 1), so that they travel under the pitch pick, the row transposition and
-  // the row's stores.
-  static constexpr int PREFETCH = (P::E == 32) ? 1 : 0;
-  // hops the sliding kernel is instantiated for (the larger shifts D = hop/2T need more edge/prefetch registers
-  // and spill: measured with -Rpass-analysis, asserted scratch-free in tests/test_abi.py)
+  // the transform's registers, so that they travel under the pitch pick, the row transposition and the row's stores.
+  static constexpr bool PREFETCH = (P::E == 32);
+  // hops the sliding kernel is instantiated for (the larger shifts D = hop/2T need more edge/prefetch registers: every
+  // instantiation is asserted scratch-free in tests/test_abi.py)
   static constexpr bool slides(int hop) {
-    // (N = 16384 / hop 1024 — a two-slot shift — keeps five dwords in scratch with the twiddle bases held; it still
-    //  beats loading its frames directly, 2.33 against 2.89 ms per hour: tests/test_abi.py knows this one exception)
     return P::N == 4096 ? (hop == 256 || hop == 512) : P::N == 16384 ? (hop == 512 || hop == 1024) : hop == 1024;
   }
   // N = 32768 (one 128 KiB image per CU, every wavefront in the same phase): rows leave as dword stores straight from
   // the registers (256 contiguous bytes per wavefront instruction) — no LDS transposition and two barriers fewer per
-  // frame: 15.4 -> 14.8 ms per hour at 375-sample columns, 5.03 -> 4.89 ms at hop 1024.  (N = 16384 measures the
-  // same either way and keeps the transposition; the two-wave N = 4096 plan's row leaves in the shadow of the next frame.)
+  // frame.  Measured again under the power limit in round 3 (profiles/variants_r03_row_stores.log): 12.9 against 13.2 ms
+  // per hour at 375-sample columns with the transposition, and non-temporal against plain stores 12.9 / 13.2.
+  // (N = 16384 measures the same either way and keeps the transposition; the two-wave N = 4096 plan's row leaves in the
+  // shadow of the next frame.)
   static constexpr bool DIRECT = (P::N == 32768);
-  // The circular window (stft_core.h) for N = 16384 / 32768, hops up to 512 samples that do not slide by whole slots:
-  // N = 32768 at 375- / 512-sample columns 14.2 -> 12.8 and 10.4 -> 9.5 ms per hour, N = 16384 at 375 6.55 -> 6.0.
+  // The circular window (stft_core.h) for N = 16384 / 32768, hops up to 512 samples that do not slide by whole slots.
   // The two-wave N = 4096 plan loses with it (1.87 against 1.70 ms) and keeps its direct loads.
   static constexpr bool CIRC = (P::N >= 16384);
-  static constexpr bool OUTSEP = TWO_WAVE;  // own 8 KiB LDS region for the magnitude transposition ...
-  static constexpr bool DEFER = TWO_WAVE;   // ... so that frame f's row and pitch record leave during frame f+1
-  // with DEFER: free the image right after the T2 read, so the next T1 scatter can start under pass 1 (+1%)
-  static constexpr bool EARLYBAR = DEFER;
+  // the two-wave plan: frame f's row and pitch record leave during frame f+1 through their own 8 KiB LDS region
+  static constexpr bool DEFER = TWO_WAVE;
 };
 
 // Launches the sliding-window kernel for HOP if the plan can slide by it (Slide<P,HOP>::ok) and the call asks for it.
@@ -78,9 +53,7 @@ template <class P, int HOP>
 bool try_slide(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
   if constexpr (Slide<P, HOP>::ok && Tune<P>::slides(HOP)) {
     if (b.hop != HOP) return false;
-    constexpr int TRS = Tune<P>::template twreg<true, HOP>();
-    hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, HOP, Tune<P>::WPE, Tune<P>::NOHOIST, true, TRS, Tune<P>::OUTSEP,
-                                    Tune<P>::DEFER, 0, Tune<P>::EARLYBAR, false, Tune<P>::DIRECT>),
+    hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, HOP, Tune<P>::WPE, Tune<P>::DEFER, false, false, Tune<P>::DIRECT>),
                        grid, block, 0, s, b);
     return true;
   } else {
@@ -96,9 +69,7 @@ bool try_circ(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
     return false;
   } else {
     if (!Circ<P>::ok(b.hop)) return false;
-    constexpr int TRS = Tune<P>::template twreg<true, 0>();
-    hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, Tune<P>::WPE, Tune<P>::NOHOIST, true, TRS, Tune<P>::OUTSEP, Tune<P>::DEFER,
-                                    0, Tune<P>::EARLYBAR, false, Tune<P>::DIRECT, true>),
+    hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, Tune<P>::WPE, Tune<P>::DEFER, false, false, Tune<P>::DIRECT, true>),
                        grid, block, 0, s, b);
     return true;
   }
@@ -114,11 +85,7 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
   b.frames_per_block = g;
   const dim3 grid((unsigned)blocks), block(P::T);
   constexpr int W = Tune<P>::WPE;
-  constexpr bool NH = Tune<P>::NOHOIST;
-  constexpr int TRD = Tune<P>::template twreg<false>();
-  constexpr bool OS = Tune<P>::OUTSEP, DF = Tune<P>::DEFER, EB = Tune<P>::EARLYBAR;
-  constexpr int PF = Tune<P>::PREFETCH;
-  constexpr bool DR = Tune<P>::DIRECT;
+  constexpr bool DF = Tune<P>::DEFER, PF = Tune<P>::PREFETCH, DR = Tune<P>::DIRECT;
   switch (mode) {
     case kBulkAligned:
       // hops that are a small multiple of 2T samples slide the windowed frame through registers (one HBM read
@@ -126,17 +93,17 @@ hipError_t launch_plan(int mode, const StftArgs &a, hipStream_t s) {
       // frame directly
       if (!(try_slide<P, 256>(b, grid, block, s) || try_slide<P, 512>(b, grid, block, s) ||
             try_slide<P, 1024>(b, grid, block, s) || try_circ<P>(b, grid, block, s)))
-        hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, NH, true, TRD, OS, DF, PF, EB, false, DR>), grid, block, 0, s, b);
+        hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, 0, W, DF, PF, false, DR>), grid, block, 0, s, b);
       break;
     case kBulkAny:
       if (try_circ<P>(b, grid, block, s)) break;
-      hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, NH, true, TRD, OS, DF, PF, EB, false, DR>), grid, block, 0, s, b); break;
+      hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, W, DF, PF, false, DR>), grid, block, 0, s, b); break;
     case kRanges:
       // texel output (fused colormap) is its own instantiation: the binary64 cos/sin of the middle colour
       // segment must not weigh on the register allocation of the plain kernels
       // (and it gets the two-waves-per-SIMD register budget: screen-sized batches are not occupancy-bound)
-      if (a.rgb) hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, (W > 2 ? 2 : W), NH, true, TRD, OS, DF, 0, EB, true>), grid, block, 0, s, b);
-      else hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, NH, true, TRD, OS, DF, 0, EB, false, DR>), grid, block, 0, s, b);
+      if (a.rgb) hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, (W > 2 ? 2 : W), DF, false, true>), grid, block, 0, s, b);
+      else hipLaunchKernelGGL((stft_kernel<P, kRanges, 0, W, DF, false, false, DR>), grid, block, 0, s, b);
       break;
     default: return hipErrorInvalidValue;
   }

@@ -55,7 +55,9 @@ void emu_from_state(std::vector<cpx> &Yall, float *mags, std::vector<int> *colli
       post_bases<C>(t, reinterpret_cast<const cpx *>(ub.data()), lo, hi);
       post_fly<C>(t, V(t), lo, hi, mg);
     } else {
-      pass3<C>(t, V(t), reinterpret_cast<const cpx *>(tw3.data()));
+      cpx w3[C::R3 - 1];  // (the N = 4096 plan: pass-3 and post-split twiddles in registers, as in the kernel)
+      fetch_tw3<C>(t, reinterpret_cast<const cpx *>(tw3.data()), w3);
+      pass3_reg<C, true>(t, V(t), w3);
       cpx u[C::R3];
       post_twiddles<C>(t, reinterpret_cast<const cpx *>(ub.data()), u);
       post<C>(t, V(t), u, mg);
