@@ -228,3 +228,56 @@ def test_schedule_from_grain_table_equals_schedule_from_audio(mxlib, sweep10):
             a, ta, ea = mxlib.schedule_build_from(w, SR, s, l, mk, cur, need)
             b, tb, eb = mxlib.schedule_build_table(n, SR, s, l, firsts, mk, cur, need)
             assert _same_steps(a, b) and ta == tb and ea == eb
+
+
+def test_run_length_is_a_power_of_two_and_monotone(mxlib):
+    """mx_stft_run_length: the default run length of a bulk launch — a power of two, never above 32, never shrinking as
+    the launch grows (so that pinning a shard to the whole signal's value never asks for more than the kernels take), and
+    an error code for sizes the library does not have."""
+    from melonix_amd import _capi, shard
+    L = _capi.lib()
+    for N, hop in ((4096, 256), (4096, 375), (16384, 512), (16384, 375), (32768, 375), (32768, 1024)):
+        prev = 1
+        for count in (1, 2047, 2048, 4096, 5000, 70000, 112500, 337500, 675000, 5400000):
+            g = L.mx_stft_run_length(N, hop, count)
+            assert 1 <= g <= 32 and g & (g - 1) == 0, (N, hop, count, g)
+            assert g >= prev and g <= max(1, count // 2048) or g == 1
+            assert shard.run_length(N, hop, count) == g
+            prev = g
+    assert L.mx_stft_run_length(1024, 256, 1000) < 0 and L.mx_stft_run_length(4096, 0, 1000) < 0
+    # the advisor's counter-example (round 2): 10 min at 4096/256 is 112 500 frames -> runs of 32; one of two shards
+    # alone would have picked a shorter run — which is why a rank pins the whole signal's value
+    assert L.mx_stft_run_length(4096, 256, 112500) == 32 and L.mx_stft_run_length(4096, 256, 56250) == 16
+
+
+def test_bench_pcg32_stream_and_jump_ahead():
+    """bench.py's noise-input secondary draws PCG32 (XSH-RR 64/32) on the device by doubling blocks of LCG states: the
+    same numbers as the scalar recurrence, at any starting index (a rank's shard starts in the middle of the stream)."""
+    import torch
+    import bench as B
+    M = (1 << 64) - 1
+    inc = 3
+    st = (((0 * B.PCG_MULT + inc) & M) + 0x6D656C6F) & M
+    st = (st * B.PCG_MULT + inc) & M
+    ref = []
+    for _ in range(3000):
+        old = st
+        st = (old * B.PCG_MULT + inc) & M
+        x = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        ref.append(((x >> rot) | (x << ((-rot) & 31))) & 0xFFFFFFFF)
+    for i0, m in ((0, 3000), (1, 64), (777, 1000), (2999, 1)):
+        u = B.pcg32_uniform(torch, torch.device("cpu"), i0, m)
+        assert ((u + 1.0) * 2147483648.0).to(torch.int64).tolist() == ref[i0:i0 + m]
+        assert float(u.min()) >= -1.0 and float(u.max()) < 1.0
+    # add_noise: samples outside the whole signal stay zero, the pads of an inner shard carry the neighbours' draws
+    n, pad = 1000, 64
+    for rank in (0, 1):
+        a = torch.zeros(n + 2 * pad, dtype=torch.float32)
+        B.add_noise(torch, torch.device("cpu"), a, rank, 2, n, pad, level=1.0)
+        lo = rank * n - pad
+        want = torch.zeros(n + 2 * pad, dtype=torch.float64)
+        for j in range(n + 2 * pad):
+            if 0 <= lo + j < 2 * n:
+                want[j] = ref[lo + j] / 2147483648.0 - 1.0
+        assert torch.equal(a, want.to(torch.float32))
