@@ -304,6 +304,10 @@ def main() -> None:
     ap.add_argument("--no-resynth", action="store_true",
                     help="STFT+pitch only in the timed step (configs[1] alone) and no supplementary measurements")
     ap.add_argument("--no-supplementary", action="store_true", help="skip the end-to-end and phase-vocoder extras")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend of the pitch-track exchange (nccl = RCCL; gloo: test use)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="(testing the multi-rank logic on a one-GPU box) every rank runs on GPU 0")
     ap.add_argument("--no-noise-secondary", action="store_true", help="skip the noise-input secondary")
     ap.add_argument("--no-limiter-probe", action="store_true", help="skip the power / clock sample behind roofline.limiter")
     args = ap.parse_args()
@@ -321,6 +325,8 @@ def main() -> None:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU implementation", file=sys.stderr)
         sys.exit(3)
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -330,7 +336,10 @@ def main() -> None:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import melonix_amd as mx
 
@@ -339,6 +348,12 @@ def main() -> None:
     minutes = args.strong_total_minutes / world if strong else args.minutes
     n = int(round(minutes * 60 * SR))
     n -= n % hop  # shards start on frame boundaries so local and global frame indexing coincide
+    if world > 1:
+        # ... and on the kernels' run heads (32 frames; whole slots for the circular-window sizes), so that with the whole
+        # signal's run length pinned below every rank's rows and pitch records are the single-rank run's bit for bit
+        from melonix_amd import shard as _sh0
+
+        n -= n % (hop * _sh0.frame_align(N, hop))
     F = mx.frame_count(n, hop)
     pad = mx.MX_AUDIO_PAD
 
@@ -448,6 +463,11 @@ def main() -> None:
     # sanity: the last step produced a plausible pitch track (guards against a silently skipped kernel)
     bins = pitch_t[(args.steps - 1) & 1][:, 0].clone()
     ok = bool(((bins >= band[0]) & (bins <= band[1])).all().item())
+    import hashlib
+
+    # sha1 of this rank's pitch track after the last timed step (a sharded run's gathered track carries its own below:
+    # N ranks over one signal must reproduce the single-rank track of that signal bit for bit)
+    local_track_sha1 = hashlib.sha1(pitch_t[(args.steps - 1) & 1].cpu().numpy().tobytes()).hexdigest()
     exchange = None
     if use_dist:  # the gathered whole-signal track must contain this rank's shard, bit for bit
         g = gathered[(args.steps - 1) & 1]
@@ -456,7 +476,9 @@ def main() -> None:
         okt = torch.tensor([1 if ok else 0, 1 if g_ok else 0], device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok, g_ok = bool(okt[0].item()), bool(okt[1].item())
+        track_sha1 = hashlib.sha1(g.cpu().numpy().tobytes()).hexdigest()
         exchange = {"backend": dist.get_backend(), "collective": "all_gather_into_tensor", "async_op": True,
+                    "gathered_track_sha1": track_sha1,
                     "bytes_per_rank": int(pitch_t[0].numel() * 4), "world_size": world,
                     "gathered_equals_local": g_ok,
                     "note": "per-rank pitch tracks (8 B/frame) stitched into the whole-signal track on RCCL's stream, "
@@ -635,6 +657,7 @@ def main() -> None:
             "kernels": kernels,
             # labelled secondary: BASELINE configs[1] alone (what round 1 quoted as `value`)
             "stft_pitch_only": {"frames_per_s": world * F / (kern_ms * 1e-3), "kernel_ms": kern_ms},
+            "pitch_track_sha1": local_track_sha1,
             "outputs_ok": ok,
         }
         if rs is not None:
