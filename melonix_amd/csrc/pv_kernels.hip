@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t to_turns(float re, float im) {
 __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   using P = PV;
   // the M-point image + the pass-2 twiddle table (2 KiB, shared by both waves); this thread's pass-3 twiddles stay
-  // in registers for the whole walk: no twiddle loads per frame (stft_kernel's TWREG = 2 arrangement)
+  // in registers for the whole walk: no twiddle loads per frame (stft_kernel's arrangement for the N = 4096 plan)
   constexpr int kTw2 = ((P::TW2 + 1) / 2) * 2;
   __shared__ __attribute__((aligned(16))) float2 lds[t1_size<P>() + kTw2];  // (image incl. the T1 padding, stft_core.h)
   __shared__ float red[2];

@@ -861,7 +861,7 @@ MX_HD void post(int t, const cpx (&v)[P::E], const cpx (&u)[P::R3], float (&mg)[
 
 // The same with the R3 post-split twiddles rebuilt from their base every frame (u[s] = base * exp(-2*pi*i*s/(2*R3)):
 // a rotation by a compile-time angle, two packed instructions) instead of being held in 2*R3 registers — the
-// registers go to the pass-2 twiddle bases (stft_kernel_impl.h, TWREG == 4), which saves R2-1 LDS reads per frame.
+// registers go to the sliding / circular frame image of the 32-points-per-thread plans (stft_kernel_impl.h, R3 == 16).
 template <class P, int S>
 struct PostFly {
   static MX_HD void run(cpx lo, cpx hi, cpx (&u)[P::R3]) {

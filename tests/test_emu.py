@@ -1,6 +1,6 @@
 """Runs the gfx950 kernel's per-thread templates (melonix_amd/csrc/stft_core.h) thread by thread
 on the CPU (tests/emu/stft_emu.cpp) and checks them against the oracle: index maps, LDS swizzle
-closed forms (bijective, equal to swz1/swz2), twiddles, the real-FFT split, the sliding window."""
+closed forms (bijective, equal to t1_index), twiddles, the real-FFT split, the sliding window."""
 import ctypes as C
 import os
 import subprocess
