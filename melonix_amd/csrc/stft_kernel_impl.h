@@ -365,23 +365,25 @@ void stft_kernel(const StftArgs a0) {
     if constexpr (DIRECT) {
       if (want_rows) {
         // Wave-uniform row base (SGPR pair) + 32-bit lane offset + 13-bit immediate.  Slot s sits 4*NS3 bytes above slot
-        // s - 1 (below, in the mirrored half): with 4*NS3 = 4096 two neighbouring slots share one lane offset, the second
-        // through the immediate (-4096), so a frame's 32 stores need 16 offset additions instead of 32.  The compiler's
-        // own address matching does not find this form (it falls back to 64-bit per-lane addresses): the store is
-        // spelled out.
+        // s - 1 (below, in the mirrored half): G = 8 KiB / (4*NS3) neighbouring slots share one lane offset and differ in the
+        // store's immediate (-4096 .. +2048), so a frame's 2*R3 stores need 2*R3/G offset additions (N = 32768: 16 instead
+        // of 32).  The compiler's own address matching does not find this form (it falls back to 64-bit per-lane
+        // addresses): the store is spelled out.
         const float *row = a.mags + (size_t)f * (size_t)(N / 2);
         constexpr int H = C::R3 / 2;
         constexpr int STEP = 4 * C::NS3;  // bytes between a thread's consecutive slots
-        static_assert(STEP == 4096, "slot pairs share an offset through the store's immediate");
+        constexpr int G = 8192 / STEP;    // slots per shared offset
+        static_assert((STEP == 4096 || STEP == 2048) && H % G == 0, "slot groups share an offset through the store's immediate");
         const unsigned blo = 4u * (unsigned)out_lo, bhi = 4u * (unsigned)(out_hi + C::NS3 * H);
         const unsigned nlo = 4u * (unsigned)(C::M - out_lo), nhi = 4u * (unsigned)(C::M - out_hi - C::NS3 * H);
         static_for<0, C::R3>([&](auto ss) {
           constexpr int s = decltype(ss)::value;
           constexpr int sl = s < H ? s : s - H;
-          constexpr int su = sl | 1, sd = sl & ~1;  // the slot of the pair that carries the lane offset (going up / down)
+          // the slot of the group whose position carries the lane offset (going up / going down)
+          constexpr int su = (sl & ~(G - 1)) + G / 2, sd = (sl & ~(G - 1)) + G / 2 - 1;
           const unsigned o0 = (s < H ? blo : bhi) + (unsigned)(su * STEP);
           unsigned o1 = (s < H ? nlo : nhi) - (unsigned)(sd * STEP);
-          if constexpr (s == H) {  // thread 0's second slot of this pair is bin M/2 instead of the Nyquist bin
+          if constexpr (s == H) {  // thread 0's mirrored bin of this slot is bin M/2 instead of the Nyquist bin
             o1 = (t == 0) ? (unsigned)(4 * (C::M / 2)) + (unsigned)((sl - sd) * STEP) : o1;
           }
           st_row_nt<(sl - su) * STEP>(row, o0, mg[2 * s]);

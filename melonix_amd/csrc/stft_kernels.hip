@@ -34,13 +34,16 @@ struct Tune {
   static constexpr bool slides(int hop) {
     return P::N == 4096 ? (hop == 256 || hop == 512) : P::N == 16384 ? (hop == 512 || hop == 1024) : hop == 1024;
   }
-  // N = 32768 (one 128 KiB image per CU, every wavefront in the same phase): rows leave as dword stores straight from
-  // the registers (256 contiguous bytes per wavefront instruction) — no LDS transposition and two barriers fewer per
-  // frame.  Measured again under the power limit in round 3 (profiles/variants_r03_row_stores.log): 12.9 against 13.2 ms
-  // per hour at 375-sample columns with the transposition, and non-temporal against plain stores 12.9 / 13.2.
-  // (N = 16384 measures the same either way and keeps the transposition; the two-wave N = 4096 plan's row leaves in the
-  // shadow of the next frame.)
-  static constexpr bool DIRECT = (P::N == 32768);
+  // The 32-points-per-thread plans: rows leave as dword stores straight from the registers (a wavefront's 64 lanes hold
+  // 64 consecutive bins of every slot: 256 contiguous bytes per store instruction, offsets shared between neighbouring
+  // slots through the store's immediate) — no LDS transposition and two barriers fewer per frame.  N = 32768 (one
+  // 128 KiB image per CU, every wavefront in the same phase), measured again under the power limit in round 3
+  // (profiles/variants_r03_row_stores.log): 12.9 against 13.2 ms per hour at 375-sample columns with the transposition, and
+  // non-temporal against plain stores 12.9 / 13.2.  N = 16384 (round 3, profiles/variants_r03_16384_direct.log): 9 % fewer
+  // shader cycles (8.3 against 9.1 M at hop 512), of which the power manager gives 2 % back as time (4.10 against 4.19 ms;
+  // hop 1024: 2.12 / 2.17; 375: the same) — round 2, with one offset addition per store, measured no difference.
+  // (The two-wave N = 4096 plan's row leaves in the shadow of the next frame.)
+  static constexpr bool DIRECT = (P::N >= 16384);
   // The circular window (stft_core.h) for N = 16384 / 32768, hops up to 512 samples that do not slide by whole slots.
   // The two-wave N = 4096 plan loses with it (1.87 against 1.70 ms) and keeps its direct loads.
   static constexpr bool CIRC = (P::N >= 16384);
