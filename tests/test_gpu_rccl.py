@@ -74,16 +74,16 @@ def test_bench_under_launcher_matches_plain_run_full_hour():
     assert 0.97 <= ratio <= 1.03, (plain["value"], dist["value"])
 
 
-def _bench_world2_one_device(args):
-    """bench.py with TWO ranks as two processes on the one GPU of the box (gloo carries the exchange: RCCL refuses two
+def _bench_ranks_one_device(args, world=2):
+    """bench.py with several ranks as that many processes on the one GPU of the box (gloo carries the exchange: RCCL refuses two
     ranks on one device) — the rank > 0 code paths on hardware: shard generation at an offset, the N - hop halo from the
     left neighbour, the pinned run length, the gathered-track check across ranks, MAX-over-ranks timing."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dist-backend", "gloo",
            "--single-device"] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -92,25 +92,28 @@ def _bench_world2_one_device(args):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("fft,hop,per_rank", [(4096, 256, 8192 * 1758), (32768, 375, 384000 * 45)])
-def test_two_ranks_on_one_device_reproduce_the_single_rank_track(fft, hop, per_rank):
+@pytest.mark.parametrize("fft,hop,per_rank,world", [(4096, 256, 8192 * 1758, 2), (32768, 375, 384000 * 45, 2),
+                                                    # BASELINE configs[3] itself: 8 h over 8 ranks, 60 min each (cut to
+                                                    # whole run heads: 674 976 frames per rank)
+                                                    (4096, 256, 172793856, 8)])
+def test_ranks_on_one_device_reproduce_the_single_rank_track(fft, hop, per_rank, world):
     """Strong scaling over ONE signal: two ranks (half the signal each, halo in the pad, the whole signal's run length
     pinned) gather a pitch track that is the single-rank run's bit for bit — at a size where a shard alone would have
     picked a shorter run length (10 min at 4096/256: the advisor's round-2 counter-example)."""
     # per_rank: samples per rank, a whole number of run heads (32 frames of 256; 1024 frames of 375: shard.frame_align)
-    minutes = 2 * per_rank / (60.0 * 48000.0)
+    minutes = world * per_rank / (60.0 * 48000.0)
     common = ["--steps", "4", "--warmup", "2", "--conditioning", "0", "--fft", str(fft), "--hop", str(hop),
               "--strong-total-minutes", repr(minutes), "--no-cpu-baseline", "--no-supplementary", "--no-noise-secondary",
               "--no-limiter-probe", "--no-resynth"]
     one, _ = _bench(common, False)
-    two = _bench_world2_one_device(common)
-    assert one["outputs_ok"] and two["outputs_ok"] and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    two = _bench_ranks_one_device(common, world)
+    assert one["outputs_ok"] and two["outputs_ok"] and two["n_gpus"] == world and two["scaling"] == "strong"
     assert two["exchange"]["backend"] == "gloo" and two["exchange"]["gathered_equals_local"] is True
-    assert two["config"]["frames_per_gpu"] == per_rank // hop and one["config"]["frames_per_gpu"] == 2 * per_rank // hop
+    assert two["config"]["frames_per_gpu"] == per_rank // hop and one["config"]["frames_per_gpu"] == world * per_rank // hop
     assert two["exchange"]["gathered_track_sha1"] == one["pitch_track_sha1"]
     log = os.environ.get("MX_RCCL_LOG")
     if log:
         with open(log, "a") as f:
-            f.write(json.dumps({"world2_one_device": {"fft": fft, "hop": hop, "minutes": minutes,
+            f.write(json.dumps({f"world{world}_one_device": {"fft": fft, "hop": hop, "minutes": minutes,
                                                       "track_sha1": one["pitch_track_sha1"],
                                                       "gathered_sha1": two["exchange"]["gathered_track_sha1"]}}) + "\n")
