@@ -11,7 +11,11 @@ import torch  # noqa: E402
 import melonix_amd as mx  # noqa: E402
 
 if os.environ.get("MX_AB_LIB"):  # A/B against another build of the library (tools/ab_prev.sh)
+    import ctypes
+
     mx._capi.LIB_PATH = os.environ["MX_AB_LIB"]
+    _other = ctypes.CDLL(mx._capi.LIB_PATH)  # an older revision may lack entry points this tool does not use
+    mx._capi.SIGNATURES = {k: v for k, v in mx._capi.SIGNATURES.items() if hasattr(_other, k)}
 from bench import SR, PowerSampler, b_alg, gen_shard  # noqa: E402
 
 dev = torch.device("cuda", 0)
