@@ -75,3 +75,26 @@ def test_facade_end_to_end(driver, oracle, tmp_path, N):
     got = np.fromfile(tmp_path / "refill.f32", np.float32)
     assert np.array_equal(got.view(np.uint32), rest.view(np.uint32))
     assert np.fromfile(tmp_path / "refill_cursor.f64", np.float64)[0] == cend
+
+
+def test_facade_without_device_row_cache(driver, oracle, tmp_path):
+    """MELONIX_SPEC_DEVICE_MB=0: no kept device rows, every batch through the staging-only calls — the path `Spec` falls
+    back to when the row cache cannot allocate.  Same rows and texels; a late getSpec and a changed
+    brightness cost transforms instead of copies / re-colourings (the driver checks the counts for this mode)."""
+    import os
+    N = 32768
+    w = accum_sweep(10 * SR)
+    w.tofile(tmp_path / "audio.f32")
+    env = dict(os.environ, MELONIX_SPEC_DEVICE_MB="0")
+    r = subprocess.run([driver, str(tmp_path / "audio.f32"), str(tmp_path), str(N)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cold_screen:" in r.stdout and "recolour_screen:" in r.stdout
+    bins = N // 2
+    keys = [(47000, 47375), (0, 256), (-500, -100), (100000, 100001)]
+    rows = np.fromfile(tmp_path / "rows.f32", np.float32).reshape(len(keys), bins)
+    ref = np.stack([oracle.spec_frame(w, N, s, e) for s, e in keys])
+    assert (np.abs(rows - ref) <= mag_tol(ref)).all()
+    tex = np.fromfile(tmp_path / "tex.u8", np.uint8).reshape(4, bins, 3)
+    texrows = np.fromfile(tmp_path / "texrows.f32", np.float32).reshape(4, bins)
+    for i in range(4):
+        assert np.array_equal(tex[i], oracle.colormap(texrows[i], 512.0 * 64))
