@@ -13,6 +13,12 @@ second of that whole step.  Weak scaling: every rank owns its own 60-minute shar
 sweep (configs[3]: 8 h over 8 GPUs) with the N-hop input halo of its left neighbour laid into its
 left pad, no data-path collective; the one exchange is an all-gather of the pitch tracks
 (8 B/frame), overlapped with the next step.  Rank 0 prints ONE JSON line.
+
+`value` is the contract's own region and nothing else: W untimed warm-up steps, then K timed steps between
+barrier + synchronize pairs, the first thing the process does with the device after its setup.  Everything
+else in the line is a labelled secondary measured afterwards (`value_conditioned`, `noise_input_secondary`,
+`pcm_gather_secondary`, the supplementary figures, `cpu_baseline`).  Under WORLD_SIZE > 1 the line carries
+`ranks`: every rank's own kernel times, package power, shader clock and PCI address.
 """
 from __future__ import annotations
 
@@ -299,7 +305,7 @@ def main() -> None:
     ap.add_argument("--pitch-only", action="store_true", help="do not materialise magnitudes")
     ap.add_argument("--frames-per-block", type=int, default=0)
     ap.add_argument("--conditioning", type=int, default=40,
-                    help="untimed steps run as part of the setup, before the --warmup steps (clock / power settling)")
+                    help="untimed steps between `value`'s region and the `value_conditioned` secondary (0: skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resynth", action="store_true",
                     help="STFT+pitch only in the timed step (configs[1] alone) and no supplementary measurements")
@@ -309,6 +315,8 @@ def main() -> None:
     ap.add_argument("--single-device", action="store_true",
                     help="(testing the multi-rank logic on a one-GPU box) every rank runs on GPU 0")
     ap.add_argument("--no-noise-secondary", action="store_true", help="skip the noise-input secondary")
+    ap.add_argument("--no-pcm-gather", action="store_true", help="(multi-rank) skip the PCM all-gather secondary")
+    ap.add_argument("--pcm-gather-reps", type=int, default=3)
     ap.add_argument("--no-limiter-probe", action="store_true", help="skip the power / clock sample behind roofline.limiter")
     args = ap.parse_args()
 
@@ -399,7 +407,7 @@ def main() -> None:
         rs = {"steps": steps_arr, "total": int(total), "d_steps": d_steps, "pcm": pcm_i, "grain_scan_s": t_gr,
               "grain_scan_warm_s": t_gr2, "schedule_host_s": t_sc}
 
-    def step(k: int, works: list, ev=None):
+    def step(k: int, works: list, ev=None, rs=None):
         if use_dist and k >= 2 and works[k - 2] is not None:
             works[k - 2].wait()  # the all-gather that read pitch buffer k&1 two steps ago is done
         if ev is not None:
@@ -417,12 +425,13 @@ def main() -> None:
         works.append(dist.all_gather_into_tensor(gathered[k & 1], pitch_t[k & 1], async_op=True)
                      if use_dist else None)
 
-    def timed_region(steps: int, warmup: int):
+    def timed_region(steps: int, warmup: int, rs):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize pairs; HIP events (torch events on
-        the stream the kernels are launched on) around each launch.  Returns (seconds max over ranks, STFT ms, resynth ms)."""
+        the stream the kernels are launched on) around each launch.  Returns (seconds max over ranks, STFT ms max over
+        ranks, resynth ms max over ranks, this rank's own STFT ms, this rank's own resynth ms)."""
         works = []
         for k in range(warmup):
-            step(k, works)
+            step(k, works, rs=rs)
         for wk in works[-2:]:
             if wk is not None:
                 wk.wait()
@@ -431,7 +440,7 @@ def main() -> None:
         works = []
         t0 = time.perf_counter()
         for k in range(steps):
-            step(k, works, ev[k])
+            step(k, works, ev[k], rs=rs)
         for wk in works[-2:]:
             if wk is not None:
                 wk.wait()
@@ -442,23 +451,28 @@ def main() -> None:
         red = torch.tensor([el, k_ms, r_ms], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(red, op=dist.ReduceOp.MAX)
-        return float(red[0].item()), float(red[1].item()), float(red[2].item())
+        return float(red[0].item()), float(red[1].item()), float(red[2].item()), k_ms, r_ms
 
-    # (1) the contract as written, on the box as it comes: W warm-up steps, K timed steps -> `value_no_conditioning`
-    elapsed_nc, kern_ms_nc, res_ms_nc = timed_region(args.steps, args.warmup)
+    # (1) THE CONTRACT, with nothing added: W untimed warm-up steps, then K timed steps between barrier + synchronize
+    # pairs -> `value`, `ms_per_step`, `roofline` (the first thing this process does with the device after its setup)
+    elapsed, kern_ms, res_ms, my_kern_ms, my_res_ms = timed_region(args.steps, args.warmup, rs)
 
-    # (2) Device conditioning (setup, like the schedule build above): a fresh box needs some tens of milliseconds of the
-    # actual load before its memory / fabric clocks and the power manager settle — the first ~25 launches of this step
-    # run 2-10 % slower than the steady state a sustained job sees.  These steps are untimed; the W warm-up steps and the
-    # K timed steps of the contract follow them -> `value` (both figures are in the line).
-    works = []
-    for k in range(args.conditioning):
-        step(k, works)
-    for wk in works[-2:]:
-        if wk is not None:
-            wk.wait()
-    barrier()
-    elapsed, kern_ms, res_ms = timed_region(args.steps, args.warmup)
+    # (2) labelled secondary `value_conditioned`: the same W + K region again after `--conditioning` more untimed steps.
+    # A fresh box needs some tens of milliseconds of the actual load before its memory / fabric clocks and the power
+    # manager settle — the first ~25 launches of this step run 2-10 % slower than the steady state a sustained job sees.
+    cond = None
+    if args.conditioning > 0:
+        works = []
+        for k in range(args.conditioning):
+            step(k, works, rs=rs)
+        for wk in works[-2:]:
+            if wk is not None:
+                wk.wait()
+        barrier()
+        el_c, k_c, r_c, _, _ = timed_region(args.steps, args.warmup, rs)
+        cond = {"value": world * F * args.steps / el_c, "ms_per_step": el_c / args.steps * 1e3, "stft_kernel_ms": k_c,
+                "resynth_kernel_ms": r_c, "conditioning_steps": args.conditioning,
+                "note": "the same W + K region after this many more untimed steps (clock / power settling); never `value`"}
 
     # sanity: the last step produced a plausible pitch track (guards against a silently skipped kernel)
     bins = pitch_t[(args.steps - 1) & 1][:, 0].clone()
@@ -545,7 +559,7 @@ def main() -> None:
         with PowerSampler(local_rank) as ps:
             works = []
             for k in range(reps):
-                step(k, works)
+                step(k, works, rs=rs)
             for wk in works[-2:]:
                 if wk is not None:
                     wk.wait()
@@ -558,31 +572,103 @@ def main() -> None:
                        "sclk_nominal_mhz": 2400.0, "samples": sm["samples"], "source": sm["source"],
                        "load": f"{reps} more steps of the timed workload, back to back, sampled from a host thread"}
 
+    # labelled secondary, multi-rank runs: the all-gather that assembles ONE int16 PCM stream from the ranks'
+    # shards — 345.6 MB per rank at configs[3], the only exchange of the path big enough to say anything about xGMI (the
+    # pitch-track gather of the timed step is 5.4 MB).  Issued asynchronously like the pitch-track gather (RCCL's own
+    # stream), timed call -> wait() -> synchronize per repetition; equal-sized exchange padded to the largest shard.
+    pcm_gather = None
+    if use_dist and rs is not None and not args.no_pcm_gather:
+        try:
+            sizes = [None] * world
+            dist.all_gather_object(sizes, int(rs["total"]))
+            m = int(max(sizes))
+            m += (-m) % 8  # whole 16-byte units
+            send = torch.zeros(m, dtype=torch.int16, device=dev)
+            send[: rs["total"]] = rs["pcm"]
+            recv = torch.empty(world * m, dtype=torch.int16, device=dev)
+            ts = []
+            for rep in range(args.pcm_gather_reps + 1):
+                barrier()
+                t0 = time.perf_counter()
+                wk = dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8), async_op=True)
+                wk.wait()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            tmax = torch.tensor([min(ts[1:])], dtype=torch.float64, device=dev)  # first repetition: connection setup
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            mine_ok = bool(torch.equal(recv[rank * m: rank * m + rs["total"]], rs["pcm"]))
+            others_ok = all(bool((recv[r * m: r * m + sizes[r] - 1500] != 0).any().item()) for r in range(world))
+            okt = torch.tensor([1 if (mine_ok and others_ok) else 0], device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            sec = float(tmax.item())
+            recv_bytes = 2.0 * m * (world - 1)  # what one rank receives from the others
+            pcm_gather = {"collective": "all_gather_into_tensor (uint8 view of int16 PCM)", "backend": dist.get_backend(),
+                          "bytes_per_rank": 2 * m, "samples_per_rank": sizes, "world_size": world, "seconds": sec,
+                          "recv_GBps_per_rank": recv_bytes / sec / 1e9 if world > 1 else None,
+                          "algbw_GBps": 2.0 * m * world / sec / 1e9,
+                          "xgmi_peak_GBps_per_rank": 7 * 153.0,
+                          "frac_of_xgmi_peak": (recv_bytes / sec / 1e9) / (7 * 153.0) if world > 1 else None,
+                          "gathered_ok": bool(okt.item()), "reps": args.pcm_gather_reps,
+                          "note": "best of reps after one untimed repetition, MAX over ranks; every rank ends up with the "
+                                  "whole stream (shard.gather_pcm's exchange); not part of the timed step"}
+            del send, recv
+        except Exception as exc:
+            pcm_gather = {"error": str(exc)}
+
     # labelled secondary (SURVEY 8d's optional variant): the same step on sweep + 1e-3 * U(-1,1) from PCG32 — a kernel at
     # the package power limit takes longer on data that toggles more wires; the grain table and the schedule are rebuilt
     # for the noisy signal, the timed region is the same W + K steps
     noise = None
     if not args.no_noise_secondary:
+        rs_n, setup_err = None, None
         try:
             add_noise(torch, dev, audio_t, rank, world, n, pad)
             torch.cuda.synchronize()
-            if rs is not None:
+            if rs is not None:  # its own grain table, schedule and PCM buffer: the clean run's `rs` is not touched
                 gs, gl, gf = ctx.grain_table_dev(audio)
                 mk = [(1, 0, 0, 3.0), (n - 1, 0, 0, 3.0)]
-                steps_arr, total, _ = mx.schedule_build_table(n, SR, gs, gl, gf, mk)
-                rs["steps"], rs["total"] = steps_arr, int(total)
-                rs["d_steps"] = torch.from_numpy(steps_arr.view(np.uint8).copy()).to(dev)
-                rs["pcm"] = torch.empty(total, dtype=torch.int16, device=dev)
-            el_n, k_n, r_n = timed_region(args.steps, args.warmup)
+                steps_n, total_n, _ = mx.schedule_build_table(n, SR, gs, gl, gf, mk)
+                rs_n = {"steps": steps_n, "total": int(total_n),
+                        "d_steps": torch.from_numpy(steps_n.view(np.uint8).copy()).to(dev),
+                        "pcm": torch.empty(total_n, dtype=torch.int16, device=dev)}
+        except Exception as exc:
+            setup_err = str(exc)
+        # the timed region below is collective (barrier, all-gather, all-reduce): every rank enters it or none does
+        flag = torch.tensor([0 if setup_err else 1], device=dev)
+        if use_dist:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not bool(flag.item()):
+            noise = {"error": setup_err or "the setup failed on another rank"}
+        else:
+            el_n, k_n, r_n, _, _ = timed_region(args.steps, args.warmup, rs_n)
             nb = pitch_t[(args.steps - 1) & 1][:, 0]
             noise = {"value": world * F * args.steps / el_n, "ms_per_step": el_n / args.steps * 1e3, "stft_kernel_ms": k_n,
                      "resynth_kernel_ms": r_n, "stft_frac": b_alg(N, hop, mags=not args.pitch_only) * F / (k_n * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "pitch_bins_equal_clean": float((nb == bins).float().mean().item()),
-                     "process_steps": int(len(rs["steps"])) if rs is not None else None,
+                     "process_steps": int(len(rs_n["steps"])) if rs_n is not None else None,
+                     "pcm_samples": rs_n["total"] if rs_n is not None else None,
                      "input": "the workload sweep + 1e-3 * U(-1,1), PCG32 XSH-RR (pcg32_srandom_r(0x6d656c6f, 1)), draw i for sample i",
                      "vs_clean": (world * F * args.steps / el_n) / (world * F * args.steps / elapsed)}
-        except Exception as exc:
-            noise = {"error": str(exc)}
+        del rs_n
+
+    # per-rank record (multi-rank runs): what each rank's own device did — a scaling curve below 0.9 can only be attributed
+    # (one hot / throttled device, a shared device, a slow host) with the ranks' own clocks and power next to their times
+    ranks = None
+    if use_dist:
+        pr = torch.cuda.get_device_properties(local_rank)
+        me = {"rank": rank, "local_rank": local_rank,
+              "pci": f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}",
+              "device": pr.name, "kernel_ms": my_kern_ms, "resynth_ms": my_res_ms,
+              "watts": limiter["watts"] if limiter else None, "sclk_mhz": limiter["sclk_mhz"] if limiter else None,
+              "cap_watts": limiter["cap_watts"] if limiter else None, "host": os.uname().nodename}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        distinct = len({(r["host"], r["pci"]) for r in ranks}) == world
+        if not args.single_device and not distinct:
+            if rank == 0:
+                print(f"bench.py: {world} ranks but only {len({(r['host'], r['pci']) for r in ranks})} distinct devices: "
+                      f"{[(r['rank'], r['pci']) for r in ranks]}", file=sys.stderr)
+            sys.exit(4)
 
     if rank == 0:
         balg = b_alg(N, hop, mags=not args.pitch_only)
@@ -620,10 +706,6 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "conditioning_steps": args.conditioning,
-            # the same W + K region on the box as it came, before the conditioning steps (the contract with nothing added)
-            "value_no_conditioning": world * F * args.steps / elapsed_nc,
-            "ms_per_step_no_conditioning": elapsed_nc / args.steps * 1e3,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
@@ -664,8 +746,14 @@ def main() -> None:
             line["resynth_setup"] = {"grain_scan_s": rs["grain_scan_s"], "grain_scan_warm_s": rs["grain_scan_warm_s"],
                                      "schedule_host_s": rs["schedule_host_s"],
                                      "note": "once per (audio, markers), before the timed region"}
+        if cond is not None:
+            line["value_conditioned"] = cond
         if exchange is not None:
             line["exchange"] = exchange
+        if ranks is not None:
+            line["ranks"] = ranks
+        if pcm_gather is not None:
+            line["pcm_gather_secondary"] = pcm_gather
         if noise is not None:
             line["noise_input_secondary"] = noise
         if pv is not None:

@@ -83,7 +83,9 @@ int mx_ctx_release_scratch(mx_ctx *ctx);
  * runs so that every CU gets work): mx_stft_run_length returns it (> 0; < 0 = error code).  A job that computes one
  * signal in several launches — the frame shards of a multi-GPU run — gets the rows of the single launch bit for bit by
  * starting every launch on a multiple of 32 frames and pinning its run length to the whole signal's:
- * mx_ctx_set_frames_per_block(ctx, mx_stft_run_length(N, hop, total_frames)) (0 = back to the default). */
+ * mx_ctx_set_frames_per_block(ctx, mx_stft_run_length(N, hop, total_frames)) (0 = back to the default).  The pin is
+ * per CONTEXT, not per (N, hop): it applies to every bulk launch of that context at any size until it is set back to 0
+ * (a job that mixes sizes re-pins between them); ranges-mode launches (mx_stft_ranges*) ignore it. */
 int mx_stft_run_length(int N, int hop, int64_t count);
 int mx_ctx_set_frames_per_block(mx_ctx *ctx, int frames);
 /* Page-locked host memory for the buffers the host-pointer entry points fill (magnitude / texel rows, PCM): a

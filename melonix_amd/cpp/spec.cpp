@@ -123,12 +123,15 @@ struct Spec::Impl {
   std::deque<std::weak_ptr<DevBatch>> devBatches;
   std::size_t devBytes = 0;
   std::size_t devBudget = std::size_t(1) << 30;
+  std::size_t devBudgetConfigured = devBudget;  // what MELONIX_SPEC_DEVICE_MB (or the default) asked for
   int devBudgetWarned = 0;
+  int keptSinceShrink = 0;  // batches kept since the budget was last cut: after kRegrowAfter of them it doubles back
   // what the worker has done so far (tests, MELONIX_TIMING)
   std::atomic<std::uint64_t> nLaunchedColumns{0}, nFetchedRows{0}, nRecolouredRows{0};
 
   explicit Impl(int fft) : N(fft) {
     if (const char *e = std::getenv("MELONIX_SPEC_DEVICE_MB")) devBudget = std::size_t(std::strtoull(e, nullptr, 10)) << 20;
+    devBudgetConfigured = devBudget;
   }
   bool usable() const { return ctx && audio; }
 
@@ -217,6 +220,12 @@ struct Spec::Impl {
       reserveDevice(keepBytes);
       mx_rows *kept = nullptr;
       rc = mx_stft_ranges_keep(ctx, audio, N, flat.data(), count, k, slab->mags, slab->rgb, &kept);
+      if (rc == MX_ERR_NOMEM) {
+        // no room next to whatever else lives on the device right now (a phase-vocoder arena, say): give back every
+        // batch the cache still holds and try once more before concluding anything about the budget
+        reserveDevice(devBudget);
+        rc = mx_stft_ranges_keep(ctx, audio, N, flat.data(), count, k, slab->mags, slab->rgb, &kept);
+      }
       if (rc == MX_OK) {
         dev = std::make_shared<DevBatch>();
         dev->ctx = ctx;
@@ -224,14 +233,28 @@ struct Spec::Impl {
         dev->bytes = keepBytes;
         devBatches.push_back(dev);
         devBytes += keepBytes;
+        // a shortage is usually transient (the arena is released again): the budget a failure halved grows back
+        // towards its configured value once keeping works again
+        constexpr int kRegrowAfter = 8;
+        if (devBudget < devBudgetConfigured && ++keptSinceShrink >= kRegrowAfter) {
+          devBudget = std::min(devBudgetConfigured, std::max<std::size_t>(devBudget * 2, keepBytes));
+          keptSinceShrink = 0;
+        }
       } else if (rc == MX_ERR_NOMEM) {
-        // no room for kept rows next to whatever else lives on the device (a phase-vocoder arena, say): the columns
-        // still get computed through the staging-only path below, and the row cache asks for half as much from now on
-        reserveDevice(devBudget);  // (drops every batch still held)
+        // still no room: the columns get computed through the staging-only path below, and the row cache asks for
+        // half as much until keeping has worked kRegrowAfter times again
         devBudget /= 2;
+        keptSinceShrink = 0;
         if (devBudgetWarned++ == 0)
           fprintf(stderr, "melonix_amd Spec worker: no device memory for the row cache (%s); budget now %zu MiB\n",
                   mx_last_error(), devBudget >> 20);
+      }
+    } else if (devBudget < devBudgetConfigured && keepBytes <= devBudgetConfigured) {
+      // the halved budget no longer admits a screen-sized batch: probe the configured one again every so often instead
+      // of recomputing every screen for the life of the Spec
+      if (++keptSinceShrink >= 8) {
+        devBudget = std::min(devBudgetConfigured, std::max<std::size_t>(devBudget * 2, keepBytes));
+        keptSinceShrink = 0;
       }
     }
     if (rc == MX_ERR_NOMEM) {  // over the budget, or the keep call could not allocate: rows leave through staging only

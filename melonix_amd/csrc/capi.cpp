@@ -208,9 +208,12 @@ int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_
   s.pitch = d_pitch;
   s.rgb = d_rgb;
   s.cmap_k = cmap_k;
-  s.frames_per_block = ctx->frames_per_block > 0 ? ctx->frames_per_block
-                       : run_length > 0         ? run_length
-                                                : default_frames_per_block(N, mode, hop, count);
+  // the context's pinned run length (mx_ctx_set_frames_per_block: the shards of a multi-GPU job, bench sweeps) is a
+  // property of BULK launches — ranges mode has no run heads (every column loads the exact table) and a screen-sized
+  // batch must keep its short runs so that every CU gets work
+  s.frames_per_block = (mode != kRanges && ctx->frames_per_block > 0) ? ctx->frames_per_block
+                       : run_length > 0                              ? run_length
+                                                                     : default_frames_per_block(N, mode, hop, count);
   if (mode != kRanges) {
     rc = get_wtab(ctx, N, hop, t, &s.wtab);
     if (rc) return rc;

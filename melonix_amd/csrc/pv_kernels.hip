@@ -119,12 +119,10 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     if (f > f0 && t < P::M / 32) a.pkmap[(size_t)(f - 1) * (P::M / 32) + t] = pkbits[t];  // 256 B per frame
     store_t1<P>(t, v, lds);
     __syncthreads();
-    cpx w2b[1][P::R2 - 1];
-#ifdef MX_LDS_ASM  // (device pass only: the batch is hand-issued ds_read_b64)
-    load_t1_tw2<P>(t, v, lds, ltw2, w2b);
-#endif
+    cpx w2[P::R2 - 1];
+    load_t1_tw2<P>(t, v, lds, ltw2, w2);
     __syncthreads();
-    pass2_reg<P>(v, w2b);
+    pass2_reg<P>(v, w2);
     store_t2<P>(t, v, lds);
     __syncthreads();
     load_t2<P>(t, v, lds);

@@ -636,16 +636,15 @@ MX_HD void load_t1(int t, cpx (&v)[P::E], const cpx *lds) {
 #endif
 }
 
-#ifdef MX_LDS_ASM
 // T1 read plus this thread's pass-2 twiddles (table in LDS) as one batch of plain
 // ds_read_b64 behind a single wait.  One butterfly per thread (NB2 == 1) only: the
 // twiddles then cost 2*(R2-1) registers for the length of pass 2.
 template <class P>
-__device__ __forceinline__ void load_t1_tw2(int t, cpx (&v)[P::E], const cpx *lds, const cpx *ltw2,
-                                            cpx (&w)[1][P::R2 - 1]) {
+MX_HD void load_t1_tw2(int t, cpx (&v)[P::E], const cpx *lds, const cpx *ltw2, cpx (&w)[P::R2 - 1]) {
   static_assert(P::NB2 == 1 && P::E == P::R2 && P::E % 8 == 0, "one pass-2 butterfly per thread");
   using R = T1Read<P>;
   const int s1 = t1_index<P>(t);
+#ifdef MX_LDS_ASM
   const uint32_t ae = lds_addr(lds + s1), ao = lds_addr(lds + (s1 ^ R::step));
   const uint32_t aw = lds_addr(ltw2 + (t & (P::R1 - 1)));
   mx_f2v q[2 * P::E];
@@ -662,9 +661,15 @@ __device__ __forceinline__ void load_t1_tw2(int t, cpx (&v)[P::E], const cpx *ld
 #pragma unroll
   for (int i = 0; i < P::E; ++i) v[i] = mk(q[i].x, q[i].y);
 #pragma unroll
-  for (int r = 1; r < P::R2; ++r) w[0][r - 1] = mk(q[P::E + r].x, q[P::E + r].y);
-}
+  for (int r = 1; r < P::R2; ++r) w[r - 1] = mk(q[P::E + r].x, q[P::E + r].y);
+#else
+  const cpx *pe = lds + s1, *po = lds + (s1 ^ R::step), *pw = ltw2 + (t & (P::R1 - 1));
+#pragma unroll
+  for (int r = 0; r < P::R2; ++r) v[r] = ((r & 1) ? po : pe)[r * R::SP];
+#pragma unroll
+  for (int r = 1; r < P::R2; ++r) w[r - 1] = pw[(r - 1) * P::R1];
 #endif
+}
 
 // ---- pass 2 ----------------------------------------------------------------
 // tw2[(r-1)*R1 + k] = exp(-2*pi*i*r*k/(R1*R2)), r = 1..R2-1, k = 0..R1-1
@@ -689,19 +694,17 @@ MX_HD void pass2(int t, cpx (&v)[P::E], const cpx *tw2) {
 }
 
 template <class P>
-MX_HD void pass2_reg(cpx (&v)[P::E], const cpx (&w)[P::NB2][P::R2 - 1]) {
+MX_HD void pass2_reg(cpx (&v)[P::E], const cpx (&w)[P::R2 - 1]) {  // NB2 == 1: the twiddles load_t1_tw2 brought
+  static_assert(P::NB2 == 1, "one pass-2 butterfly per thread");
+  cpx in[P::R2], ww[P::R2], out[P::R2];
+  ww[0] = mk(1.0f, 0.0f);
 #pragma unroll
-  for (int b = 0; b < P::NB2; ++b) {
-    cpx in[P::R2], ww[P::R2], out[P::R2];
-    ww[0] = mk(1.0f, 0.0f);
+  for (int r = 0; r < P::R2; ++r) in[r] = v[r];
 #pragma unroll
-    for (int r = 0; r < P::R2; ++r) in[r] = v[b * P::R2 + r];
+  for (int r = 1; r < P::R2; ++r) ww[r] = w[r - 1];
+  DftTw<P::R2, 1, 0, false>::run(in, ww, out);
 #pragma unroll
-    for (int r = 1; r < P::R2; ++r) ww[r] = w[b][r - 1];
-    DftTw<P::R2, 1, 0, false>::run(in, ww, out);
-#pragma unroll
-    for (int r = 0; r < P::R2; ++r) v[b * P::R2 + r] = out[r];
-  }
+  for (int r = 0; r < P::R2; ++r) v[r] = out[r];
 }
 
 template <class P>

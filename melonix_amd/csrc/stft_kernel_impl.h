@@ -271,30 +271,29 @@ void stft_kernel(const StftArgs a0) {
 
     cpx v[P::E];
     pass1<P>(Y, v);
-#if defined(MX_LDS_ASM)
-    constexpr bool kTw2Batch = (P::NB2 == 1);  // one pass-2 butterfly per thread: its twiddles ride with the T1 read
-#else
-    constexpr bool kTw2Batch = false;  // (host pass of this translation unit: the batch is hand-issued ds_read_b64)
-#endif
-    cpx w2b[1][P::R2 - 1];
+    // one pass-2 butterfly per thread (N = 4096, N = 32768): its twiddles ride with the T1 read, one batch, one wait
+    constexpr bool kTw2Batch = (P::NB2 == 1);
     store_t1<P>(t, v, lds);
     MX_BARRIER();
     if constexpr (DEFER || DIRECT) {
       if (f > f0) flush_pitch(f - 1, t);
     }
     if constexpr (kTw2Batch) {
-#ifdef MX_LDS_ASM
-      load_t1_tw2<P>(t, v, lds, ltw2, w2b);
-#endif
+      cpx w2[P::R2 - 1];
+      load_t1_tw2<P>(t, v, lds, ltw2, w2);
+      if constexpr (DEFER) {
+        if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
+      }
+      MX_BARRIER();
+      pass2_reg<P>(v, w2);
     } else {
       load_t1<P>(t, v, lds);
+      if constexpr (DEFER) {
+        if (f > f0) flush_row(f - 1, t);
+      }
+      MX_BARRIER();
+      pass2<P>(t, v, ltw2);
     }
-    if constexpr (DEFER) {
-      if (f > f0) flush_row(f - 1, t);  // previous frame's row: LDS -> HBM in the shadow of T1
-    }
-    MX_BARRIER();
-    if constexpr (kTw2Batch) pass2_reg<P>(v, w2b);
-    else pass2<P>(t, v, ltw2);
     store_t2<P>(t, v, lds);
     MX_BARRIER();
     load_t2<P>(t, v, lds);

@@ -31,11 +31,31 @@ def run_length(N: int, hop: int, total_frames: int) -> int:
 
 
 def pin_run_length(ctx, N: int, hop: int, total_frames: int) -> int:
-    """Make `ctx` cut its bulk launches at (N, hop) into the runs an unsharded launch over the WHOLE signal's
-    `total_frames` frames uses.  Every rank of a sharded job calls this before its launches."""
+    """Make `ctx` cut its bulk launches into the runs an unsharded launch at (N, hop) over the WHOLE signal's
+    `total_frames` frames uses.  Every rank of a sharded job calls this before its launches.
+
+    The pin is a property of the CONTEXT (mx_ctx_set_frames_per_block), not of (N, hop): it applies to every bulk
+    launch of that context, at any size, until `ctx.set_frames_per_block(0)` puts the default back (ranges-mode
+    launches ignore it).  A job that mixes sizes on one context re-pins between them; `pinned_run_length` below
+    restores the default on exit."""
     g = run_length(N, hop, total_frames)
     ctx.set_frames_per_block(g)
     return g
+
+
+class pinned_run_length:
+    """`with pinned_run_length(ctx, N, hop, total_frames) as g:` — pin_run_length for the duration of the block, the
+    context's default run length (0) restored afterwards, also when the block raises."""
+
+    def __init__(self, ctx, N: int, hop: int, total_frames: int):
+        self.ctx, self.args = ctx, (N, hop, total_frames)
+
+    def __enter__(self) -> int:
+        return pin_run_length(self.ctx, *self.args)
+
+    def __exit__(self, *exc):
+        self.ctx.set_frames_per_block(0)
+        return False
 
 
 def frame_align(N: int, hop: int) -> int:

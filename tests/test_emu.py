@@ -34,7 +34,7 @@ def test_single_frames(emu, oracle, N, E):
 
 
 @pytest.mark.parametrize("N,E,hop,first,count", [(4096, 16, 256, 520, 43), (4096, 16, 256, 0, 40),
-                                                  (4096, 16, 256, 520, 43), (16384, 32, 512, 0, 40), (16384, 32, 512, 250, 32),
+                                                  (16384, 32, 512, 0, 40), (16384, 32, 512, 250, 32),
                                                   (4096, 16, 512, 0, 24), (4096, 16, 512, 100, 20), (16384, 32, 1024, 3, 20),
                                                   (32768, 32, 1024, 0, 20), (32768, 32, 1024, 40, 18)])
 def test_sliding_window(emu, oracle, N, E, hop, first, count):
