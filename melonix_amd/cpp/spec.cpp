@@ -115,6 +115,9 @@ struct Spec::Impl {
   melonix::LruTable<Range, Row, pair_hash> rows{static_cast<std::size_t>(MaxRanges)};
   // key -> "somebody asked for the magnitudes" (getSpec); false = only texels are wanted so far (requestTexRow)
   std::unordered_map<Range, bool, pair_hash> pending;
+  // the batch the worker is computing right now (key -> magnitudes wanted): a column that is asked for again while its
+  // batch is on the device is neither queued nor computed a second time
+  std::unordered_map<Range, bool, pair_hash> inflight;
   std::atomic<bool> alive{true};
   std::atomic<float> texScale{0.f};  // 0 = no SpecCache attached: magnitudes only
   std::atomic<int> failures{0};
@@ -363,8 +366,16 @@ struct Spec::Impl {
             (mags ? wantM : wantT).push_back(kv.first);
           }
         }
+        inflight.swap(pending);
         pending.clear();
       }
+      struct Landed {  // the batch is no longer in flight when this scope is left, whichever way
+        Impl *self;
+        ~Landed() {
+          std::lock_guard<std::mutex> lk(self->mu);
+          self->inflight.clear();
+        }
+      } landed{this};
       if (!usable()) continue;  // no device: every column stays empty (the reference's failure mode)
       const bool trace = std::getenv("MELONIX_TIMING") != nullptr;
       const auto t0 = std::chrono::steady_clock::now();
@@ -453,6 +464,7 @@ auto Spec::getSpec(int start, int end) const -> std::vector<float> {
     // only the texel row of this column was brought back so far (SpecCache was its only consumer): the worker copies
     // the magnitudes from the device row (or computes them again if that was released), answering {} until they are
     // there — getSpec never blocks on the device (spec.cpp:28,41)
+    if (auto fl = impl->inflight.find(key); fl != impl->inflight.end() && fl->second) return {};  // on its way
     impl->pending[key] = true;
     impl->wake.notify_one();
     return {};
@@ -489,7 +501,7 @@ int Spec::requestTexView(int start, int end, float k, TexView &view) const {
       if (row->mag) return 2;  // the caller colours the getSpec row itself, as the reference does
       // texels of another scale and no magnitudes on the host: the worker re-colours the device row with k (or
       // computes the column again if that was released)
-      if (impl->pending.find(key) == impl->pending.end()) {
+      if (impl->pending.find(key) == impl->pending.end() && impl->inflight.find(key) == impl->inflight.end()) {
         impl->pending[key] = false;
         impl->wake.notify_one();
       }

@@ -161,8 +161,12 @@ int main(int argc, char **argv) {
       check(after.computedColumns == before.computedColumns, "a changed brightness costs no transform");
       check(after.recolouredRows - before.recolouredRows == 1280, "every column re-coloured from its cached device row");
     } else {
-      check(after.computedColumns - before.computedColumns == 1280 && after.recolouredRows == before.recolouredRows,
-            "without device rows a changed brightness recomputes the screen");
+      const bool ok = after.computedColumns - before.computedColumns == 1280 && after.recolouredRows == before.recolouredRows;
+      if (!ok)
+        fprintf(stderr, "computed %llu -> %llu, recoloured %llu -> %llu\n", (unsigned long long)before.computedColumns,
+                (unsigned long long)after.computedColumns, (unsigned long long)before.recolouredRows,
+                (unsigned long long)after.recolouredRows);
+      check(ok, "without device rows a changed brightness recomputes the screen");
     }
     printf("recolour_screen: N=%d 1280 columns after %d draw passes, %.1f ms\n", N, frames, ms2);
     {  // one of them against the reference's UI-thread colormap of its magnitudes (fetched from the device row)
