@@ -656,7 +656,7 @@ MX_HD void load_t1_tw2(int t, cpx (&v)[P::E], const cpx *lds, const cpx *ltw2, c
     constexpr int r = decltype(rr)::value;
     q[P::E + r] = lds_rd64<(r - 1) * P::R1 * 8>(aw);
   });
-  q[P::E] = q[P::E + 1];  // pads the tie list to a multiple of 8
+  q[P::E] = mx_f2v{0.0f, 0.0f};  // pads the tie list to a multiple of 8 (a constant: never a copy of a read still in flight)
   lds_wait(q);
 #pragma unroll
   for (int i = 0; i < P::E; ++i) v[i] = mk(q[i].x, q[i].y);

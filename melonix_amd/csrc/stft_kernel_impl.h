@@ -51,11 +51,12 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 
 // One dword of a magnitude row: *(float *)((char *)base + off + IMM) = x, streaming (nt), with `base` wave-uniform
 // (an SGPR pair), `off` a 32-bit lane offset and IMM the instruction's 13-bit signed immediate.
-template <int IMM>
+template <int IMM, bool NT = true>
 __device__ __forceinline__ void st_row_nt(const float *base, unsigned off, float x) {
   static_assert(IMM >= -4096 && IMM <= 4095, "global_store immediate offset");
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(off), "v"(x), "s"(base), "n"(IMM) : "memory");
+  if constexpr (NT) asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(off), "v"(x), "s"(base), "n"(IMM) : "memory");
+  else asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(off), "v"(x), "s"(base), "n"(IMM) : "memory");
 #endif
 }
 

@@ -12,6 +12,8 @@
 
 #include "kernels.h"
 #include "stft_kernel_impl.h"
+#include "stft_kernel_ovl.h"
+#include <cstdlib>
 
 namespace mx {
 
@@ -51,11 +53,26 @@ struct Tune {
   static constexpr bool DEFER = TWO_WAVE;
 };
 
+// (round-4 A/B switch, removed once the measurement is in: MELONIX_STFT_OVL=0 launches the lock-step kernels)
+static bool use_ovl() {
+  static const bool v = [] {
+    const char *e = getenv("MELONIX_STFT_OVL");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
 // Launches the sliding-window kernel for HOP if the plan can slide by it (Slide<P,HOP>::ok) and the call asks for it.
 template <class P, int HOP>
 bool try_slide(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
   if constexpr (Slide<P, HOP>::ok && Tune<P>::slides(HOP)) {
     if (b.hop != HOP) return false;
+    if constexpr (P::E == 32) {
+      if (use_ovl()) {
+        hipLaunchKernelGGL((stft_kernel_ovl<P, HOP, Tune<P>::WPE>), grid, block, 0, s, b);
+        return true;
+      }
+    }
     hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, HOP, Tune<P>::WPE, Tune<P>::DEFER, false, false, Tune<P>::DIRECT>),
                        grid, block, 0, s, b);
     return true;
@@ -72,6 +89,10 @@ bool try_circ(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
     return false;
   } else {
     if (!Circ<P>::ok(b.hop)) return false;
+    if (use_ovl()) {
+      hipLaunchKernelGGL((stft_kernel_ovl<P, 0, Tune<P>::WPE>), grid, block, 0, s, b);
+      return true;
+    }
     hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, Tune<P>::WPE, Tune<P>::DEFER, false, false, Tune<P>::DIRECT, true>),
                        grid, block, 0, s, b);
     return true;

@@ -26,7 +26,7 @@
 #pragma once
 #include "stft_core.h"
 
-#if defined(__HIPCC__)
+#if defined(__HIP_DEVICE_COMPILE__)  // (the kernels that use these are device-pass only as well)
 namespace mx {
 
 // ---- scatter side ---------------------------------------------------------------------------------------------
@@ -83,8 +83,12 @@ __device__ __forceinline__ void final_stage_store(const cpx (&E)[R / 2], const c
 
 // every LDS operation of this wave has completed, then the workgroup barrier (the asm stores above are invisible to the
 // compiler's own wait insertion)
+// (fenced for the scheduler as well: register-only work written in front of the barrier — the stages that let the waves
+// drift apart before they meet — must not sink below it, nor the work behind it rise above)
 __device__ __forceinline__ void lds_drain_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---- gather side ----------------------------------------------------------------------------------------------
@@ -109,19 +113,21 @@ __device__ __forceinline__ void lds_drain_barrier() {
 #define MX_OVL_IN0
 #define MX_OVL_IN2 , [a0] "v"(a0), [a1] "v"(a1), [i0] "n"(I0), [i1] "n"(I1)
 #define MX_OVL_IN4 MX_OVL_IN2, [a2] "v"(a2), [a3] "v"(a3), [i2] "n"(I2), [i3] "n"(I3)
-#define MX_OVL_STEP(RDS, OUTS, INS, LEAF)                                                                 \
-  asm volatile("s_waitcnt lgkmcnt(%[cnt])\n\t" RDS LEAF                                                   \
-               : [o0] "=&v"(o0), [o1] "=&v"(o1) OUTS                                                      \
+#define MX_OVL_RD0
+// (the operand lists carry commas: they are selected by token pasting inside the statement, never passed as arguments)
+#define MX_OVL_STEP(NI_, LEAF)                                                                            \
+  asm volatile("s_waitcnt lgkmcnt(%[cnt])\n\t" MX_OVL_RD##NI_ LEAF                                        \
+               : [o0] "=&v"(o0), [o1] "=&v"(o1) MX_OVL_OUT##NI_                                           \
                : [v0] "v"(v0), [w0] "v"(w0), [v1] "v"(v1), [w1] "v"(w1), [two] "s"(mx_v2{2.0f, 2.0f}),    \
-                 [cnt] "n"(CNT) INS                                                                       \
+                 [cnt] "n"(CNT) MX_OVL_IN##NI_                                                            \
                : "memory")
-#define MX_OVL_STEP_NI(RDS, OUTS, INS)                                        \
-  if constexpr (HAS_W0) {                                                     \
-    if constexpr (CONJ) MX_OVL_STEP(RDS, OUTS, INS, MX_OVL_LEAF(MX_PK_YWC));  \
-    else MX_OVL_STEP(RDS, OUTS, INS, MX_OVL_LEAF(MX_PK_YW));                  \
-  } else {                                                                    \
-    if constexpr (CONJ) MX_OVL_STEP(RDS, OUTS, INS, MX_OVL_LEAF0(MX_PK_YWC)); \
-    else MX_OVL_STEP(RDS, OUTS, INS, MX_OVL_LEAF0(MX_PK_YW));                 \
+#define MX_OVL_STEP_NI(NI_)                                          \
+  if constexpr (HAS_W0) {                                            \
+    if constexpr (CONJ) MX_OVL_STEP(NI_, MX_OVL_LEAF(MX_PK_YWC));    \
+    else MX_OVL_STEP(NI_, MX_OVL_LEAF(MX_PK_YW));                    \
+  } else {                                                           \
+    if constexpr (CONJ) MX_OVL_STEP(NI_, MX_OVL_LEAF0(MX_PK_YWC));   \
+    else MX_OVL_STEP(NI_, MX_OVL_LEAF0(MX_PK_YW));                   \
   }
 template <bool CONJ, bool HAS_W0, int CNT, int NI, int I0 = 0, int I1 = 0, int I2 = 0, int I3 = 0>
 __device__ __forceinline__ void leaf_step(mx_v2 v0, mx_v2 w0, mx_v2 v1, mx_v2 w1, cpx &out0, cpx &out1, uint32_t a0,
@@ -131,11 +137,11 @@ __device__ __forceinline__ void leaf_step(mx_v2 v0, mx_v2 w0, mx_v2 v1, mx_v2 w1
   static_assert(I0 >= 0 && I0 < 65536 && I1 >= 0 && I1 < 65536 && I2 >= 0 && I2 < 65536 && I3 >= 0 && I3 < 65536, "ds offset field");
   mx_v2 o0, o1;
   if constexpr (NI == 0) {
-    MX_OVL_STEP_NI(, MX_OVL_OUT0, MX_OVL_IN0)
+    MX_OVL_STEP_NI(0)
   } else if constexpr (NI == 2) {
-    MX_OVL_STEP_NI(MX_OVL_RD2, MX_OVL_OUT2, MX_OVL_IN2)
+    MX_OVL_STEP_NI(2)
   } else {
-    MX_OVL_STEP_NI(MX_OVL_RD4, MX_OVL_OUT4, MX_OVL_IN4)
+    MX_OVL_STEP_NI(4)
   }
   out0 = pkc(o0);
   out1 = pkc(o1);
@@ -173,40 +179,53 @@ struct DftFromLeaves {
 #define MX_OVL_WIN(OFF) ((OFF) >> 16)
 #define MX_OVL_LOW(OFF) ((OFF) & 65535)
 
-// ---- T1 gather + pass-2 leaves, one pass-2 butterfly per thread (N = 32768: R2 = 32) ------------------------------
-// Thread t gathers points t + r*S (r = 0..R2-1) and its R2-1 twiddles tw2[(r-1)*R1 + (t & (R1-1))] (LDS table), three
-// leaves ahead (12 reads in flight), and leaves L[2*O0], L[2*O0+1] = leaf (O0, O0 + R2/2) of DftTw<R2, 1, 0, false>.
+// ---- T1 gather + pass-2 leaves ---------------------------------------------------------------------------------------
+// Thread t gathers, for each of its NB2 pass-2 butterflies j = t + T*b, the points j + r*S (r = 0..R2-1) and — once, they
+// are the same for every b because T is a multiple of R1 — its R2-1 twiddles tw2[(r-1)*R1 + (t & (R1-1))] (LDS table),
+// three leaves ahead (at most 12 reads in flight), and leaves L[b*R2 + 2*O0], [.. + 1] = leaf (O0, O0 + R2/2) of
+// DftTw<R2, 1, 0, false> on butterfly b.  N = 32768: R2 = 32, NB2 = 1; N = 16384: R2 = 16, NB2 = 2 (the second
+// butterfly's leaves take the twiddles the first one's steps left in their registers).
 template <class P>
 __device__ __forceinline__ void gather_t1_leaves(int t, const cpx *lds, const cpx *ltw2, cpx (&L)[P::E]) {
-  static_assert(P::NB2 == 1 && P::E == P::R2 && t1_padded<P>(), "one pass-2 butterfly per thread, padded T1 layout");
+  static_assert(P::NB2 * P::R2 == P::E && t1_padded<P>() && P::T % P::R1 == 0, "padded T1 layout, shared twiddles");
   using R = T1Read<P>;
-  constexpr int NL = P::R2 / 2, BITS = ilog2(NL), D = 3;
-  constexpr int DS = R::SP * 8, TS = P::R1 * 8;  // bytes between consecutive r: data, twiddles
-  static_assert((P::R2 - 1) * DS < 2 * 65536 && (P::R2 - 2) * TS < 65536, "two data windows, one twiddle window");
+  constexpr int NL = P::R2 / 2, BITS = ilog2(NL), D = 3, NT = P::NB2 * NL;
+  constexpr int DS = R::SP * 8, BS = R::TP * 8, TS = P::R1 * 8;  // bytes between consecutive r / b (data), r (twiddles)
+  static_assert((P::NB2 - 1) * BS + (P::R2 - 1) * DS < 2 * 65536 && (P::R2 - 2) * TS < 65536, "two data windows, one twiddle window");
   const uint32_t ad0 = lds_addr(lds + t1_index<P>(t)), ad1 = ad0 + 65536u;
   const uint32_t aw = lds_addr(ltw2 + (t & (P::R1 - 1)));
-  mx_v2 v0[NL], w0[NL], v1[NL], w1[NL];
-  // prologue: leaves 0 .. D-1 (leaf 0 = (0, R2/2) has no twiddle on its first operand)
+  mx_v2 v0[NT], v1[NT], w0[NL], w1[NL];
+  auto dbase = [&](int off) { return MX_OVL_WIN(off) ? ad1 : ad0; };
+  // prologue: leaves 0 .. D-1 of butterfly 0 (leaf 0 = (0, R2/2) has no twiddle on its first operand)
+  static_assert(D <= NL, "the prologue stays inside the first butterfly");
   static_for<0, D>([&](auto nn) {
     constexpr int n = decltype(nn)::value, i0 = bitrev<BITS>(n), i1 = i0 + NL;
-    v0[n] = lds_rd64<MX_OVL_LOW(i0 * DS)>(MX_OVL_WIN(i0 * DS) ? ad1 : ad0);
+    v0[n] = lds_rd64<MX_OVL_LOW(i0 * DS)>(dbase(i0 * DS));
     if constexpr (i0 != 0) w0[n] = lds_rd64<(i0 - 1) * TS>(aw);
-    v1[n] = lds_rd64<MX_OVL_LOW(i1 * DS)>(MX_OVL_WIN(i1 * DS) ? ad1 : ad0);
+    v1[n] = lds_rd64<MX_OVL_LOW(i1 * DS)>(dbase(i1 * DS));
     w1[n] = lds_rd64<(i1 - 1) * TS>(aw);
   });
-  static_for<0, NL>([&](auto nn) {
-    constexpr int n = decltype(nn)::value, i0 = bitrev<BITS>(n);
-    constexpr int last = (n + D - 1 < NL - 1) ? n + D - 1 : NL - 1;  // newest leaf already issued
-    constexpr int CNT = 4 * (last - n);
-    if constexpr (n + D < NL) {
-      constexpr int m = n + D, j0 = bitrev<BITS>(m), j1 = j0 + NL;
-      leaf_step<false, (i0 != 0), CNT, 4, MX_OVL_LOW(j0 * DS), (j0 - 1) * TS, MX_OVL_LOW(j1 * DS), (j1 - 1) * TS>(
-          v0[n], i0 != 0 ? w0[n] : v0[n], v1[n], w1[n], L[2 * i0], L[2 * i0 + 1], MX_OVL_WIN(j0 * DS) ? ad1 : ad0, aw,
-          MX_OVL_WIN(j1 * DS) ? ad1 : ad0, aw, v0[m], w0[m], v1[m], w1[m]);
+  static_for<0, NT>([&](auto mm) {
+    constexpr int m = decltype(mm)::value, b = m / NL, n = m % NL, i0 = bitrev<BITS>(n);
+    constexpr int last = (m + D - 1 < NT - 1) ? m + D - 1 : NT - 1;  // newest leaf already issued
+    // reads in flight behind this leaf's: 4 per leaf of butterfly 0, 2 per leaf of the others
+    constexpr int nb0 = (last < NL ? last : NL - 1) - (m < NL ? m : NL - 1);
+    constexpr int CNT = 4 * nb0 + 2 * ((last - m) - nb0);
+    const mx_v2 ww0 = i0 != 0 ? w0[n] : v0[m];
+    cpx &o0 = L[b * P::R2 + 2 * i0], &o1 = L[b * P::R2 + 2 * i0 + 1];
+    mx_v2 d0, d1, d2, d3;
+    if constexpr (m + D < NT) {
+      constexpr int x = m + D, xb = x / NL, xn = x % NL, j0 = bitrev<BITS>(xn), j1 = j0 + NL;
+      constexpr int F0 = xb * BS + j0 * DS, F1 = xb * BS + j1 * DS;
+      if constexpr (xb == 0) {
+        leaf_step<false, (i0 != 0), CNT, 4, MX_OVL_LOW(F0), (j0 - 1) * TS, MX_OVL_LOW(F1), (j1 - 1) * TS>(
+            v0[m], ww0, v1[m], w1[n], o0, o1, dbase(F0), aw, dbase(F1), aw, v0[x], w0[xn], v1[x], w1[xn]);
+      } else {
+        leaf_step<false, (i0 != 0), CNT, 2, MX_OVL_LOW(F0), MX_OVL_LOW(F1)>(v0[m], ww0, v1[m], w1[n], o0, o1, dbase(F0),
+                                                                             dbase(F1), 0u, 0u, v0[x], v1[x], d2, d3);
+      }
     } else {
-      mx_v2 d0, d1, d2, d3;
-      leaf_step<false, (i0 != 0), CNT, 0>(v0[n], i0 != 0 ? w0[n] : v0[n], v1[n], w1[n], L[2 * i0], L[2 * i0 + 1], 0u, 0u, 0u,
-                                          0u, d0, d1, d2, d3);
+      leaf_step<false, (i0 != 0), CNT, 0>(v0[m], ww0, v1[m], w1[n], o0, o1, 0u, 0u, 0u, 0u, d0, d1, d2, d3);
     }
   });
 }
@@ -233,9 +252,16 @@ __device__ __forceinline__ void gather_t2_leaves(int t, const cpx *lds, const cp
     constexpr int n = decltype(nn)::value, c = n / NL, i0 = bitrev<BITS>(n % NL), i1 = i0 + NL;
     constexpr int last = (n + D - 1 < NT - 1) ? n + D - 1 : NT - 1;
     constexpr int CNT = 2 * (last - n);
-    const cpx(&w)[R] = c ? wq : wp;
-    cpx(&L)[R] = c ? LQ : LP;
-    const mx_v2 ww0 = i0 != 0 ? pkv(w[i0]) : v0[n], ww1 = pkv(w[i1]);
+    cpx wa, wb_;
+    if constexpr (c == 1) {
+      wa = wq[i0];
+      wb_ = wq[i1];
+    } else {
+      wa = wp[i0];
+      wb_ = wp[i1];
+    }
+    cpx *const L = c == 1 ? LQ : LP;  // (c is a constant expression: folded)
+    const mx_v2 ww0 = i0 != 0 ? pkv(wa) : v0[n], ww1 = pkv(wb_);
     mx_v2 d2, d3;
     if constexpr (n + D < NT) {
       constexpr int m = n + D, cm = m / NL, j0 = bitrev<BITS>(m % NL), j1 = j0 + NL;
@@ -269,4 +295,4 @@ __device__ __forceinline__ void tw3_from_bases(int t, const cpx (&wb)[6], cpx (&
 }
 
 }  // namespace mx
-#endif  // __HIPCC__
+#endif  // __HIP_DEVICE_COMPILE__

@@ -2,5 +2,7 @@ set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r04
 O=gpurun_out/r04
-MX_RCCL_LOG=$O/rccl_r04.log MX_PARITY_LOG=$O/parity_r04_whole_config_vs_oracle.log timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
-tail -15 $O/pytest_gpu.log
+export MELONIX_STFT_OVL=0
+L=$O/ab_mirror_stores.log
+bash tools/pmc_variant.sh "32768x375 16384x512" shipped melonix_amd/lib/variants/mirror_plain.so melonix_amd/lib/variants/all_plain.so 2>&1 | tee -a $L
+tail -3 gpurun_out/pmc_var/shipped_WRITE_SIZE.log
