@@ -38,7 +38,7 @@ UNITS = [
     # pure host logic: plain g++, no contraction, no -march (SURVEY §7 "Bit-exact schedule")
     ("host_logic.cpp", "cxx", ["-ffp-contract=off"]),
 ]
-HEADERS = ["kernels.h", "colormap_core.h", "stft_kernel_impl.h", "stft_kernel_ovl.h", "stft_overlap.h", "stft_core.h", "pk_math.h", "stft_tables.h", "stft_consts.inc",
+HEADERS = ["kernels.h", "colormap_core.h", "stft_kernel_impl.h", "stft_core.h", "pk_math.h", "stft_tables.h", "stft_consts.inc",
            "host_logic.h",
            os.path.join("..", "..", "include", "melonix_amd.h")]
 

@@ -49,8 +49,8 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
   return ((unsigned long long)mhi << 32) | mlo;
 }
 
-// One dword of a magnitude row: *(float *)((char *)base + off + IMM) = x, streaming (nt), with `base` wave-uniform
-// (an SGPR pair), `off` a 32-bit lane offset and IMM the instruction's 13-bit signed immediate.
+// One dword of a magnitude row: *(float *)((char *)base + off + IMM) = x, streaming (NT: nt) or plain write-back, with
+// `base` wave-uniform (an SGPR pair), `off` a 32-bit lane offset and IMM the instruction's 13-bit signed immediate.
 template <int IMM, bool NT = true>
 __device__ __forceinline__ void st_row_nt(const float *base, unsigned off, float x) {
   static_assert(IMM >= -4096 && IMM <= 4095, "global_store immediate offset");
@@ -387,7 +387,7 @@ void stft_kernel(const StftArgs a0) {
             o1 = (t == 0) ? (unsigned)(4 * (C::M / 2)) + (unsigned)((sl - sd) * STEP) : o1;
           }
           st_row_nt<(sl - su) * STEP>(row, o0, mg[2 * s]);
-          st_row_nt<-(sl - sd) * STEP>(row, o1, mg[2 * s + 1]);
+          st_row_nt<-(sl - sd) * STEP, false>(row, o1, mg[2 * s + 1]);  // mirrored half: write-back, L2 merges the partial blocks
         });
       }
     } else if (want_rows) {

@@ -12,8 +12,6 @@
 
 #include "kernels.h"
 #include "stft_kernel_impl.h"
-#include "stft_kernel_ovl.h"
-#include <cstdlib>
 
 namespace mx {
 
@@ -45,6 +43,12 @@ struct Tune {
   // shader cycles (8.3 against 9.1 M at hop 512), of which the power manager gives 2 % back as time (4.10 against 4.19 ms;
   // hop 1024: 2.12 / 2.17; 375: the same) — round 2, with one offset addition per store, measured no difference.
   // (The two-wave N = 4096 plan's row leaves in the shadow of the next frame.)
+  // Round 4: the mirrored half of such a row (bins M - k: one float off the 256-byte blocks a wavefront stores, so every
+  // block is finished by a second wavefront's lane) leaves through plain write-back stores so that L2 merges the two pieces,
+  // the direct half stays non-temporal: HBM writes 1.124x -> 1.035x of the row bytes at N = 16384 / 512, 1.060x -> 1.023x at
+  // 32768 / 375, same time (profiles/variants_r04_mirror_stores.log; both halves plain: 1.00x but 1 % slower).
+  // Also round 4, measured and withdrawn (commit 6d1bde4 has the code, profiles/variants_r04_overlap.log the measurement): the transpositions woven
+  // into the neighbouring passes inside each wave — 1.6-3.6 % slower at N = 32768; a wave's own DS issue blocks it.
   static constexpr bool DIRECT = (P::N >= 16384);
   // The circular window (stft_core.h) for N = 16384 / 32768, hops up to 512 samples that do not slide by whole slots.
   // The two-wave N = 4096 plan loses with it (1.87 against 1.70 ms) and keeps its direct loads.
@@ -53,26 +57,11 @@ struct Tune {
   static constexpr bool DEFER = TWO_WAVE;
 };
 
-// (round-4 A/B switch, removed once the measurement is in: MELONIX_STFT_OVL=0 launches the lock-step kernels)
-static bool use_ovl() {
-  static const bool v = [] {
-    const char *e = getenv("MELONIX_STFT_OVL");
-    return !(e && e[0] == '0');
-  }();
-  return v;
-}
-
 // Launches the sliding-window kernel for HOP if the plan can slide by it (Slide<P,HOP>::ok) and the call asks for it.
 template <class P, int HOP>
 bool try_slide(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
   if constexpr (Slide<P, HOP>::ok && Tune<P>::slides(HOP)) {
     if (b.hop != HOP) return false;
-    if constexpr (P::E == 32) {
-      if (use_ovl()) {
-        hipLaunchKernelGGL((stft_kernel_ovl<P, HOP, Tune<P>::WPE>), grid, block, 0, s, b);
-        return true;
-      }
-    }
     hipLaunchKernelGGL((stft_kernel<P, kBulkAligned, HOP, Tune<P>::WPE, Tune<P>::DEFER, false, false, Tune<P>::DIRECT>),
                        grid, block, 0, s, b);
     return true;
@@ -89,10 +78,6 @@ bool try_circ(const StftArgs &b, dim3 grid, dim3 block, hipStream_t s) {
     return false;
   } else {
     if (!Circ<P>::ok(b.hop)) return false;
-    if (use_ovl()) {
-      hipLaunchKernelGGL((stft_kernel_ovl<P, 0, Tune<P>::WPE>), grid, block, 0, s, b);
-      return true;
-    }
     hipLaunchKernelGGL((stft_kernel<P, kBulkAny, 0, Tune<P>::WPE, Tune<P>::DEFER, false, false, Tune<P>::DIRECT, true>),
                        grid, block, 0, s, b);
     return true;

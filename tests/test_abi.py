@@ -107,3 +107,22 @@ def test_pv_kernels_do_not_spill():
     assert len(names) == len(scratch) == len(vgprs) and len(names) >= 7
     assert not [(n, s) for n, s in zip(names, scratch) if s != 0]
     assert max(vgprs) <= 256
+
+
+@pytest.mark.parametrize("unit", ["stft_kernels.hip", "pv_kernels.hip"])
+def test_hand_issued_lds_reads_are_covered_by_their_waits(unit, tmp_path):
+    """The transposition reads are inline-asm ds_read_b64 behind a hand-placed s_waitcnt (stft_core.h lds_rd64 / lds_wait):
+    hipcc neither counts them nor knows their destinations are invalid until that wait.  tools/lds_audit.py walks the
+    ISA of every instantiation with the hardware's LGKM queue: no instruction may touch a destination register between its
+    read and the wait that covers it (round 4 found — and removed — a v_mov that copied one into an unused pad register),
+    no scalar memory operation may be in flight at a counted wait."""
+    import sys
+    src = os.path.join(ROOT, "melonix_amd", "csrc", unit)
+    asm = tmp_path / (unit + ".s")
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-ffp-contract=off", "-x", "hip",
+                          "--cuda-device-only", "-S", src, "-o", str(asm)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    aud = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lds_audit.py"), str(asm)], capture_output=True, text=True)
+    assert aud.returncode == 0, aud.stdout[-3000:]
+    m = re.fullmatch(r"(\d+) kernel\(s\) audited, 0 finding\(s\)", aud.stdout.splitlines()[-1])
+    assert m and int(m.group(1)) >= 7, aud.stdout[-500:]
