@@ -774,13 +774,15 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   p.s_len = (Fl - first) * Hs + N;
   p.s_origin = F_lo * Hs;
   const int64_t nchunks = (Fl - first + p.scan_chunk - 1) / p.scan_chunk;
-  // one arena: apos, the two windows, mags, phase, phi, chunk sums, boundary halos, s (+1 for s[m+1]), split
-  // twiddles, source bins of the chunk maps, peak maps, this rank's total map, carry-in, the neighbours' seams
+  // one arena: apos, the two windows, the complex spectra, the peak records, the peaks' synthesis offsets, chunk sums,
+  // boundary halos, s (+1 for s[m+1]), split twiddles, source bins of the chunk maps, peak maps and counts, this rank's
+  // total map, carry-in, the neighbours' seams.  (Records and offsets have room for a peak in every bin — silence, an
+  // impulse — but only a frame's first pkcount entries are ever touched.)
   const size_t rowsz = (size_t)Fl * M;
   size_t off = 0;
   auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_apos = take((size_t)Fl * 8), o_h = take(N * 4), o_hs = take(N * 4), o_m = take(rowsz * 4),
-               o_p = take(rowsz * 4), o_i = take(rowsz * 4), o_c = take((size_t)nchunks * M * 4),
+  const size_t o_apos = take((size_t)Fl * 8), o_h = take(N * 4), o_hs = take(N * 4), o_m = take(rowsz * 8),
+               o_p = take(rowsz * 8), o_i = take(rowsz * 4), o_pc = take((size_t)Fl * 4), o_c = take((size_t)nchunks * M * 4),
                o_f = take((size_t)pv_halo_floats(Fl - first) * 4), o_s = take(((size_t)p.s_len + 1) * 4),
                o_w = take((size_t)M * 8), o_a = take((size_t)nchunks * M * 2), o_ow = take((size_t)Fl * (M / 32) * 4),
                o_ts = take((size_t)M * 4), o_ta = take((size_t)M * 2), o_ci = take((size_t)M * 4),
@@ -825,9 +827,10 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   p.hratio = reinterpret_cast<const double *>(arena + o_hr);
   p.hann = reinterpret_cast<const float *>(arena + o_h);
   p.hann_scaled = reinterpret_cast<const float *>(arena + o_hs);
-  p.mags = reinterpret_cast<float *>(arena + o_m);
-  p.phase = reinterpret_cast<uint32_t *>(arena + o_p);
-  p.phi = reinterpret_cast<uint32_t *>(arena + o_i);
+  p.xrows = reinterpret_cast<float2 *>(arena + o_m);
+  p.recs = reinterpret_cast<uint2 *>(arena + o_p);
+  p.cvals = reinterpret_cast<uint32_t *>(arena + o_i);
+  p.pkcount = reinterpret_cast<uint32_t *>(arena + o_pc);
   p.chunk_sums = reinterpret_cast<uint32_t *>(arena + o_c);
   p.halo = reinterpret_cast<float *>(arena + o_f);
   p.wsplit = reinterpret_cast<const float2 *>(arena + o_w);
@@ -1014,19 +1017,6 @@ int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int ra
   ctx->pv_job_active = true;
   return MX_OK;
 }
-
-#ifdef MX_PV_DEBUG
-// (debug builds only) one row of the staged job's intermediates: 0 mags, 1 phase words, 2 owners, 3 phi
-int mx_debug_pv_row(mx_ctx *ctx, int kind, int64_t row, void *out) {
-  if (!ctx || !ctx->pv_job_active || !out) return fail(MX_ERR_INVALID, "no staged job");
-  const PvArgs &p = ctx->pv_job;
-  if (row < 0 || row >= p.frames) return fail(MX_ERR_INVALID, "row out of range");
-  const void *src = kind == 0 ? (const void *)(p.mags + row * kPvM) : kind == 1 ? (const void *)(p.phase + row * kPvM)
-                   : kind == 2 ? (const void *)(p.pkmap + row * (kPvM / 32)) : (const void *)(p.phi + row * kPvM);
-  hipStreamSynchronize(ctx->stream);
-  return hipMemcpy(out, src, (size_t)kPvM * (kind == 2 ? 2 : 4), hipMemcpyDeviceToHost) == hipSuccess ? MX_OK : MX_ERR_DEVICE;
-}
-#endif
 
 int mx_pv_shard_synthesize(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out) {
   if (!ctx || !head_out || !tail_out) return fail(MX_ERR_INVALID, "bad argument");

@@ -66,12 +66,21 @@ struct PvArgs {
   const float *hann;         // periodic Hann (synthesis window)
   const float2 *wsplit;      // e^{+2 pi i c/N}, c = 0..N/2-1 (pre-split of the inverse transform)
   const float2 *tw2, *tw3, *ubase;  // Plan<4096,16> tables
-  float *mags;        // [frames][N/2]
-  uint32_t *phase;    // [frames][N/2] analysis phases: turns * 2^32 (even) | activity flag in bit 0
-  uint32_t *phi;      // [frames][N/2] synthesis phases (output of the scan)
-  uint32_t *pkmap;    // [frames][N/64] bit k: bin k is a spectral peak of the frame
+  // Per frame (row) the analysis leaves: the one-sided spectrum X/N, complex (what synthesis rotates), the frame's spectral
+  // peaks as a 2048-bit map, and one 8-byte record per peak, in bin order — everything the phase recurrence needs of the
+  // frame (the recurrence runs over peaks only; every other bin rides on its owner peak's phasor):
+  //   rec.x = p | q << 11 | qvalid << 22 | cont << 23   p: the peak's bin; q: the peak of the PREVIOUS frame that owns bin p
+  //                                                     (nearest within reach); cont: p carried signal in both frames and h >= 1
+  //   rec.y = delta = P_{f-1}[p] + inc_f[p] - P_f[p]    (uint32 turns; inc: pv_inc)
+  // so that the peak's synthesis offset is  C_f[p] = E_{f-1}[p] + delta  (cont) with E_{f-1}[p] = C_{f-1}[q] where q
+  // continued itself, else 0; a peak that does not continue restarts (offset 0: its bins keep their analysis phases).
+  float2 *xrows;       // [frames][N/2]
+  uint32_t *pkmap;     // [frames][N/64] bit k: bin k is a spectral peak of the frame
+  uint32_t *pkcount;   // [frames] number of peaks (= records) of the frame
+  uint2 *recs;         // [frames][N/2] the frame's records (only the first pkcount are written or read)
+  uint32_t *cvals;     // [frames][N/2] out of the second sweep: C_f of the frame's peaks in record order (0 = restarted)
   uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2] a chunk's composed map: delta (or restart value) ...
-  uint16_t *chunk_org;   // ... and source bin at the chunk's start (0xFFFF: restart); then the chunk-start phases
+  uint16_t *chunk_org;   // ... and source bin at the chunk's start (0xFFFF: restart); then the chunk-start offsets
   int scan_chunk;
   float *halo;        // pv_halo_floats(frames): partial sums right of each synthesis-workgroup boundary
   float *s;           // stretched signal, s_len = frames*Hs + N, index 0 = stretched time -N/2

@@ -6,30 +6,41 @@
 // (oracle/pv_oracle.py, whose header is the definition: N = 4096, Hs = 256, stretch by r then resample
 // by r).  PARITY UNPINNED — there is no reference arithmetic to match.
 //
-// Stages (all frame-parallel; the phase recurrence is an integer prefix sum over frames, so the parallel
-// scan gives exactly the serial result):
-//   pv_analysis   one workgroup walks consecutive frames: Hann-windowed frame at a_f -> the LDS-resident
-//                 real FFT of stft_core.h -> |X|/N and arg X as uint32 turns whose low bit is the
-//                 activity flag (|X| >= 1e-3 of the frame's peak), rows [F][N/2]; the frame's spectral peaks as
-//                 a 2048-bit map, [F][N/64]
-//   pv_lock_*     identity phase locking: a peak continues from what its bin held in the previous frame plus its
-//                 measured advance (integer arithmetic), every other bin takes its owner peak's synthesis phase plus
-//                 the analysis phase difference; a bin whose peak carried no signal in the previous frame restarts
-//                 from its analysis phase.  A frame is therefore a map bin -> (source bin, delta) | restart, maps
-//                 compose associatively, and the frame axis is scanned in chunks: composed chunk maps, a serial
-//                 pass over them, then the rows of Phi (uint32 wrap = mod 1 turn).  The maps are recomputed in
-//                 both sweeps from the phase rows and the peak maps, never stored
-//   pv_synthesis  a workgroup walks >= 32 consecutive frames: |X| e^{i Phi} -> inverse real FFT (the same
-//                 three passes run on the conjugated, pre-split spectrum) -> Hann window -> overlap-add in
-//                 an LDS ring of N samples; after each frame the oldest hop is complete and leaves as one
-//                 1 KiB store, normalised by sum w^2 = 3N/(8 Hs).  Only the N - Hs samples either side of
-//                 a workgroup boundary see two workgroups: the left one leaves its partial sums in s, the
-//                 right one in a halo buffer
+// Round 4: the phasor form of identity phase locking.  With every bin riding on its owner peak p,
+//   Phi_f[k] = Phi_{f-1}[p] + inc_f[p] + (P_f[k] - P_f[p])   =>   |X_f[k]| e^{i Phi_f[k]} = X_f[k] * e^{i C_f[p]},
+//   C_f[p] = Phi_{f-1}[p] + inc_f[p] - P_f[p]
+// — the synthesis coefficient of a bin is its ANALYSIS coefficient rotated by its peak's offset.  So nothing but the
+// peaks ever needs a phase: the analysis leaves the complex spectra and one 8-byte record per peak, the recurrence runs
+// over the records alone, and synthesis rotates.  Against rounds 1-3 (magnitude rows, arg rows for every bin, a
+// synthesis-phase row for every bin, two sweeps that each read whole rows): no atan2 outside the peaks, no Phi rows, no
+// row traffic in the sweeps — 40 GB of intermediates per hour of audio become 27, of which the sweeps touch a few MB.
+// The peaks' bookkeeping is the same integer arithmetic on the same values as before (uint32 turns, composable maps).
+//
+// Stages:
+//   pv_analysis   one workgroup walks consecutive frames: Hann-windowed frame at a_f -> the LDS-resident real FFT of
+//                 stft_core.h -> X/N, rows [F][N/2] complex; the frame's peaks (active, not below rho times any of its
+//                 four neighbours) as a 2048-bit map and, compacted in bin order, one record per peak:
+//                 (bin p, owner q of bin p in the PREVIOUS frame's peak map, continues?, delta) with
+//                 delta = P_{f-1}[p] + inc_f[p] - P_f[p] — the previous frame's spectrum stays in LDS for that (the two
+//                 FFT images take turns), a workgroup's first frame is preceded by a warm-up transform of the frame before
+//   pv_lock_walk  the recurrence over the records of a chunk of the frame axis, one barrier per row, rows a few dozen
+//                 records long:   C_f[p] = E_{f-1}[p] + delta  (continues)  |  restart,
+//                 E_{f-1}[p] = C_{f-1}[q] where q (valid) continued itself, else 0.  A frame is therefore a map
+//                 bin -> (source bin, delta) | restart, maps compose associatively, and the frame axis is scanned in
+//                 chunks: composed chunk maps (dense again at the chunk's end: every bin's owner in the last row), a
+//                 serial pass over them (pv_lock_chunks), then the same walk with the chunk-start offsets writes the
+//                 peaks' C values, in record order
+//   pv_synthesis  a workgroup walks >= 32 consecutive frames: the frame's peaks claim their bins (interval fill of an
+//                 owner-index array in the free FFT image), every bin's coefficient is X_f[k] e^{2 pi i C/2^32} ->
+//                 inverse real FFT (the same three passes on the conjugated, pre-split spectrum) -> Hann window ->
+//                 overlap-add in an LDS ring of N samples; after each frame the oldest hop is complete and leaves as one
+//                 1 KiB store, normalised by sum w^2 = 3N/(8 Hs).  Only the N - Hs samples either side of a workgroup
+//                 boundary see two workgroups: the left one leaves its partial sums in s, the right one in a halo buffer
 //   pv_fixup      adds the halo to s across each boundary (in frame order: deterministic, no atomics)
 //   pv_resample   linear interpolation at i*r -> f32 / int16 PCM (pv_resample_frames: the marker-driven variant,
 //                 where each frame carries its own warped time and ratio and owns a range of output samples)
 // One rank of a multi-GPU run executes the same kernels on its range of frames in three stages
-// (launch_pv_analyze / _synthesize / _finish): the phase carry into the rank and the two overlap-add seams come
+// (launch_pv_analyze / _synthesize / _finish): the offset carry into the rank and the two overlap-add seams come
 // from its neighbours between the stages (capi.cpp mx_pv_shard_*, melonix_amd/shard.py).
 #include <hip/hip_runtime.h>
 
@@ -42,17 +53,18 @@ namespace {
 
 using PV = Plan<4096, 16>;
 constexpr int kPvN = 4096, kPvM = kPvN / 2, kPvHs = 256;
-constexpr float kPvActiveRel = 1e-3f;  // a bin is active within 60 dB of its frame's peak
-constexpr int kPvReach = 32;            // a peak owns bins at most this far away
-constexpr float kPvPeakMargin = 0.9990234375f;  // 1 - 2^-10: near-ties are peaks on both sides, not left to rounding
-constexpr uint16_t kPvNoBin = 0xFFFF;   // owner / origin: none
+constexpr float kPvActiveRel2 = 1e-6f;  // a bin is active within 60 dB of its frame's peak (squared magnitudes)
+constexpr int kPvReach = 32;             // a peak owns bins at most this far away
+// (1 - 2^-10)^2: near-ties are peaks on both sides, not left to rounding (compared on squared magnitudes)
+constexpr float kPvPeakMargin2 = 0.9990234375f * 0.9990234375f;
+constexpr uint16_t kPvNoBin = 0xFFFF;    // owner / origin: none
+constexpr uint32_t kRecQValid = 1u << 22, kRecCont = 1u << 23;
 static_assert(kPlan4096E == 16, "pv kernels use the 16-points-per-thread tables of N = 4096");
+static_assert(t1_size<PV>() == kPvM, "the FFT image of this plan is exactly one spectrum (XOR layout, no padding)");
 
-// arg(re + i im) in turns as an even uint32 (2^-31 turn steps; the float carries 24 bits of it, and the low bit of
-// the word is free for the bin's activity flag); arg(0, 0) = 0.  atan(q)/2pi on q = min/max in [0, 1] is an odd
-// polynomial (degree 17, |error| < 2e-8 turn incl. f32 rounding — the resolution of the float itself at 1/8 turn),
-// then the octant is undone; no division, no 64-bit conversion (the libm atan2f + llrintf this replaces was half
-// of the kernel's instructions).
+// arg(re + i im) in turns as an even uint32 (2^-31 turn steps; the float carries 24 bits of it); arg(0, 0) = 0.
+// atan(q)/2pi on q = min/max in [0, 1] is an odd polynomial (degree 17, |error| < 2e-8 turn incl. f32 rounding — the
+// resolution of the float itself at 1/8 turn), then the octant is undone; no division, no 64-bit conversion.
 __device__ __forceinline__ uint32_t to_turns(float re, float im) {
   const float ax = __builtin_fabsf(re), ay = __builtin_fabsf(im);
   const float hi = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 1e-30f), lo = __builtin_fminf(ax, ay);
@@ -74,26 +86,63 @@ __device__ __forceinline__ uint32_t to_turns(float re, float im) {
   return (uint32_t)(int32_t)__builtin_rintf(r * 2147483648.0f) << 1;  // |r * 2^31| <= 2^30
 }
 
-__global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
+// inc_f[k] = (k*Hs mod N) * 2^32/N + trunc(double(d) * (Hs/h)),  d = int32(P_f[k] - P_{f-1}[k] - (k*h mod N) * 2^32/N)
+// (one binary64 product of a binary64 quotient: the same two roundings on every IEEE machine; uint32 wrap = mod 1 turn).
+__device__ __forceinline__ uint32_t pv_inc(int k, uint32_t h, double hratio, uint32_t p, uint32_t prev_p) {
+  constexpr uint32_t unit = (uint32_t)(4294967296ull / kPvN);
+  const uint32_t expect = (((uint32_t)k * h) & (uint32_t)(kPvN - 1)) * unit;
+  const int32_t d = (int32_t)(p - prev_p - expect);
+  const int64_t q = (int64_t)((double)d * hratio);  // truncates toward zero
+  return (((uint32_t)k * (uint32_t)kPvHs) & (uint32_t)(kPvN - 1)) * unit + (uint32_t)q;
+}
+
+// Owner of bin k in a peak map: the nearest peak at most kPvReach bins away, the lower one on a tie.  `pk` points at the
+// map's word 0 inside an array that carries one zero word either side (pk[-1], pk[M/32]).
+__device__ __forceinline__ int pv_owner(const uint32_t *pk, int k) {
+  const int wi = k >> 5, bit = k & 31;
+  const uint32_t w0 = pk[wi - 1], w1 = pk[wi], w2 = pk[wi + 1];
+  const uint64_t below = ((uint64_t)w1 << 32) | w0, above = ((uint64_t)w2 << 32) | w1;
+  const uint64_t lm_ = below & (~0ull >> (31 - bit));  // peaks at or below k (bit 32 + `bit` is k itself)
+  const uint64_t rm_ = above & (~0ull << bit);         // peaks at or above k
+  const int dl = lm_ ? (32 + bit) - (63 - __builtin_clzll(lm_)) : 1 << 20;
+  const int dr = rm_ ? __builtin_ctzll(rm_) - bit : 1 << 20;
+  const int dmin = dl <= dr ? dl : dr;
+  return dmin <= kPvReach ? (dl <= dr ? k - dl : k + dr) : (int)kPvNoBin;
+}
+
+__global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(3, 3))) void pv_analysis(const PvArgs a) {
   using P = PV;
-  // the M-point image + the pass-2 twiddle table (2 KiB, shared by both waves); this thread's pass-3 twiddles stay
-  // in registers for the whole walk: no twiddle loads per frame (stft_kernel's arrangement for the N = 4096 plan)
+  // the M-point image (after the transform it holds X_f in bin order, for the peak search and the records); the pass-2
+  // twiddle table (2 KiB, shared by both waves); this thread's pass-3 twiddles stay in registers for the whole walk
+  // (stft_kernel's arrangement).  The previous frame's spectrum, which the records need at this frame's peaks only, is
+  // read back from its row in HBM/L2 — this workgroup wrote it one iteration ago (a second image for it would cost the
+  // third wave per SIMD: 39 KiB of LDS per workgroup against 23).
   constexpr int kTw2 = ((P::TW2 + 1) / 2) * 2;
-  __shared__ __attribute__((aligned(16))) float2 lds[t1_size<P>() + kTw2];  // (image incl. the T1 padding, stft_core.h)
-  __shared__ float red[2];
-  __shared__ uint32_t pkbits[P::M / 32];
-  float2 *const ltw2 = lds + t1_size<P>();
+  constexpr int W = P::M / 32;  // words of a peak map
+  __shared__ __attribute__((aligned(16))) float2 lds[P::M];
+  __shared__ __attribute__((aligned(16))) float2 ltw2[kTw2];
+  __shared__ uint32_t pkb[2][W + 2];  // the frame's peak map and the previous frame's, a zero word either side
+  __shared__ uint16_t plist[P::M];    // the frame's peak bins, ascending
+  __shared__ float red[2][2];         // per wavefront: the largest squared magnitude (alternating frames)
+  __shared__ uint32_t npk;
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;
-  cpx u[P::R3];
-  post_twiddles<P>(t_, a.ubase, u);
-  cpx w3r[P::R3 - 1];
-  fetch_tw3<P>(t_, a.tw3, w3r);
+  // (the eight post-split twiddles are rebuilt from their base every frame — a rotation by a constant each, stft_core.h
+  // PostFly —: held for the whole walk they are the registers between two and three waves per SIMD)
+  cpx ulo0, uhi0;
+  post_bases<P>(t_, a.ubase, ulo0, uhi0);
+  // ... and of the seven pass-3 twiddles gamma^r three stay (r = 1, 2, 4), the other four are one packed product each per frame
+  cpx w3b[3];
+  {
+    const int col = t_ ? t_ : P::NS3 / 2;
+    w3b[0] = a.tw3[0 * P::NS3 + col];
+    w3b[1] = a.tw3[1 * P::NS3 + col];
+    w3b[2] = a.tw3[3 * P::NS3 + col];
+  }
   for (int i = t_; i < P::TW2; i += P::T) ltw2[i] = a.tw2[i];
-  __syncthreads();
-  // XCD-aware block -> frame-range map, as in stft_kernel: the dispatcher places block b on XCD b % 8 and each XCD has
-  // its own L2, so every XCD takes one contiguous eighth of the frame range — the 95 % overlap between neighbouring
-  // blocks' samples is then an L2 hit (with blocks dealt round-robin the kernel fetched 11.2 GB for 0.69 GB of audio)
+  for (int i = t_; i < 2 * (W + 2); i += P::T) (&pkb[0][0])[i] = 0u;
+  // XCD-aware block -> frame-range map, as in stft_kernel: every XCD takes one contiguous eighth of the frame range — the
+  // 95 % overlap between neighbouring blocks' samples is then an L2 hit
   unsigned lb = blockIdx.x;
   {
     const unsigned nb = gridDim.x, xcd = lb & 7u, q = nb >> 3, rr = nb & 7u;
@@ -101,22 +150,26 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   }
   const int64_t f0 = (int64_t)lb * a.frames_per_block;
   const int64_t f1 = f0 + a.frames_per_block < a.frames ? f0 + a.frames_per_block : a.frames;
-  // the samples of frame f + 1 are requested while frame f is in its last pass (their latency, left at the top of the
-  // loop, was a third of the kernel)
+  if (f0 >= f1) return;
+  // the walk starts one frame early: frame f0's records need X_{f0-1} (this workgroup writes that row as well — the very
+  // values its owner writes — so that what it reads back is its own), its peak map and its threshold
+  const int64_t fw = f0 > 0 ? f0 - 1 : 0;
   cpx xr[P::E];
-  if (f0 < f1) load_raw<P, false>(t_, xr, a.audio + MX_AUDIO_PAD + (a.apos[f0] - P::N / 2));
-  for (int64_t f = f0; f < f1; ++f) {
+  load_raw<P, false>(t_, xr, a.audio + MX_AUDIO_PAD + (a.apos[fw] - P::N / 2));
+  __syncthreads();
+  int cur = 0;
+  float thr2_prev = 0.f;
+  bool have_prev = false;
+  for (int64_t f = fw; f < f1; ++f) {
     // as in stft_kernel: re-materialise the thread index and a zero table offset per frame, or LICM hoists every
-    // frame-invariant table value and address out of the loop (256 VGPRs and spills instead of ~150)
+    // frame-invariant table value and address out of the loop
     int t = t_, zoff = 0;
     asm volatile("" : "+v"(t), "+s"(zoff));
+    const bool emit = f >= f0;  // (block-uniform)
     cpx Y[P::E], v[P::E];
-    // (the window weights are reloaded per frame — L2 hits issued behind the already-landed samples: kept in
-    // registers for the whole walk they cost the third wave per SIMD once the sample prefetch holds 32 registers)
     apply_window<P, 1, true>(t, Y, xr, a.hann_scaled + zoff);
     pass1<P>(Y, v);
-    __syncthreads();  // every wave is past the previous frame's load_t2, row reads and peak-map updates
-    if (f > f0 && t < P::M / 32) a.pkmap[(size_t)(f - 1) * (P::M / 32) + t] = pkbits[t];  // 256 B per frame
+    __syncthreads();  // every wave is past the previous frame's record loop (it read the image and both maps)
     store_t1<P>(t, v, lds);
     __syncthreads();
     cpx w2[P::R2 - 1];
@@ -126,218 +179,213 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     store_t2<P>(t, v, lds);
     __syncthreads();
     load_t2<P>(t, v, lds);
-    __syncthreads();  // every wave has its T2 read: the image is free for the two rows (below)
-    if (f + 1 < f1) load_raw<P, false>(t, xr, a.audio + MX_AUDIO_PAD + (a.apos[f + 1] - P::N / 2));
+    __syncthreads();  // every wave has its T2 read: the image is free for X_f
     cpx X[P::E];
-    if (wave0) {
-      pass3_reg<P, true>(t, v, w3r);
-      post_cplx<P, true>(t, v, u, X);
-    } else {
-      pass3_reg<P, false>(t, v, w3r);
-      post_cplx<P, false>(t, v, u, X);
+    {
+      cpx ulo = ulo0, uhi = uhi0, u[P::R3];
+      cpx g1 = w3b[0];
+      asm volatile("" : "+v"(ulo.x), "+v"(ulo.y), "+v"(uhi.x), "+v"(uhi.y), "+v"(g1.x), "+v"(g1.y));  // (not hoisted out of the walk)
+      cpx w3r[P::R3 - 1];
+      w3r[0] = g1;
+      w3r[1] = w3b[1];
+      w3r[3] = w3b[2];
+      w3r[2] = pk_cmul2(w3b[1], g1);
+      w3r[4] = pk_cmul2(w3b[2], g1);
+      w3r[5] = pk_cmul2(w3b[2], w3b[1]);
+      w3r[6] = pk_cmul2(w3b[2], w3r[2]);
+      if (wave0) {
+        pass3_reg<P, true>(t, v, w3r);
+        PostFly<P, 0>::run(ulo, uhi, u);
+        post_cplx<P, true>(t, v, u, X);
+      } else {
+        pass3_reg<P, false>(t, v, w3r);
+        PostFly<P, 0>::run(ulo, ulo, u);
+        post_cplx<P, false>(t, v, u, X);
+      }
     }
-    float m[P::E];
-    float mx = 0.f;
+    // X_f goes into the image in bin order (consecutive lanes hold consecutive bins) — for the peak search, the records
+    // and, behind the barrier, for its way to HBM as aligned 16-byte stores, 1 KiB per wavefront instruction; the frame's
+    // largest squared magnitude through the DPP crossbar and two LDS words
+    float mx2 = 0.f;
 #pragma unroll
     for (int o = 0; o < P::E; ++o) {
-      m[o] = fast_sqrt(cnorm2(X[o]));
-      mx = m[o] > mx ? m[o] : mx;
+      const float n2 = cnorm2(X[o]);
+      mx2 = n2 > mx2 ? n2 : mx2;
+      lds[out_bin<P>(t, o)] = X[o];
     }
-    // the frame's peak magnitude: wavefront maximum through the DPP crossbar (non-negative floats order like their bit
-    // patterns), the two wavefronts through LDS behind the same barrier as the rows
-    const uint32_t wmax = wave_reduce_u32<true>(__float_as_uint(mx));
-    if ((t & 63) == 0) red[t >> 6] = __uint_as_float(wmax);
-    // Both rows leave through the (now free) image: every lane scatters its 16 bins as dwords (consecutive lanes ->
-    // consecutive bins), then owns 4 consecutive bins of each row — 8 stores of 1 KiB per wavefront instruction
-    // instead of 32 dword stores.  Bit 0 of the phase word: the bin is active (within 60 dB of the frame's peak) — the
-    // phase sweeps then need this one word per bin and frame, not the magnitude; it is set on the way out.
-    float *lm = reinterpret_cast<float *>(lds);
-    uint32_t *lp = reinterpret_cast<uint32_t *>(lds) + P::M;
+    const uint32_t wmax = wave_reduce_u32<true>(__float_as_uint(mx2));  // non-negative floats order like their bit patterns
+    if ((t & 63) == 0) red[cur][t >> 6] = __uint_as_float(wmax);
+    if (t < W) pkb[cur][t + 1] = 0u;
+    __syncthreads();
+    // the samples of frame f + 1 are requested here: they travel under the peak search, the numbering and the records
+    // (requested before the last pass their 32 registers cost the third wave per SIMD)
+    if (f + 1 < f1) load_raw<P, false>(t, xr, a.audio + MX_AUDIO_PAD + (a.apos[f + 1] - P::N / 2));
+    {
+      using f32x4 = float __attribute__((ext_vector_type(4)));
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(lds) + t;
+      f32x4 *dst = reinterpret_cast<f32x4 *>(a.xrows + (size_t)f * P::M) + t;
 #pragma unroll
-    for (int o = 0; o < P::E; ++o) {
-      const int k = out_bin<P>(t, o);
-      lm[k] = m[o];
-      lp[k] = to_turns(X[o].x, X[o].y);
+      for (int i = 0; i < P::M / 2 / P::T; ++i) __builtin_nontemporal_store(src[P::T * i], &dst[P::T * i]);
     }
-    if (t < P::M / 32) pkbits[t] = 0u;  // (the previous frame's map left after this frame's first barrier)
-    __syncthreads();  // (red is rewritten only after the next frame's barriers)
-    const float thr = kPvActiveRel * (red[0] > red[1] ? red[0] : red[1]);
+    const float thr2 = kPvActiveRel2 * (red[cur][0] > red[cur][1] ? red[cur][0] : red[cur][1]);
+    // Peaks of the row: active and not below rho times any of its four neighbours (squared magnitudes; bins outside the
+    // row never stand in the way).  Thread t looks at bins 4j .. 4j+3, j = t + T i.
     using f32x4 = float __attribute__((ext_vector_type(4)));
-    using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
-    f32x4 qm[P::M / 4 / P::T];
-    u32x4 qp[P::M / 4 / P::T];
 #pragma unroll
     for (int i = 0; i < P::M / 4 / P::T; ++i) {
-      qm[i] = reinterpret_cast<const f32x4 *>(lm)[t + P::T * i];
-      qp[i] = reinterpret_cast<const u32x4 *>(lp)[t + P::T * i];
-      qp[i].x |= qm[i].x >= thr ? 1u : 0u;
-      qp[i].y |= qm[i].y >= thr ? 1u : 0u;
-      qp[i].z |= qm[i].z >= thr ? 1u : 0u;
-      qp[i].w |= qm[i].w >= thr ? 1u : 0u;
-    }
-    f32x4 *mrow = reinterpret_cast<f32x4 *>(a.mags + (size_t)f * P::M) + t;
-    u32x4 *prow = reinterpret_cast<u32x4 *>(a.phase + (size_t)f * P::M) + t;
-#pragma unroll
-    for (int i = 0; i < P::M / 4 / P::T; ++i) {
-      __builtin_nontemporal_store(qm[i], &mrow[P::T * i]);  // (streamed: the rows must not push the audio out of L2)
-      __builtin_nontemporal_store(qp[i], &prow[P::T * i]);
-    }
-    // Peaks of the row (active, not below rho times any of its four neighbours) as a 2048-bit map: what the phase
-    // sweeps need to know of the magnitudes (they find every bin's owner peak in it).
-#pragma unroll
-    for (int i = 0; i < P::M / 4 / P::T; ++i) {
-      const int j = t + P::T * i;  // bins 4j .. 4j+3
-      const float2 lo = j > 0 ? reinterpret_cast<const float2 *>(lm)[2 * j - 1] : make_float2(-1.f, -1.f);
-      const float2 hi = j < P::M / 4 - 1 ? reinterpret_cast<const float2 *>(lm)[2 * j + 2] : make_float2(-1.f, -1.f);
-      const float v[8] = {lo.x, lo.y, qm[i].x, qm[i].y, qm[i].z, qm[i].w, hi.x, hi.y};
-      const uint32_t w[4] = {qp[i].x, qp[i].y, qp[i].z, qp[i].w};
+      const int j = t + P::T * i;
+      const f32x4 *x4 = reinterpret_cast<const f32x4 *>(lds);  // two bins per 16 bytes
+      const f32x4 c0 = x4[2 * j], c1 = x4[2 * j + 1];
+      const f32x4 lo = j > 0 ? x4[2 * j - 1] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 hi = j < P::M / 4 - 1 ? x4[2 * j + 2] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const float neg = -1.f;
+      const float v8[8] = {j > 0 ? fma_(lo.x, lo.x, lo.y * lo.y) : neg, j > 0 ? fma_(lo.z, lo.z, lo.w * lo.w) : neg,
+                           fma_(c0.x, c0.x, c0.y * c0.y),               fma_(c0.z, c0.z, c0.w * c0.w),
+                           fma_(c1.x, c1.x, c1.y * c1.y),               fma_(c1.z, c1.z, c1.w * c1.w),
+                           j < P::M / 4 - 1 ? fma_(hi.x, hi.x, hi.y * hi.y) : neg,
+                           j < P::M / 4 - 1 ? fma_(hi.z, hi.z, hi.w * hi.w) : neg};
       uint32_t nib = 0;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const float c = v[b + 2];
-        const bool pk = (w[b] & 1u) && c >= kPvPeakMargin * v[b + 1] && c >= kPvPeakMargin * v[b] &&
-                        c >= kPvPeakMargin * v[b + 3] && c >= kPvPeakMargin * v[b + 4];
+        const float c = v8[b + 2];
+        const bool pk = c >= thr2 && c >= kPvPeakMargin2 * v8[b + 1] && c >= kPvPeakMargin2 * v8[b] &&
+                        c >= kPvPeakMargin2 * v8[b + 3] && c >= kPvPeakMargin2 * v8[b + 4];
         nib |= pk ? (1u << b) : 0u;
       }
-      if (nib) atomicOr(&pkbits[j >> 3], nib << (4 * (j & 7)));
+      if (nib) atomicOr(&pkb[cur][1 + (j >> 3)], nib << (4 * (j & 7)));
     }
+    __syncthreads();
+    // the first wavefront numbers the peaks (exclusive scan of the words' populations through the DPP crossbar) and lists
+    // their bins in ascending order; records are then one per thread, whatever the peaks' positions
+    if (wave0) {
+      const uint32_t w = pkb[cur][1 + t];  // W == 64: one word per lane
+      const int c = __builtin_popcount(w);
+      int inc = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(inc, d, 64);
+        inc += (t >= d) ? up : 0;
+      }
+      const int base = inc - c;
+      if (t == 63) npk = (uint32_t)inc;
+      uint32_t rest = w;
+      int r = base;
+      while (rest) {
+        const int b = __builtin_ctz(rest);
+        rest &= rest - 1;
+        plist[r++] = (uint16_t)(32 * t + b);
+      }
+    }
+    __syncthreads();
+    const int cnt = (int)npk;
+    if (emit) {
+      const uint32_t h = a.hop[f];
+      const double hr = a.hratio[f];
+      uint2 *rrow = a.recs + (size_t)f * P::M;
+      const float2 *xprev = a.xrows + (size_t)(f > 0 ? f - 1 : 0) * P::M;
+      for (int i = t; i < cnt; i += P::T) {
+        const int p = plist[i];
+        const float2 xc = lds[p], xq = have_prev ? xprev[p] : make_float2(0.f, 0.f);
+        const uint32_t pc_ = to_turns(xc.x, xc.y), pp_ = to_turns(xq.x, xq.y);
+        const bool cont = have_prev && h >= 1 && cnorm2(xq) >= thr2_prev;
+        const int q = pv_owner(&pkb[cur ^ 1][1], p);
+        const uint32_t delta = pp_ + pv_inc(p, h, hr, pc_, pp_) - pc_;
+        uint2 rec;
+        rec.x = (uint32_t)p | (q != (int)kPvNoBin ? ((uint32_t)q << 11) | kRecQValid : 0u) | (cont ? kRecCont : 0u);
+        rec.y = delta;
+        rrow[i] = rec;
+      }
+      if (t < W) a.pkmap[(size_t)f * W + t] = pkb[cur][1 + t];
+      if (t == 0) a.pkcount[f] = (uint32_t)cnt;
+    }
+    thr2_prev = thr2;
+    have_prev = true;
+    cur ^= 1;
   }
-  // the last frame's peak map (every other frame's leaves after the next frame's first barrier, below)
-  __syncthreads();
-  if (f0 < f1 && t_ < P::M / 32) a.pkmap[(size_t)(f1 - 1) * (P::M / 32) + t_] = pkbits[t_];
 }
 
-// Phase bookkeeping with identity phase locking (oracle/pv_oracle.py is the definition).  In frame f bin k with owner
-// peak p continues from what bin p held in frame f-1:
-//   Phi_f[k] = Phi_{f-1}[p] + inc_f[p] + (P_f[k] - P_f[p])      if p carried signal in both frames and h_f >= 1
-//   Phi_f[k] = P_f[k]                                            otherwise (restart)
-//   inc_f[p] = (p*Hs mod N) * 2^32/N + trunc(double(d) * (Hs/h)),  d = int32(P_f[p] - P_{f-1}[p] - (p*h mod N) * 2^32/N)
-// (one binary64 product of a binary64 quotient: the same two roundings on every IEEE machine; uint32 wrap = mod 1 turn).
-// So a frame is a map k -> (source bin, delta) | restart(value), and maps compose associatively: the frame axis is cut
-// into chunks, every chunk's composed map comes out of one sweep, the chunk-start phases out of a short serial pass over
-// the chunk maps, and a second sweep writes the rows.  Bins exchange values across the whole row, so a workgroup walks
-// whole rows: three analysis-phase rows rotate through LDS (previous, current, the one being filled) next to the
-// double-buffered state, one barrier per row.
-__device__ __forceinline__ uint32_t pv_inc(int k, uint32_t h, double hratio, uint32_t p, uint32_t prev_p) {
-  constexpr uint32_t unit = (uint32_t)(4294967296ull / kPvN);
-  const uint32_t expect = (((uint32_t)k * h) & (uint32_t)(kPvN - 1)) * unit;
-  const int32_t d = (int32_t)(p - prev_p - expect);
-  const int64_t q = (int64_t)((double)d * hratio);  // truncates toward zero
-  return (((uint32_t)k * (uint32_t)kPvHs) & (uint32_t)(kPvN - 1)) * unit + (uint32_t)q;
-}
-
-constexpr int kLockT = 512, kLockV = kPvM / kLockT;  // threads per row-walking workgroup, bins per thread
-static_assert(kLockV == 4, "a thread moves its bins as one 16-byte word");
+// ---- the recurrence over the peak records ---------------------------------------------------------------------------
+// State after row r, at the bins that are peaks of row r: whether the peak continued (a bit map) and, if so, its offset
+// C_r[p] — as a value (APPLY) or as a map entry (source bin at the chunk's start | none, sum of deltas).  Row r + 1 looks
+// its peaks' predecessors up in that state: E_r[p] = C_r[q] if q (the owner of bin p in row r: in the record) is valid and
+// continued, else 0.  The FIRST row of a chunk takes E from the dense row the chunk starts from instead (every bin has an
+// entry there: the identity map, or the offsets pv_lock_chunks computed), and the chunk's composed map is made dense again
+// after its last row (every bin's owner in that row).
+// APPLY = false: the chunk's composed map -> chunk_org / chunk_sums.  APPLY = true: chunk_sums holds the offsets at the
+// chunk's start; the peaks' offsets are written in record order (0 for a peak that restarts: its bins keep their phases).
+constexpr int kLockT = 256;
 __host__ __device__ inline int64_t pv_chunks(const PvArgs &a) { return (a.frames - a.first + a.scan_chunk - 1) / a.scan_chunk; }
 
-// APPLY = false: the chunk's composed map -> chunk_org / chunk_sums.  APPLY = true: chunk_sums holds the phases at the
-// chunk's start (pv_lock_chunks); the rows of Phi are written.
 template <bool APPLY>
 __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
-  using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
-  using u16x4 = uint16_t __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) uint32_t P[3][kPvM];
-  __shared__ __attribute__((aligned(16))) uint32_t D[2][kPvM];
-  __shared__ __attribute__((aligned(16))) uint16_t O[APPLY ? 1 : 2][APPLY ? 4 : kPvM];
-  const int t = threadIdx.x, k0 = t * kLockV;
+  constexpr int W = kPvM / 32;
+  __shared__ uint32_t SUM[2][kPvM];
+  __shared__ uint16_t ORG[APPLY ? 1 : 2][APPLY ? 2 : kPvM];
+  __shared__ uint32_t CM[3][W];      // bit p: peak p of that row continued (this row's, the previous row's, the one being cleared)
+  __shared__ uint32_t pkw[W + 2];    // (chunk end) the last row's peak map, a zero word either side
+  const int t = threadIdx.x;
   const int64_t c = blockIdx.x;
   const int64_t r0 = a.first + c * a.scan_chunk, r1 = r0 + a.scan_chunk < a.frames ? r0 + a.scan_chunk : a.frames;
-  u32x4 st;
-  if constexpr (APPLY) st = *reinterpret_cast<const u32x4 *>(a.chunk_sums + c * kPvM + k0);
-  else st = u32x4{0u, 0u, 0u, 0u};
-  *reinterpret_cast<u32x4 *>(&D[0][k0]) = st;
-  if constexpr (!APPLY) {
-    const u16x4 id = {(uint16_t)k0, (uint16_t)(k0 + 1), (uint16_t)(k0 + 2), (uint16_t)(k0 + 3)};
-    *reinterpret_cast<u16x4 *>(&O[0][k0]) = id;
+  if constexpr (APPLY) {
+    for (int k = t; k < kPvM; k += kLockT) SUM[1][k] = a.chunk_sums[c * kPvM + k];  // E at the chunk's start
   }
-  u32x4 prevrow = u32x4{0u, 0u, 0u, 0u};
-  if (r0 > 0) prevrow = *reinterpret_cast<const u32x4 *>(a.phase + (size_t)(r0 - 1) * kPvM + k0);
-  *reinterpret_cast<u32x4 *>(&P[(r0 + 2) % 3][k0]) = prevrow;  // row r0 - 1 sits in slot (r0 - 1) mod 3
-  __shared__ uint32_t pkw[2][kPvM / 32 + 2];  // the row's peak map, a zero word either side
-  if (t < 2) pkw[t][0] = pkw[t][kPvM / 32 + 1] = 0u;
-  u32x4 wn = *reinterpret_cast<const u32x4 *>(a.phase + (size_t)r0 * kPvM + k0);
-  uint32_t bn = t < kPvM / 32 ? a.pkmap[(size_t)r0 * (kPvM / 32) + t] : 0u;
-  int cur = 0;
-  u16x4 org_out = u16x4{kPvNoBin, kPvNoBin, kPvNoBin, kPvNoBin};
-  int pc = (int)(r0 % 3);
-  uint32_t hn = a.hop[r0];
-  double hrn = a.hratio[r0];
+  if (t < W) CM[0][t] = CM[1][t] = 0u;
+  int cur = 0;     // SUM / ORG: the row being written; cur ^ 1: the previous row's state
+  int cw = 0;      // CM: this row's map; (cw + 2) % 3 the previous row's; (cw + 1) % 3 is cleared for the next row
+  uint32_t cn = a.pkcount[r0];
+  uint2 rn = t < (int)cn ? a.recs[(size_t)r0 * kPvM + t] : uint2{0u, 0u};
+  __syncthreads();
   for (int64_t r = r0; r < r1; ++r) {
-    const int pp = pc == 0 ? 2 : pc - 1;  // row r - 1 sits in slot (r - 1) mod 3
-    const u32x4 w = wn;
-    *reinterpret_cast<u32x4 *>(&P[pc][k0]) = w;
-    if (t < kPvM / 32) pkw[r & 1][t + 1] = bn;
-    __syncthreads();  // row r and the state after row r-1 are complete; slot (r+1) mod 3 is no longer read
-    if (r + 1 < r1) {
-      wn = *reinterpret_cast<const u32x4 *>(a.phase + (size_t)(r + 1) * kPvM + k0);
-      if (t < kPvM / 32) bn = a.pkmap[(size_t)(r + 1) * (kPvM / 32) + t];
+    const int cnt = (int)cn;
+    uint2 rec = rn;
+    if (r + 1 < r1) {  // the next row's first kLockT records travel under this row
+      cn = a.pkcount[r + 1];
+      rn = t < (int)cn ? a.recs[(size_t)(r + 1) * kPvM + t] : uint2{0u, 0u};
     }
-    const uint32_t h = hn;
-    const double hr = hrn;
-    if (r + 1 < r1) {  // (scalar loads: a row ahead as well)
-      hn = a.hop[r + 1];
-      hrn = a.hratio[r + 1];
-    }
-    const uint32_t wk[4] = {w.x, w.y, w.z, w.w};
-    // owners of this thread's four bins: the nearest peak at most kPvReach bins away, the lower one on a tie
-    uint16_t ok[4];
-    {
-      const int wi = t >> 3;  // bins 4t .. 4t+3 sit in word wi of the map
-      const uint32_t w0 = pkw[r & 1][wi], w1 = pkw[r & 1][wi + 1], w2 = pkw[r & 1][wi + 2];
-      const uint64_t below = ((uint64_t)w1 << 32) | w0, above = ((uint64_t)w2 << 32) | w1;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int k = k0 + b, bit = k & 31;
-        const uint64_t lm_ = below & (~0ull >> (31 - bit));  // peaks at or below k (bit 32 + `bit` is k itself)
-        const uint64_t rm_ = above & (~0ull << bit);         // peaks at or above k
-        const int dl = lm_ ? (32 + bit) - (63 - __builtin_clzll(lm_)) : 1 << 20;
-        const int dr = rm_ ? __builtin_ctzll(rm_) - bit : 1 << 20;
-        const int dmin = dl <= dr ? dl : dr;
-        ok[b] = dmin <= kPvReach ? (uint16_t)(dl <= dr ? k - dl : k + dr) : kPvNoBin;
-      }
-    }
-    uint32_t nd[4];
-    uint16_t no[4];
-    // neighbouring bins mostly share their owner: its phase step and state are fetched once per run of equal owners
-    int p_prev = -1;
-    bool cont = false;
-    uint32_t base = 0u;       // D[cur][p] + inc_f[p] - P_f[p]
-    uint16_t base_org = kPvNoBin;
-#pragma unroll
-    for (int j = 0; j < kLockV; ++j) {
-      const uint32_t pk = wk[j] & ~1u;
-      const int p = ok[j];
-      if (p != p_prev) {
-        p_prev = p;
-        cont = false;
-        if (h >= 1 && p != kPvNoBin) {
-          const uint32_t wp = P[pc][p], wq = P[pp][p];
-          if ((wp & wq & 1u) != 0u) {
-            const uint32_t pp_ = wp & ~1u;
-            cont = true;
-            base = D[cur][p] + pv_inc(p, h, hr, pp_, wq & ~1u) - pp_;
-            if constexpr (!APPLY) base_org = O[cur][p];
-          }
+    const uint2 *rrow = a.recs + (size_t)r * kPvM;
+    uint32_t *crow = APPLY ? a.cvals + (size_t)r * kPvM : nullptr;
+    const int cp = cw == 0 ? 2 : cw - 1, cx = cw == 2 ? 0 : cw + 1;
+    if (t < W) CM[cx][t] = 0u;  // (last read during the previous row, before the barrier that ended it)
+    for (int i = t; i < cnt; i += kLockT) {
+      if (i != t) rec = rrow[i];
+      const int p = (int)(rec.x & 2047u);
+      const bool cont = (rec.x & kRecCont) != 0u;
+      uint32_t val = 0u;
+      uint16_t org = kPvNoBin;
+      if (cont) {
+        if (r == r0) {  // from the dense row the chunk starts from
+          val = (APPLY ? SUM[cur ^ 1][p] : 0u) + rec.y;
+          org = (uint16_t)p;
+        } else {
+          const int q = (int)((rec.x >> 11) & 2047u);
+          const bool link = (rec.x & kRecQValid) != 0u && ((CM[cp][q >> 5] >> (q & 31)) & 1u) != 0u;
+          val = (link ? SUM[cur ^ 1][q] : 0u) + rec.y;
+          if constexpr (!APPLY) org = link ? ORG[cur ^ 1][q] : kPvNoBin;
         }
+        SUM[cur][p] = val;
+        if constexpr (!APPLY) ORG[cur][p] = org;
+        atomicOr(&CM[cw][p >> 5], 1u << (p & 31));
       }
-      nd[j] = cont ? base + pk : pk;
-      no[j] = cont ? base_org : kPvNoBin;
+      if constexpr (APPLY) crow[i] = val;  // (0 where the peak restarts)
     }
-    const u32x4 ndv = {nd[0], nd[1], nd[2], nd[3]};
-    *reinterpret_cast<u32x4 *>(&D[cur ^ 1][k0]) = ndv;
-    if constexpr (!APPLY) {
-      org_out = u16x4{no[0], no[1], no[2], no[3]};
-      *reinterpret_cast<u16x4 *>(&O[cur ^ 1][k0]) = org_out;
-    } else {
-      __builtin_nontemporal_store(ndv, reinterpret_cast<u32x4 *>(a.phi + (size_t)r * kPvM + k0));
-    }
-    st = ndv;
+    __syncthreads();  // row r's state is complete; nobody reads row r-1's any more
     cur ^= 1;
-    pc = pc == 2 ? 0 : pc + 1;
+    cw = cx;
   }
   if constexpr (!APPLY) {
-    *reinterpret_cast<u32x4 *>(a.chunk_sums + c * kPvM + k0) = st;
-    *reinterpret_cast<u16x4 *>(a.chunk_org + c * kPvM + k0) = org_out;
+    // the chunk's map, dense: bin k ends the chunk with its owner's entry (or restarted: no owner, or an owner that did not
+    // continue).  cur ^ 1 (SUM / ORG) and the map before cw hold the last row's state.
+    const int cl = cw == 0 ? 2 : cw - 1;
+    const int64_t rl = r1 - 1;
+    if (t < W) pkw[t + 1] = r1 > r0 ? a.pkmap[(size_t)rl * W + t] : 0u;
+    if (t < 2) pkw[t ? W + 1 : 0] = 0u;
+    __syncthreads();
+    for (int k = t; k < kPvM; k += kLockT) {
+      const int o = pv_owner(&pkw[1], k);
+      const bool ok = o != (int)kPvNoBin && ((CM[cl][o >> 5] >> (o & 31)) & 1u) != 0u;
+      a.chunk_sums[c * kPvM + k] = ok ? SUM[cur ^ 1][o] : 0u;
+      a.chunk_org[c * kPvM + k] = ok ? ORG[cur ^ 1][o] : kPvNoBin;
+    }
   }
 }
 
@@ -407,13 +455,11 @@ __global__ __launch_bounds__(kChunkT) void pv_lock_chunks(const PvArgs a, int64_
   }
 }
 
-// One synthesis coefficient Yhat[k] = |X[k]|/N * e^{2 pi i Phi/2^32}; the Nyquist bin (k = M) is zero.
-__device__ __forceinline__ cpx pv_coef(float m, uint32_t phi, bool dc) {
-  const float turns = (float)(int32_t)phi * 2.3283064365386963e-10f;  // [-1/2, 1/2)
-  // v_sin_f32 / v_cos_f32 take their argument in turns
-  // (bin 0 contributes its real part only — y is the real part of the one-sided sum — and a locked DC bin no longer
-  // has a real coefficient by construction)
-  return mk(m * __builtin_amdgcn_cosf(turns), dc ? 0.f : m * __builtin_amdgcn_sinf(turns));
+// The phasor of a peak offset: e^{2 pi i C / 2^32} (v_sin_f32 / v_cos_f32 take their argument in turns; C = 0 gives (1, 0)
+// exactly, and multiplying by it leaves a coefficient bit for bit as it was).
+__device__ __forceinline__ cpx pv_phasor(uint32_t c) {
+  const float turns = (float)(int32_t)c * 2.3283064365386963e-10f;  // [-1/2, 1/2)
+  return mk(__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns));
 }
 
 // y[j] = sum_{k<N} Yhat[k] e^{+2 pi i jk/N} (Hermitian extension, real).  Packed z[m] = y[2m] + i y[2m+1] is
@@ -430,8 +476,14 @@ __host__ __device__ constexpr int64_t pv_blocks(int64_t frames) {
 
 __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) void pv_synthesis(const PvArgs a) {
   using P = PV;
+  // 16 + 16 + 8 KiB: exactly a quarter of the CU's LDS (four workgroups = two waves per SIMD)
   __shared__ __attribute__((aligned(16))) float2 lds[t1_size<P>()];
   __shared__ __attribute__((aligned(16))) float ring[P::N];  // overlap-add accumulator, stretched time mod N
+  // cd[k]: the synthesis offset C of bin k's owner peak in the frame whose coefficients are formed next (0: the bin rides
+  // on no peak, or on one that restarted — it keeps its analysis phase).  Written for frame f + 1 between the barriers of
+  // frame f's transform (zeroed after the first, the peaks' intervals filled in after the second), so the lock costs the
+  // walk no barrier of its own.
+  __shared__ __attribute__((aligned(16))) uint32_t cd[P::M];
   const int t_ = threadIdx.x;
   const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;
   for (int i = t_; i < P::N; i += P::T) ring[i] = 0.f;
@@ -440,63 +492,189 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   const int64_t f0 = a.first + blk * kPvBlockFrames;  // local frame indices; s[0] belongs to local frame a.first
   const int64_t f1 = blk == nb - 1 ? a.frames : f0 + kPvBlockFrames;
   float2 *ring2 = reinterpret_cast<float2 *>(ring);
+  // Every continuing peak of frame `fr` claims its bins in cd: from the midpoint to its lower neighbour (a tie goes to
+  // the lower peak) up to the midpoint to its upper neighbour, at most kPvReach either side.  A peak is served by
+  // G = 2^lg lanes (as many as the frame's peak count leaves: a sweep's handful of peaks are 65-bin intervals, music's
+  // hundreds are short).  The first round's records arrive as arguments (requested a frame earlier).
+  auto lanes_per_peak = [](int cnt) { return cnt <= 8 ? 4 : cnt <= 16 ? 3 : cnt <= 32 ? 2 : cnt <= 64 ? 1 : 0; };
+  auto fill_cd = [&](int64_t fr, int cnt, int tt, uint32_t r_m, uint32_t r_i, uint32_t r_n, uint32_t cv) {
+    const int lg = lanes_per_peak(cnt), G = 1 << lg, sub = tt & (G - 1);
+    const uint2 *rrow = a.recs + (size_t)fr * P::M;
+    const uint32_t *crow = a.cvals + (size_t)fr * P::M;
+    bool first = true;
+    for (int i = tt >> lg; i < cnt; i += P::T >> lg) {
+      if (!first) {
+        r_i = rrow[i].x;
+        r_m = i > 0 ? rrow[i - 1].x : 0u;
+        r_n = i + 1 < cnt ? rrow[i + 1].x : 0u;
+        cv = crow[i];
+      }
+      first = false;
+      if (!(r_i & kRecCont) || cv == 0u) continue;  // restarted (or an offset of exactly 0): nothing to write
+      const int p = (int)(r_i & 2047u);
+      const int pm = i > 0 ? (int)(r_m & 2047u) : -(1 << 14), pn = i + 1 < cnt ? (int)(r_n & 2047u) : (1 << 14);
+      int lo = ((pm + p) >> 1) + 1, hi = (p + pn) >> 1;  // (pm + p may be negative: arithmetic shift = floor)
+      lo = lo < p - kPvReach ? p - kPvReach : lo;
+      hi = hi > p + kPvReach ? p + kPvReach : hi;
+      lo = lo < 0 ? 0 : lo;
+      hi = hi > P::M - 1 ? P::M - 1 : hi;
+      for (int k = lo + sub; k <= hi; k += G) cd[k] = cv;
+    }
+  };
+  auto fetch_fill = [&](int64_t fr, int cnt, int tt, uint32_t &r_m, uint32_t &r_i, uint32_t &r_n, uint32_t &cv) {
+    const int i = tt >> lanes_per_peak(cnt);
+    const uint2 *rrow = a.recs + (size_t)fr * P::M;
+    r_m = r_i = r_n = cv = 0u;
+    if (i < cnt) {
+      r_i = rrow[i].x;
+      r_m = i > 0 ? rrow[i - 1].x : 0u;
+      r_n = i + 1 < cnt ? rrow[i + 1].x : 0u;
+      cv = a.cvals[(size_t)fr * P::M + i];
+    }
+  };
+  auto zero_cd = [&](int tt) {
+    using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < P::M / 4 / P::T; ++j) reinterpret_cast<u32x4 *>(cd)[tt + P::T * j] = u32x4{0u, 0u, 0u, 0u};
+  };
   // This thread's 2 x 16 bins of a frame: c = t + T e and its mirror M - c (bin M, thread 0's mirror of c = 0, is the
-  // dropped Nyquist bin: the load is clamped and the coefficient zeroed).  The rows of frame f + 1 are requested while
-  // frame f is in its last pass — left at the top of the loop their latency is the kernel (3.5 of 7.0 ms).
-  float rm[2 * P::E];
-  uint32_t rp[2 * P::E];
+  // dropped Nyquist bin: the load is clamped and the coefficient zeroed).  The row of frame f + 1 is requested while
+  // frame f is in its last pass.
+  cpx rx[2 * P::E];
   auto fetch_rows = [&](int64_t fr, int tt) {
-    const float *mrow = a.mags + (size_t)fr * P::M;
-    const uint32_t *prow = a.phi + (size_t)fr * P::M;
+    const float2 *xrow = a.xrows + (size_t)fr * P::M;
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       const int c = tt + P::T * e;
       const int cm = (P::M - c) & (P::M - 1);  // (c = 0 -> 0: clamped)
-      rm[2 * e] = mrow[c];
-      rp[2 * e] = prow[c];
-      rm[2 * e + 1] = mrow[cm];
-      rp[2 * e + 1] = prow[cm];
+      rx[2 * e] = xrow[c];
+      rx[2 * e + 1] = xrow[cm];
     }
   };
-  if (f0 < f1) fetch_rows(f0, t_);
-  const cpx wbase = a.wsplit[t_];  // e^{+2 pi i t/N}
+  int cnt1 = 0, cnt2 = 0;  // peak counts of frames f + 1, f + 2
+  if (f0 < f1) {
+    fetch_rows(f0, t_);
+    zero_cd(t_);
+    uint32_t r_m, r_i, r_n, cv;
+    const int cnt0 = (int)a.pkcount[f0];
+    fetch_fill(f0, cnt0, t_, r_m, r_i, r_n, cv);
+    cnt1 = f0 + 1 < f1 ? (int)a.pkcount[f0 + 1] : 0;
+    __syncthreads();
+    fill_cd(f0, cnt0, t_, r_m, r_i, r_n, cv);
+    __syncthreads();
+  }
+  const cpx wbase0 = a.wsplit[t_];  // e^{+2 pi i t/N}
+  // The pass twiddles of this thread are powers of one root each: gamma^r (pass 2, r = 1..15) and delta^r (pass 3,
+  // r = 1..7).  The powers 1, 2, 4 (, 8) stay in registers for the whole walk, the others are one packed product each per
+  // frame: a table read per twiddle and frame — 22 L2 round trips in front of the two passes — was latency nothing hid.
+  cpx g2b[4], g3b[3];
+  {
+    const int k = t_ & (P::R1 - 1), col = t_ ? t_ : P::NS3 / 2;
+    g2b[0] = a.tw2[0 * P::R1 + k];
+    g2b[1] = a.tw2[1 * P::R1 + k];
+    g2b[2] = a.tw2[3 * P::R1 + k];
+    g2b[3] = a.tw2[7 * P::R1 + k];
+    g3b[0] = a.tw3[0 * P::NS3 + col];
+    g3b[1] = a.tw3[1 * P::NS3 + col];
+    g3b[2] = a.tw3[3 * P::NS3 + col];
+  }
   for (int64_t f = f0; f < f1; ++f) {
     // LICM may keep this thread's window and split twiddles in registers for the whole walk (twice as fast as
     // reloading them per frame), but not the pass twiddles as well: those would push the kernel past 256 VGPRs
     const int t = t_;
     int zoff = 0;
     asm volatile("" : "+s"(zoff));
-    const float2 *tw2 = a.tw2 + zoff, *tw3 = a.tw3 + zoff;
     const float2 *w2 = reinterpret_cast<const float2 *>(a.hann);
     const int kp = k0p<P>(t), kq = k0q<P>(t);
+    // (the sixteen products wbase * e^{2 pi i e/32} are rebuilt per frame: hoisted out of the walk they cost 32 registers and
+    // the kernel spills — 15.3 against 13.9 ms per hour)
+    cpx wbase = wbase0;
+    asm volatile("" : "+v"(wbase.x), "+v"(wbase.y));
+    // the next frame's first round of records (its count came a frame ago) and the count of the frame after it
+    uint32_t nr_m, nr_i, nr_n, ncv;
+    fetch_fill(f + 1 < f1 ? f + 1 : f, cnt1, t, nr_m, nr_i, nr_n, ncv);
+    cnt2 = f + 2 < f1 ? (int)a.pkcount[f + 2] : 0;
     cpx Y[P::E], v[P::E];
+    uint32_t cc[2 * P::E];  // (one batch of LDS reads in front of the wave-uniform branches below, not one wait per branch)
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       const int c = t + P::T * e;
-      const cpx A = pv_coef(rm[2 * e], rp[2 * e], c == 0);
-      cpx B = cconj(pv_coef(rm[2 * e + 1], rp[2 * e + 1], false));
-      if (c == 0) B = mk(0.f, 0.f);
+      cc[2 * e] = cd[c];
+      cc[2 * e + 1] = cd[(P::M - c) & (P::M - 1)];
+    }
+    // Yhat[k] = X[k] e^{2 pi i C/2^32}, C the offset of the bin's owner (0: the bin keeps its analysis phase — most bins of
+    // most frames: a wavefront whose bins of four slots all ride on nothing skips their phasors; multiplying by the phasor
+    // of 0 would leave them bit for bit as they are, so who skips does not matter)
+#pragma unroll
+    for (int e4 = 0; e4 < P::E; e4 += 4) {
+      uint32_t any = 0u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) any |= cc[2 * e4 + j];
+      if (__ballot(any != 0u) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rx[2 * e4 + j] = cmul(rx[2 * e4 + j], pv_phasor(cc[2 * e4 + j]));
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      const int c = t + P::T * e;
+      cpx A = rx[2 * e], B = rx[2 * e + 1];
+      B = cconj(B);
+      // (bin 0 contributes its real part only — y is the real part of the one-sided sum — and bin M, thread 0's mirror
+      // of c = 0, is the dropped Nyquist bin)
+      if (c == 0) {
+        A = mk(A.x, 0.f);
+        B = mk(0.f, 0.f);
+      }
       const cpx Sm = cadd(A, B), Dm = csub(A, B);
       // w_c = e^{2 pi i c/N} = e^{2 pi i t/N} * e^{2 pi i e/32}: one hoisted value and a constant, not 16 table entries
-      // held in registers for the whole walk (they are what the row prefetch needed the room of)
       const cpx wd = cmul(cmul(wbase, mk(kW32[e][0], kW32[e][1])), Dm);  // w_c (A-B)
       Y[e] = mk(Sm.x - wd.y, -(Sm.y + wd.x));      // conj((A+B) + i*wd)
     }
     pass1<P>(Y, v);
-    __syncthreads();  // (also: the previous frame's hop has left the ring and its slots are zero)
+    __syncthreads();  // (the previous frame's hop has left the ring; every wave has read this frame's offsets)
     store_t1<P>(t, v, lds);
+    zero_cd(t);
     __syncthreads();
     load_t1<P>(t, v, lds);
     __syncthreads();
-    pass2<P>(t, v, tw2);
+    {
+      cpx g1 = g2b[0];
+      asm volatile("" : "+v"(g1.x), "+v"(g1.y));  // (the products below are not hoisted out of the walk)
+      cpx w[P::R2 - 1];
+      w[0] = g1;
+      w[1] = g2b[1];
+      w[3] = g2b[2];
+      w[7] = g2b[3];
+      w[2] = pk_cmul2(g2b[1], g1);
+      w[4] = pk_cmul2(g2b[2], g1);
+      w[5] = pk_cmul2(g2b[2], g2b[1]);
+      w[6] = pk_cmul2(g2b[2], w[2]);
+#pragma unroll
+      for (int r = 0; r < 7; ++r) w[8 + r] = pk_cmul2(g2b[3], w[r]);
+      pass2_reg<P>(v, w);
+    }
     store_t2<P>(t, v, lds);
+    // (here, not right behind the zeroing barrier: the records requested at the top of the frame have had two passes to arrive)
+    if (f + 1 < f1) fill_cd(f + 1, cnt1, t, nr_m, nr_i, nr_n, ncv);
+    cnt1 = cnt2;
     __syncthreads();
     load_t2<P>(t, v, lds);
     cpx w3[P::R3 - 1];
     int tl = t_;
     asm volatile("" : "+v"(tl));  // (or the 64 row offsets are kept in registers for the whole walk)
-    fetch_tw3<P>(tl, tw3, w3);  // (ahead of the row requests: loads return in order)
     if (f + 1 < f1) fetch_rows(f + 1, tl);
+    {
+      cpx d1 = g3b[0];
+      asm volatile("" : "+v"(d1.x), "+v"(d1.y));
+      w3[0] = d1;
+      w3[1] = g3b[1];
+      w3[3] = g3b[2];
+      w3[2] = pk_cmul2(g3b[1], d1);
+      w3[4] = pk_cmul2(g3b[2], d1);
+      w3[5] = pk_cmul2(g3b[2], g3b[1]);
+      w3[6] = pk_cmul2(g3b[2], w3[2]);
+    }
     if (wave0) pass3_reg<P, true>(t, v, w3);
     else pass3_reg<P, false>(t, v, w3);
     // v[r] = D[k0p + NS3 r], v[q_index(r)] = D[k0q + NS3 r]; sample pair m: y[2m] = Re D[m], y[2m+1] = -Im D[m].

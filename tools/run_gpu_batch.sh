@@ -1,8 +1,9 @@
 set -u
-export TMPDIR=/tmp
-mkdir -p gpurun_out/r04
-O=gpurun_out/r04
-export MELONIX_STFT_OVL=0
-L=$O/ab_mirror_stores.log
-bash tools/pmc_variant.sh "32768x375 16384x512" shipped melonix_amd/lib/variants/mirror_plain.so melonix_amd/lib/variants/all_plain.so 2>&1 | tee -a $L
-tail -3 gpurun_out/pmc_var/shipped_WRITE_SIZE.log
+timeout 900 python -m pytest tests/test_pv.py -m gpu -q -x 2>&1 | tail -2
+for lib in shipped melonix_amd/lib/variants/pvs_winzoff.so; do
+  if [ "$lib" = shipped ]; then unset MX_AB_LIB; else export MX_AB_LIB=$lib; fi
+  echo "== $lib"
+  python tools/pv_ab.py 60 3 sweep 2>&1 | grep "^pv"
+  python tools/pv_ab.py 60 3 rich 2>&1 | grep "^pv"
+  STATS_ONLY=1 bash tools/profile_pv.sh ab sweep | grep -E "^pv_(analysis|synthesis)"
+done
