@@ -769,8 +769,8 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   p.tw2 = t.tw2;
   p.tw3 = t.tw3;
   p.ubase = t.ubase;
-  // chunks of the frame axis for the scan: about 768 of them (the pass over the chunk maps is serial), at least 64 frames each
-  p.scan_chunk = (int)std::max<int64_t>(64, (Fl - first + 767) / 768);  // (three row-walking workgroups per CU)
+  // chunks of the frame axis for the scan: about 1536 of them (their maps are composed in groups of 32), at least 64 frames each
+  p.scan_chunk = (int)std::max<int64_t>(64, (Fl - first + 1535) / 1536);  // (one round of row-walking workgroups, six per CU)
   p.s_len = (Fl - first) * Hs + N;
   p.s_origin = F_lo * Hs;
   const int64_t nchunks = (Fl - first + p.scan_chunk - 1) / p.scan_chunk;
@@ -783,6 +783,7 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_apos = take((size_t)Fl * 8), o_h = take(N * 4), o_hs = take(N * 4), o_m = take(rowsz * 8),
                o_p = take(rowsz * 8), o_i = take(rowsz * 4), o_pc = take((size_t)Fl * 4), o_c = take((size_t)nchunks * M * 4),
+               o_gs = take((size_t)((nchunks + 31) / 32) * M * 4), o_go = take((size_t)((nchunks + 31) / 32) * M * 2),
                o_f = take((size_t)pv_halo_floats(Fl - first) * 4), o_s = take(((size_t)p.s_len + 1) * 4),
                o_w = take((size_t)M * 8), o_a = take((size_t)nchunks * M * 2), o_ow = take((size_t)Fl * (M / 32) * 4),
                o_ts = take((size_t)M * 4), o_ta = take((size_t)M * 2), o_ci = take((size_t)M * 4),
@@ -832,6 +833,8 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   p.cvals = reinterpret_cast<uint32_t *>(arena + o_i);
   p.pkcount = reinterpret_cast<uint32_t *>(arena + o_pc);
   p.chunk_sums = reinterpret_cast<uint32_t *>(arena + o_c);
+  p.group_sums = reinterpret_cast<uint32_t *>(arena + o_gs);
+  p.group_org = reinterpret_cast<uint16_t *>(arena + o_go);
   p.halo = reinterpret_cast<float *>(arena + o_f);
   p.wsplit = reinterpret_cast<const float2 *>(arena + o_w);
   p.s = reinterpret_cast<float *>(arena + o_s);

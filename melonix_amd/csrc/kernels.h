@@ -81,6 +81,8 @@ struct PvArgs {
   uint32_t *cvals;     // [frames][N/2] out of the second sweep: C_f of the frame's peaks in record order (0 = restarted)
   uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2] a chunk's composed map: delta (or restart value) ...
   uint16_t *chunk_org;   // ... and source bin at the chunk's start (0xFFFF: restart); then the chunk-start offsets
+  uint32_t *group_sums;  // [ceil(chunks/32)][N/2] the same for groups of 32 chunks (the composition is two-level)
+  uint16_t *group_org;
   int scan_chunk;
   float *halo;        // pv_halo_floats(frames): partial sums right of each synthesis-workgroup boundary
   float *s;           // stretched signal, s_len = frames*Hs + N, index 0 = stretched time -N/2

@@ -110,19 +110,32 @@ __device__ __forceinline__ int pv_owner(const uint32_t *pk, int k) {
   return dmin <= kPvReach ? (dl <= dr ? k - dl : k + dr) : (int)kPvNoBin;
 }
 
-__global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(3, 3))) void pv_analysis(const PvArgs a) {
+// inclusive sum over the 64 lanes of a wavefront through the DPP crossbar (row_shr 1, 2, 4, 8; row_bcast:15, row_bcast:31)
+__device__ __forceinline__ int wave_scan_add(int x) {
+#define MX_SCAN_STEP(CTRL, ROWS) x += __builtin_amdgcn_update_dpp(0, x, CTRL, ROWS, 0xf, false);
+  MX_SCAN_STEP(0x111, 0xf)
+  MX_SCAN_STEP(0x112, 0xf)
+  MX_SCAN_STEP(0x114, 0xf)
+  MX_SCAN_STEP(0x118, 0xf)
+  MX_SCAN_STEP(0x142, 0xa)
+  MX_SCAN_STEP(0x143, 0xc)
+#undef MX_SCAN_STEP
+  return x;
+}
+
+__global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   using P = PV;
-  // the M-point image (after the transform it holds X_f in bin order, for the peak search and the records); the pass-2
-  // twiddle table (2 KiB, shared by both waves); this thread's pass-3 twiddles stay in registers for the whole walk
-  // (stft_kernel's arrangement).  The previous frame's spectrum, which the records need at this frame's peaks only, is
-  // read back from its row in HBM/L2 — this workgroup wrote it one iteration ago (a second image for it would cost the
-  // third wave per SIMD: 39 KiB of LDS per workgroup against 23).
+  // the M-point image (after the transform it holds X_f in bin order, for the peak search and the row's way to HBM); the
+  // pass-2 twiddle table (2 KiB, shared by both waves).  The records of a frame need its spectrum and the previous
+  // frame's at its peaks only: they are made ONE FRAME LATER, from the two rows in HBM/L2 (this workgroup wrote them) —
+  // the gathers are issued at the top of the next frame's transform and have all of it to arrive.  (A second image for the
+  // previous spectrum costs the third wave per SIMD; gathering in the frame's own iteration leaves ~4 us of latency bare.)
   constexpr int kTw2 = ((P::TW2 + 1) / 2) * 2;
   constexpr int W = P::M / 32;  // words of a peak map
   __shared__ __attribute__((aligned(16))) float2 lds[P::M];
   __shared__ __attribute__((aligned(16))) float2 ltw2[kTw2];
-  __shared__ uint32_t pkb[2][W + 2];  // the frame's peak map and the previous frame's, a zero word either side
-  __shared__ uint16_t plist[P::M];    // the frame's peak bins, ascending
+  __shared__ uint32_t pkb[3][W + 2];  // the peak maps of frames f, f-1, f-2 (by frame mod 3), a zero word either side
+  __shared__ uint16_t plist[P::M];    // the peak bins of the frame whose records are pending, ascending
   __shared__ float red[2][2];         // per wavefront: the largest squared magnitude (alternating frames)
   __shared__ uint32_t npk;
   const int t_ = threadIdx.x;
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     w3b[2] = a.tw3[3 * P::NS3 + col];
   }
   for (int i = t_; i < P::TW2; i += P::T) ltw2[i] = a.tw2[i];
-  for (int i = t_; i < 2 * (W + 2); i += P::T) (&pkb[0][0])[i] = 0u;
+  for (int i = t_; i < 3 * (W + 2); i += P::T) (&pkb[0][0])[i] = 0u;
   // XCD-aware block -> frame-range map, as in stft_kernel: every XCD takes one contiguous eighth of the frame range — the
   // 95 % overlap between neighbouring blocks' samples is then an L2 hit
   unsigned lb = blockIdx.x;
@@ -157,19 +170,46 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   cpx xr[P::E];
   load_raw<P, false>(t_, xr, a.audio + MX_AUDIO_PAD + (a.apos[fw] - P::N / 2));
   __syncthreads();
+
+  // The record of one peak of frame fr (p: its bin; xc, xq: X_fr[p], X_{fr-1}[p]; pkq: the peak map of frame fr - 1;
+  // thrq: that frame's activity threshold)
+  auto make_record = [&](int64_t fr, int p, float2 xc, float2 xq, const uint32_t *pkq, float thrq, bool prev_exists) {
+    const uint32_t h = a.hop[fr];
+    const double hr = a.hratio[fr];
+    const uint32_t pc_ = to_turns(xc.x, xc.y), pp_ = to_turns(xq.x, xq.y);
+    const bool cont = prev_exists && h >= 1 && cnorm2(xq) >= thrq;
+    const int q = pv_owner(pkq, p);
+    uint2 rec;
+    rec.x = (uint32_t)p | (q != (int)kPvNoBin ? ((uint32_t)q << 11) | kRecQValid : 0u) | (cont ? kRecCont : 0u);
+    rec.y = pp_ + pv_inc(p, h, hr, pc_, pp_) - pc_;
+    return rec;
+  };
+  // pending: the frame whose peaks are listed in plist (records not yet written)
+  int pend_cnt = 0;
+  bool pend = false;
+  float thr2_1 = 0.f, thr2_2 = 0.f;  // thresholds of frames f-1, f-2
+  int m0 = (int)(fw % 3);            // pkb index of frame f
   int cur = 0;
-  float thr2_prev = 0.f;
-  bool have_prev = false;
   for (int64_t f = fw; f < f1; ++f) {
     // as in stft_kernel: re-materialise the thread index and a zero table offset per frame, or LICM hoists every
     // frame-invariant table value and address out of the loop
     int t = t_, zoff = 0;
     asm volatile("" : "+v"(t), "+s"(zoff));
     const bool emit = f >= f0;  // (block-uniform)
+    const int m1 = m0 == 0 ? 2 : m0 - 1, m2 = m1 == 0 ? 2 : m1 - 1;  // maps of frames f-1, f-2
     cpx Y[P::E], v[P::E];
     apply_window<P, 1, true>(t, Y, xr, a.hann_scaled + zoff);
     pass1<P>(Y, v);
-    __syncthreads();  // every wave is past the previous frame's record loop (it read the image and both maps)
+    __syncthreads();  // every wave is past the previous frame's peak numbering: plist and npk are complete
+    if (pend) pend_cnt = (int)npk;
+    // the pending frame's (f - 1) first record per thread: its spectrum and the one before at the peak, from their rows
+    float2 ga = make_float2(0.f, 0.f), gb = make_float2(0.f, 0.f);
+    int gp = 0;
+    if (pend && t < pend_cnt) {
+      gp = plist[t];
+      ga = a.xrows[(size_t)(f - 1) * P::M + gp];
+      if (f >= 2) gb = a.xrows[(size_t)(f - 2) * P::M + gp];
+    }
     store_t1<P>(t, v, lds);
     __syncthreads();
     cpx w2[P::R2 - 1];
@@ -203,9 +243,9 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         post_cplx<P, false>(t, v, u, X);
       }
     }
-    // X_f goes into the image in bin order (consecutive lanes hold consecutive bins) — for the peak search, the records
-    // and, behind the barrier, for its way to HBM as aligned 16-byte stores, 1 KiB per wavefront instruction; the frame's
-    // largest squared magnitude through the DPP crossbar and two LDS words
+    // X_f goes into the image in bin order (consecutive lanes hold consecutive bins) — for the peak search and, behind the
+    // barrier, for its way to HBM as aligned 16-byte stores, 1 KiB per wavefront instruction; the frame's largest squared
+    // magnitude through the DPP crossbar and two LDS words
     float mx2 = 0.f;
 #pragma unroll
     for (int o = 0; o < P::E; ++o) {
@@ -215,10 +255,9 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     }
     const uint32_t wmax = wave_reduce_u32<true>(__float_as_uint(mx2));  // non-negative floats order like their bit patterns
     if ((t & 63) == 0) red[cur][t >> 6] = __uint_as_float(wmax);
-    if (t < W) pkb[cur][t + 1] = 0u;
+    if (t < W) pkb[m0][t + 1] = 0u;
     __syncthreads();
-    // the samples of frame f + 1 are requested here: they travel under the peak search, the numbering and the records
-    // (requested before the last pass their 32 registers cost the third wave per SIMD)
+    // the samples of frame f + 1 are requested here: they travel under the peak search, the records and the numbering
     if (f + 1 < f1) load_raw<P, false>(t, xr, a.audio + MX_AUDIO_PAD + (a.apos[f + 1] - P::N / 2));
     {
       using f32x4 = float __attribute__((ext_vector_type(4)));
@@ -252,55 +291,60 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(3, 3))) v
                         c >= kPvPeakMargin2 * v8[b + 3] && c >= kPvPeakMargin2 * v8[b + 4];
         nib |= pk ? (1u << b) : 0u;
       }
-      if (nib) atomicOr(&pkb[cur][1 + (j >> 3)], nib << (4 * (j & 7)));
+      if (nib) atomicOr(&pkb[m0][1 + (j >> 3)], nib << (4 * (j & 7)));
+    }
+    // the pending frame's records (one per thread from the registers; a frame with more peaks than threads gathers the
+    // rest here), before this frame's peaks take the list over
+    if (pend) {
+      uint2 *rrow = a.recs + (size_t)(f - 1) * P::M;
+      const float2 *xa = a.xrows + (size_t)(f - 1) * P::M, *xb = a.xrows + (size_t)(f >= 2 ? f - 2 : 0) * P::M;
+      for (int i = t; i < pend_cnt; i += P::T) {
+        if (i != t) {
+          gp = plist[i];
+          ga = xa[gp];
+          gb = f >= 2 ? xb[gp] : make_float2(0.f, 0.f);
+        }
+        rrow[i] = make_record(f - 1, gp, ga, gb, &pkb[m2][1], thr2_2, f >= 2);
+      }
     }
     __syncthreads();
-    // the first wavefront numbers the peaks (exclusive scan of the words' populations through the DPP crossbar) and lists
-    // their bins in ascending order; records are then one per thread, whatever the peaks' positions
+    // the first wavefront numbers this frame's peaks (exclusive scan of the words' populations through the DPP crossbar)
+    // and lists their bins in ascending order
     if (wave0) {
-      const uint32_t w = pkb[cur][1 + t];  // W == 64: one word per lane
+      const uint32_t w = pkb[m0][1 + t];  // W == 64: one word per lane
       const int c = __builtin_popcount(w);
-      int inc = c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(inc, d, 64);
-        inc += (t >= d) ? up : 0;
-      }
-      const int base = inc - c;
+      const int inc = wave_scan_add(c);
       if (t == 63) npk = (uint32_t)inc;
       uint32_t rest = w;
-      int r = base;
+      int r = inc - c;
       while (rest) {
         const int b = __builtin_ctz(rest);
         rest &= rest - 1;
         plist[r++] = (uint16_t)(32 * t + b);
       }
-    }
-    __syncthreads();
-    const int cnt = (int)npk;
-    if (emit) {
-      const uint32_t h = a.hop[f];
-      const double hr = a.hratio[f];
-      uint2 *rrow = a.recs + (size_t)f * P::M;
-      const float2 *xprev = a.xrows + (size_t)(f > 0 ? f - 1 : 0) * P::M;
-      for (int i = t; i < cnt; i += P::T) {
-        const int p = plist[i];
-        const float2 xc = lds[p], xq = have_prev ? xprev[p] : make_float2(0.f, 0.f);
-        const uint32_t pc_ = to_turns(xc.x, xc.y), pp_ = to_turns(xq.x, xq.y);
-        const bool cont = have_prev && h >= 1 && cnorm2(xq) >= thr2_prev;
-        const int q = pv_owner(&pkb[cur ^ 1][1], p);
-        const uint32_t delta = pp_ + pv_inc(p, h, hr, pc_, pp_) - pc_;
-        uint2 rec;
-        rec.x = (uint32_t)p | (q != (int)kPvNoBin ? ((uint32_t)q << 11) | kRecQValid : 0u) | (cont ? kRecCont : 0u);
-        rec.y = delta;
-        rrow[i] = rec;
+      if (emit) {
+        a.pkmap[(size_t)f * W + t] = w;
+        if (t == 63) a.pkcount[f] = (uint32_t)inc;
       }
-      if (t < W) a.pkmap[(size_t)f * W + t] = pkb[cur][1 + t];
-      if (t == 0) a.pkcount[f] = (uint32_t)cnt;
     }
-    thr2_prev = thr2;
-    have_prev = true;
+    pend = emit;
+    thr2_2 = thr2_1;
+    thr2_1 = thr2;
+    m0 = m0 == 2 ? 0 : m0 + 1;
     cur ^= 1;
+  }
+  __syncthreads();
+  pend_cnt = (int)npk;
+  // the last frame's records: no next transform to hide the gathers under
+  {
+    const int64_t fl = f1 - 1;
+    const int m1 = m0 == 0 ? 2 : m0 - 1, m2 = m1 == 0 ? 2 : m1 - 1;  // m1: frame fl's map, m2: frame fl - 1's
+    uint2 *rrow = a.recs + (size_t)fl * P::M;
+    const float2 *xa = a.xrows + (size_t)fl * P::M, *xb = a.xrows + (size_t)(fl >= 1 ? fl - 1 : 0) * P::M;
+    for (int i = t_; i < pend_cnt; i += P::T) {
+      const int p = plist[i];
+      rrow[i] = make_record(fl, p, xa[p], fl >= 1 ? xb[p] : make_float2(0.f, 0.f), &pkb[m2][1], thr2_2, fl >= 1);
+    }
   }
 }
 
@@ -313,7 +357,7 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 // after its last row (every bin's owner in that row).
 // APPLY = false: the chunk's composed map -> chunk_org / chunk_sums.  APPLY = true: chunk_sums holds the offsets at the
 // chunk's start; the peaks' offsets are written in record order (0 for a peak that restarts: its bins keep their phases).
-constexpr int kLockT = 256;
+constexpr int kLockT = 128;
 __host__ __device__ inline int64_t pv_chunks(const PvArgs &a) { return (a.frames - a.first + a.scan_chunk - 1) / a.scan_chunk; }
 
 template <bool APPLY>
@@ -332,45 +376,68 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
   if (t < W) CM[0][t] = CM[1][t] = 0u;
   int cur = 0;     // SUM / ORG: the row being written; cur ^ 1: the previous row's state
   int cw = 0;      // CM: this row's map; (cw + 2) % 3 the previous row's; (cw + 1) % 3 is cleared for the next row
-  uint32_t cn = a.pkcount[r0];
-  uint2 rn = t < (int)cn ? a.recs[(size_t)r0 * kPvM + t] : uint2{0u, 0u};
+  // Rows are a few dozen records each and a row's work is a handful of LDS operations: what a row costs is the latency of
+  // its records' load.  They are requested kAhead rows ahead (counts and each thread's first record, a register ring).
+  constexpr int kAhead = 4;
+  uint32_t cn[kAhead];
+  uint2 rn[kAhead];
+  // (unconditional loads — a row past the chunk reads the chunk's last row again, a thread past the row's count reads an
+  // entry nobody wrote: neither is used — so that the compiler can count them: behind a branch every wait becomes vmcnt(0)
+  // and the ring hides nothing)
+  auto request = [&](int64_t rr, uint32_t &cnt_, uint2 &rec_) {
+    const int64_t rq = rr < r1 ? rr : r1 - 1;
+    cnt_ = rr < r1 ? a.pkcount[rq] : 0u;
+    rec_ = a.recs[(size_t)rq * kPvM + t];
+  };
+#pragma unroll
+  for (int j = 0; j < kAhead; ++j) request(r0 + j, cn[j], rn[j]);
   __syncthreads();
-  for (int64_t r = r0; r < r1; ++r) {
-    const int cnt = (int)cn;
-    uint2 rec = rn;
-    if (r + 1 < r1) {  // the next row's first kLockT records travel under this row
-      cn = a.pkcount[r + 1];
-      rn = t < (int)cn ? a.recs[(size_t)(r + 1) * kPvM + t] : uint2{0u, 0u};
+  for (int64_t rb = r0; rb < r1; rb += kAhead) {
+    uint32_t cc[kAhead];
+    uint2 rc[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+      cc[j] = cn[j];
+      rc[j] = rn[j];
     }
-    const uint2 *rrow = a.recs + (size_t)r * kPvM;
-    uint32_t *crow = APPLY ? a.cvals + (size_t)r * kPvM : nullptr;
-    const int cp = cw == 0 ? 2 : cw - 1, cx = cw == 2 ? 0 : cw + 1;
-    if (t < W) CM[cx][t] = 0u;  // (last read during the previous row, before the barrier that ended it)
-    for (int i = t; i < cnt; i += kLockT) {
-      if (i != t) rec = rrow[i];
-      const int p = (int)(rec.x & 2047u);
-      const bool cont = (rec.x & kRecCont) != 0u;
-      uint32_t val = 0u;
-      uint16_t org = kPvNoBin;
-      if (cont) {
-        if (r == r0) {  // from the dense row the chunk starts from
-          val = (APPLY ? SUM[cur ^ 1][p] : 0u) + rec.y;
-          org = (uint16_t)p;
-        } else {
-          const int q = (int)((rec.x >> 11) & 2047u);
-          const bool link = (rec.x & kRecQValid) != 0u && ((CM[cp][q >> 5] >> (q & 31)) & 1u) != 0u;
-          val = (link ? SUM[cur ^ 1][q] : 0u) + rec.y;
-          if constexpr (!APPLY) org = link ? ORG[cur ^ 1][q] : kPvNoBin;
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) request(rb + kAhead + j, cn[j], rn[j]);
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+      const int64_t r = rb + j;
+      if (r >= r1) break;  // (block-uniform)
+      const int cnt = (int)cc[j];
+      uint2 rec = rc[j];
+      const uint2 *rrow = a.recs + (size_t)r * kPvM;
+      uint32_t *crow = APPLY ? a.cvals + (size_t)r * kPvM : nullptr;
+      const int cp = cw == 0 ? 2 : cw - 1, cx = cw == 2 ? 0 : cw + 1;
+      if (t < W) CM[cx][t] = 0u;  // (last read during the previous row, before the barrier that ended it)
+      for (int i = t; i < cnt; i += kLockT) {
+        if (i != t) rec = rrow[i];
+        const int p = (int)(rec.x & 2047u);
+        const bool cont = (rec.x & kRecCont) != 0u;
+        uint32_t val = 0u;
+        uint16_t org = kPvNoBin;
+        if (cont) {
+          if (r == r0) {  // from the dense row the chunk starts from
+            val = (APPLY ? SUM[cur ^ 1][p] : 0u) + rec.y;
+            org = (uint16_t)p;
+          } else {
+            const int q = (int)((rec.x >> 11) & 2047u);
+            const bool link = (rec.x & kRecQValid) != 0u && ((CM[cp][q >> 5] >> (q & 31)) & 1u) != 0u;
+            val = (link ? SUM[cur ^ 1][q] : 0u) + rec.y;
+            if constexpr (!APPLY) org = link ? ORG[cur ^ 1][q] : kPvNoBin;
+          }
+          SUM[cur][p] = val;
+          if constexpr (!APPLY) ORG[cur][p] = org;
+          atomicOr(&CM[cw][p >> 5], 1u << (p & 31));
         }
-        SUM[cur][p] = val;
-        if constexpr (!APPLY) ORG[cur][p] = org;
-        atomicOr(&CM[cw][p >> 5], 1u << (p & 31));
+        if constexpr (APPLY) crow[i] = val;  // (0 where the peak restarts)
       }
-      if constexpr (APPLY) crow[i] = val;  // (0 where the peak restarts)
+      __syncthreads();  // row r's state is complete; nobody reads row r-1's any more
+      cur ^= 1;
+      cw = cx;
     }
-    __syncthreads();  // row r's state is complete; nobody reads row r-1's any more
-    cur ^= 1;
-    cw = cx;
   }
   if constexpr (!APPLY) {
     // the chunk's map, dense: bin k ends the chunk with its owner's entry (or restarted: no owner, or an owner that did not
@@ -389,22 +456,36 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
   }
 }
 
-// The serial pass over the chunk maps (one workgroup, two bins per thread, one barrier per chunk).
-// MAP = false: phases at every chunk's start, from carry_in (the phase row at the end of the previous rank's last
-// frame; irrelevant for the rank that holds frame 0, which restarts every bin) — they replace the chunk's delta row.
-// MAP = true: this rank's total map (tot_org, tot_sums), what the other ranks need to know of it; the chunk maps stay.
+// Composition of chunk maps, in order (two bins per thread, one barrier per map).  One workgroup composes the maps
+// sums[n0 .. n0 + cnt) / org[...] of its group, n0 = blockIdx.x * per_group:
+// MAP = false: the offsets every map of the group starts from, beginning with init (+ blockIdx.x * M when init_per_group;
+//              null: zeros) — they REPLACE the map's delta row.
+// MAP = true:  the group's composed map -> out_sums / out_org [blockIdx.x][M]; the maps stay.
+// The frame axis is cut into ~1536 chunks (one round of row-walking workgroups: what a walk costs is rows x latency), so
+// their composition is two-level: groups of kPvGroup chunk maps in parallel (MAP = true), one pass over the group maps
+// (MAP = false: group-start offsets, from carry_in — the offset row at the end of the previous rank's last frame,
+// irrelevant for the rank that holds frame 0, which restarts every bin; MAP = true: this rank's total map, what the
+// other ranks need to know of it), then the groups again in parallel from their start offsets (MAP = false).
 constexpr int kChunkT = 1024, kChunkV = kPvM / kChunkT;
+constexpr int kPvGroup = 32;
 template <bool MAP>
-__global__ __launch_bounds__(kChunkT) void pv_lock_chunks(const PvArgs a, int64_t nchunks) {
+__global__ __launch_bounds__(kChunkT) void pv_lock_chunks(uint32_t *sums, uint16_t *org, int64_t n, int per_group,
+                                                          const uint32_t *init, int init_per_group, uint32_t *out_sums,
+                                                          uint16_t *out_org) {
   __shared__ uint32_t D[2][kPvM];
   __shared__ uint16_t O[MAP ? 2 : 1][MAP ? kPvM : 2];
   const int t = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * per_group;
+  const int64_t cnt = n0 + per_group < n ? per_group : n - n0;
+  sums += n0 * kPvM;
+  org += n0 * kPvM;
+  if (init && init_per_group) init += (int64_t)blockIdx.x * kPvM;
   uint32_t sd[kChunkV];
   uint16_t so[kChunkV];
 #pragma unroll
   for (int j = 0; j < kChunkV; ++j) {
     const int k = t + kChunkT * j;
-    sd[j] = MAP ? 0u : (a.carry_in ? a.carry_in[k] : 0u);
+    sd[j] = MAP ? 0u : (init ? init[k] : 0u);
     so[j] = (uint16_t)k;
     D[0][k] = sd[j];
     if constexpr (MAP) O[0][k] = so[j];
@@ -414,26 +495,26 @@ __global__ __launch_bounds__(kChunkT) void pv_lock_chunks(const PvArgs a, int64_
   uint16_t no[kChunkV];
 #pragma unroll
   for (int j = 0; j < kChunkV; ++j) {
-    nd[j] = nchunks > 0 ? a.chunk_sums[t + kChunkT * j] : 0u;
-    no[j] = nchunks > 0 ? a.chunk_org[t + kChunkT * j] : kPvNoBin;
+    nd[j] = cnt > 0 ? sums[t + kChunkT * j] : 0u;
+    no[j] = cnt > 0 ? org[t + kChunkT * j] : kPvNoBin;
   }
-  for (int64_t c = 0; c < nchunks; ++c) {
+  for (int64_t c = 0; c < cnt; ++c) {
     __syncthreads();
     uint32_t cd[kChunkV];
     uint16_t co[kChunkV];
 #pragma unroll
     for (int j = 0; j < kChunkV; ++j) { cd[j] = nd[j]; co[j] = no[j]; }
-    if (c + 1 < nchunks) {
+    if (c + 1 < cnt) {
 #pragma unroll
       for (int j = 0; j < kChunkV; ++j) {
-        nd[j] = a.chunk_sums[(c + 1) * kPvM + t + kChunkT * j];
-        no[j] = a.chunk_org[(c + 1) * kPvM + t + kChunkT * j];
+        nd[j] = sums[(c + 1) * kPvM + t + kChunkT * j];
+        no[j] = org[(c + 1) * kPvM + t + kChunkT * j];
       }
     }
 #pragma unroll
     for (int j = 0; j < kChunkV; ++j) {
       const int k = t + kChunkT * j;
-      if constexpr (!MAP) a.chunk_sums[c * kPvM + k] = sd[j];  // the phases this chunk starts from
+      if constexpr (!MAP) sums[c * kPvM + k] = sd[j];  // the offsets this map starts from
       if (co[j] == kPvNoBin) {
         sd[j] = cd[j];
         so[j] = kPvNoBin;
@@ -449,8 +530,8 @@ __global__ __launch_bounds__(kChunkT) void pv_lock_chunks(const PvArgs a, int64_
   if constexpr (MAP) {
 #pragma unroll
     for (int j = 0; j < kChunkV; ++j) {
-      a.tot_sums[t + kChunkT * j] = sd[j];
-      a.tot_org[t + kChunkT * j] = so[j];
+      out_sums[(int64_t)blockIdx.x * kPvM + t + kChunkT * j] = sd[j];
+      out_org[(int64_t)blockIdx.x * kPvM + t + kChunkT * j] = so[j];
     }
   }
 }
@@ -497,7 +578,7 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   // G = 2^lg lanes (as many as the frame's peak count leaves: a sweep's handful of peaks are 65-bin intervals, music's
   // hundreds are short).  The first round's records arrive as arguments (requested a frame earlier).
   auto lanes_per_peak = [](int cnt) { return cnt <= 8 ? 4 : cnt <= 16 ? 3 : cnt <= 32 ? 2 : cnt <= 64 ? 1 : 0; };
-  auto fill_cd = [&](int64_t fr, int cnt, int tt, uint32_t r_m, uint32_t r_i, uint32_t r_n, uint32_t cv) {
+  auto fill_cd = [&](int64_t fr, int cnt, int tt, uint32_t r_i, uint32_t cv) {
     const int lg = lanes_per_peak(cnt), G = 1 << lg, sub = tt & (G - 1);
     const uint2 *rrow = a.recs + (size_t)fr * P::M;
     const uint32_t *crow = a.cvals + (size_t)fr * P::M;
@@ -505,14 +586,13 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     for (int i = tt >> lg; i < cnt; i += P::T >> lg) {
       if (!first) {
         r_i = rrow[i].x;
-        r_m = i > 0 ? rrow[i - 1].x : 0u;
-        r_n = i + 1 < cnt ? rrow[i + 1].x : 0u;
         cv = crow[i];
       }
       first = false;
       if (!(r_i & kRecCont) || cv == 0u) continue;  // restarted (or an offset of exactly 0): nothing to write
+      // (the neighbours' bins: L2 hits, read only by the lanes that have something to write)
       const int p = (int)(r_i & 2047u);
-      const int pm = i > 0 ? (int)(r_m & 2047u) : -(1 << 14), pn = i + 1 < cnt ? (int)(r_n & 2047u) : (1 << 14);
+      const int pm = i > 0 ? (int)(rrow[i - 1].x & 2047u) : -(1 << 14), pn = i + 1 < cnt ? (int)(rrow[i + 1].x & 2047u) : (1 << 14);
       int lo = ((pm + p) >> 1) + 1, hi = (p + pn) >> 1;  // (pm + p may be negative: arithmetic shift = floor)
       lo = lo < p - kPvReach ? p - kPvReach : lo;
       hi = hi > p + kPvReach ? p + kPvReach : hi;
@@ -521,14 +601,11 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       for (int k = lo + sub; k <= hi; k += G) cd[k] = cv;
     }
   };
-  auto fetch_fill = [&](int64_t fr, int cnt, int tt, uint32_t &r_m, uint32_t &r_i, uint32_t &r_n, uint32_t &cv) {
+  auto fetch_fill = [&](int64_t fr, int cnt, int tt, uint32_t &r_i, uint32_t &cv) {
     const int i = tt >> lanes_per_peak(cnt);
-    const uint2 *rrow = a.recs + (size_t)fr * P::M;
-    r_m = r_i = r_n = cv = 0u;
+    r_i = cv = 0u;
     if (i < cnt) {
-      r_i = rrow[i].x;
-      r_m = i > 0 ? rrow[i - 1].x : 0u;
-      r_n = i + 1 < cnt ? rrow[i + 1].x : 0u;
+      r_i = a.recs[(size_t)fr * P::M + i].x;
       cv = a.cvals[(size_t)fr * P::M + i];
     }
   };
@@ -551,16 +628,21 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       rx[2 * e + 1] = xrow[cm];
     }
   };
-  int cnt1 = 0, cnt2 = 0;  // peak counts of frames f + 1, f + 2
+  // (peak counts of frames f + 1, f + 2: loaded through an index the compiler cannot prove uniform, so that they stay in
+  // vector registers — as wave-uniform values hipcc moves them to a scalar register the moment they are requested, behind
+  // an s_waitcnt vmcnt(0) at the top of every frame)
+  int lane0;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
+  int cnt1 = 0, cnt2 = 0;
   if (f0 < f1) {
     fetch_rows(f0, t_);
     zero_cd(t_);
-    uint32_t r_m, r_i, r_n, cv;
+    uint32_t r_i, cv;
     const int cnt0 = (int)a.pkcount[f0];
-    fetch_fill(f0, cnt0, t_, r_m, r_i, r_n, cv);
-    cnt1 = f0 + 1 < f1 ? (int)a.pkcount[f0 + 1] : 0;
+    fetch_fill(f0, cnt0, t_, r_i, cv);
+    cnt1 = f0 + 1 < f1 ? (int)a.pkcount[f0 + 1 + lane0] : 0;
     __syncthreads();
-    fill_cd(f0, cnt0, t_, r_m, r_i, r_n, cv);
+    fill_cd(f0, cnt0, t_, r_i, cv);
     __syncthreads();
   }
   const cpx wbase0 = a.wsplit[t_];  // e^{+2 pi i t/N}
@@ -591,9 +673,9 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     cpx wbase = wbase0;
     asm volatile("" : "+v"(wbase.x), "+v"(wbase.y));
     // the next frame's first round of records (its count came a frame ago) and the count of the frame after it
-    uint32_t nr_m, nr_i, nr_n, ncv;
-    fetch_fill(f + 1 < f1 ? f + 1 : f, cnt1, t, nr_m, nr_i, nr_n, ncv);
-    cnt2 = f + 2 < f1 ? (int)a.pkcount[f + 2] : 0;
+    uint32_t nr_i, ncv;
+    fetch_fill(f + 1 < f1 ? f + 1 : f, cnt1, t, nr_i, ncv);
+    cnt2 = f + 2 < f1 ? (int)a.pkcount[f + 2 + lane0] : 0;
     cpx Y[P::E], v[P::E];
     uint32_t cc[2 * P::E];  // (one batch of LDS reads in front of the wave-uniform branches below, not one wait per branch)
 #pragma unroll
@@ -656,7 +738,7 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
     store_t2<P>(t, v, lds);
     // (here, not right behind the zeroing barrier: the records requested at the top of the frame have had two passes to arrive)
-    if (f + 1 < f1) fill_cd(f + 1, cnt1, t, nr_m, nr_i, nr_n, ncv);
+    if (f + 1 < f1) fill_cd(f + 1, cnt1, t, nr_i, ncv);
     cnt1 = cnt2;
     __syncthreads();
     load_t2<P>(t, v, lds);
@@ -813,6 +895,15 @@ hipError_t launch_pv_plan_const(int64_t *apos, uint32_t *hop, double *hratio, in
 // Stage 1: analysis rows and this rank's phase totals.  Stage 2: carries (from carry_in), synthesis phases, synthesis
 // with the overlap-add ring (afterwards halo[0 .. N-Hs) is this rank's head seam and s[(frames-first)*Hs ..) its
 // tail seam, both raw).  Stage 3: boundary fix-up (with the neighbours' seams) and resampling.
+namespace {
+// the group maps of the chunk maps (chunk_sums / chunk_org stay as they are)
+void launch_group_maps(const PvArgs &a, int64_t nchunks, hipStream_t s) {
+  const unsigned G = (unsigned)((nchunks + kPvGroup - 1) / kPvGroup);
+  hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(G), dim3(kChunkT), 0, s, a.chunk_sums, a.chunk_org, nchunks, kPvGroup,
+                     (const uint32_t *)nullptr, 0, a.group_sums, a.group_org);
+}
+}  // namespace
+
 hipError_t launch_pv_analyze(const PvArgs &a0, hipStream_t s) {
   PvArgs a = a0;
   if (a.frames - a.first <= 0) return hipSuccess;
@@ -821,13 +912,25 @@ hipError_t launch_pv_analyze(const PvArgs &a0, hipStream_t s) {
   const int64_t nchunks = pv_chunks(a);
   hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
   hipLaunchKernelGGL(pv_lock_walk<false>, dim3((unsigned)nchunks), dim3(kLockT), 0, s, a);
-  if (a.tot_sums) hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(1), dim3(kChunkT), 0, s, a, nchunks);
+  if (a.tot_sums) {  // this rank's total map: the composition of its group maps
+    launch_group_maps(a, nchunks, s);
+    const int64_t G = (nchunks + kPvGroup - 1) / kPvGroup;
+    hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(1), dim3(kChunkT), 0, s, a.group_sums, a.group_org, G, (int)G,
+                       (const uint32_t *)nullptr, 0, a.tot_sums, a.tot_org);
+  }
   return hipGetLastError();
 }
 hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
   const int64_t nchunks = pv_chunks(a);
-  hipLaunchKernelGGL(pv_lock_chunks<false>, dim3(1), dim3(kChunkT), 0, s, a, nchunks);
+  const int64_t G = (nchunks + kPvGroup - 1) / kPvGroup;
+  launch_group_maps(a, nchunks, s);
+  // the offsets every group starts from (they replace the group maps' delta rows) ...
+  hipLaunchKernelGGL(pv_lock_chunks<false>, dim3(1), dim3(kChunkT), 0, s, a.group_sums, a.group_org, G, (int)G, a.carry_in, 0,
+                     (uint32_t *)nullptr, (uint16_t *)nullptr);
+  // ... and, from those, the offsets every chunk starts from
+  hipLaunchKernelGGL(pv_lock_chunks<false>, dim3((unsigned)G), dim3(kChunkT), 0, s, a.chunk_sums, a.chunk_org, nchunks, kPvGroup,
+                     (const uint32_t *)a.group_sums, 1, (uint32_t *)nullptr, (uint16_t *)nullptr);
   hipLaunchKernelGGL(pv_lock_walk<true>, dim3((unsigned)nchunks), dim3(kLockT), 0, s, a);
   hipLaunchKernelGGL(pv_synthesis, dim3((unsigned)pv_blocks(a.frames - a.first)), dim3(PV::T), 0, s, a);
   return hipGetLastError();

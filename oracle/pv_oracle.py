@@ -42,6 +42,13 @@ and this file is the only oracle it can have.  The definition (N = 4096, Hs = 25
 The phase bookkeeping is integer (the one binary64 product is rounded identically everywhere) and each frame's
 update is a map k -> (source bin, delta) or a restart, so composing those maps in any grouping — a parallel
 scan over frames — gives exactly the serial result.
+
+How the product evaluates this definition (round 4; melonix_amd/csrc/pv_kernels.hip): with identity phase locking
+Phi_f[k] - P_f[k] = C_f[p] is one number per PEAK (p = the owner of k), so the synthesis coefficient
+|X_f[k]| e^{2 pi i Phi_f[k]/2^32} equals X_f[k] e^{2 pi i C_f[p]/2^32} up to the 2^-31-turn quantisation of P_f[k]
+(3e-9 rad).  The product therefore keeps phases at the peaks only — the same uint32 arithmetic as above on the same
+values — and rotates the complex analysis bins by their owner's phasor; bins without a continuing owner keep X_f[k]
+as it is.  This file stays the definition: the per-bin form below is what the tests compare against.
 """
 import numpy as np
 
