@@ -474,9 +474,19 @@ def main() -> None:
                 "resynth_kernel_ms": r_c, "conditioning_steps": args.conditioning,
                 "note": "the same W + K region after this many more untimed steps (clock / power settling); never `value`"}
 
-    # sanity: the last step produced a plausible pitch track (guards against a silently skipped kernel)
+    # The outputs of the last timed step, checked against what the workload is (the parity tests are the correctness
+    # proof; this guards the bench run itself against a skipped or mis-launched kernel): every pitch bin in the band, and —
+    # the signal is a linear sweep — within two bins of the sweep's instantaneous frequency at the frame's newest samples.
     bins = pitch_t[(args.steps - 1) & 1][:, 0].clone()
     ok = bool(((bins >= band[0]) & (bins <= band[1])).all().item())
+    h = torch.arange(F, device=dev, dtype=torch.float64)
+    newest = (rank * n + (h + 1.0) * hop - 0.5 * hop).clamp_(min=0.0)   # global sample index at the middle of the newest hop
+    f_inst = 110.0 + (1760.0 - 110.0) * newest / float(world * n)
+    want_bin = f_inst * N / SR
+    settled = h >= (N // hop)                                           # (frames that still reach before the signal's start aside)
+    bin_err = (bins.to(torch.float64) - want_bin).abs()[settled]
+    pitch_err = float(bin_err.max().item()) if bin_err.numel() else 0.0
+    ok = ok and pitch_err <= 2.5
     import hashlib
 
     # sha1 of this rank's pitch track after the last timed step (a sharded run's gathered track carries its own below:
@@ -498,10 +508,16 @@ def main() -> None:
                     "note": "per-rank pitch tracks (8 B/frame) stitched into the whole-signal track on RCCL's stream, "
                             "double-buffered against the next step's kernels"}
 
-    if rs is not None:  # the resynthesis leg produced a plausible PCM stream (guards against a skipped kernel)
+    pcm_rms = None
+    if rs is not None:  # the resynthesis leg: the terminating zeros, and a sweep of amplitude 0.5 has an rms of 0.5 / sqrt(2)
         tail_ok = not bool(rs["pcm"][-1500:].any().item())
         body = rs["pcm"][: rs["total"] - 1500]
-        ok = ok and tail_ok and bool((body != 0).any().item())
+        pcm_rms = float(body.to(torch.float32).pow(2).mean().sqrt().item() / 32767.0)
+        ok = ok and tail_ok and 0.33 <= pcm_rms <= 0.375
+    if use_dist:  # the line's outputs_ok is every rank's
+        okf = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        ok = bool(okf.item())
     supplementary = rank == 0 and world == 1 and not args.no_resynth and not args.no_supplementary
     host = audio_t[pad:pad + n].cpu().numpy() if supplementary else None
     # supplementary (SURVEY 8d timing protocol, second figure): end to end from a host buffer — H2D of the audio
@@ -741,6 +757,10 @@ def main() -> None:
             "stft_pitch_only": {"frames_per_s": world * F / (kern_ms * 1e-3), "kernel_ms": kern_ms},
             "pitch_track_sha1": local_track_sha1,
             "outputs_ok": ok,
+            "outputs_check": {"pitch_max_abs_bin_error_vs_sweep": pitch_err, "pcm_rms_full_scale": pcm_rms,
+                              "note": "every pitch bin in band and within 2.5 bins of the sweep's instantaneous frequency at the "
+                                      "frame's newest hop; int16 PCM rms within 0.33 .. 0.375 of full scale (0.5 / sqrt 2 = 0.354), "
+                                      "terminating zeros in place; MIN over ranks"},
         }
         if rs is not None:
             line["resynth_setup"] = {"grain_scan_s": rs["grain_scan_s"], "grain_scan_warm_s": rs["grain_scan_warm_s"],

@@ -126,6 +126,28 @@ def test_gpu_properties(gpu_ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("st", [3.0, -5.0])
+def test_gpu_impulse_train_every_bin_a_peak(gpu_ctx, pv, st):
+    """Impulses 4001 samples apart: at most one per frame, so a frame's spectrum is flat — every bin is its own peak (the
+    margin rho makes that robust in either precision: oracle header) — or, between impulses, silent, where every bin is a
+    peak as well.  2048 records per frame: the numbering beyond one wavefront's words, the walks' rows longer than a
+    workgroup, the synthesis fill with one lane per peak over sixteen rounds."""
+    n = 2 * SR
+    w = np.zeros(n, np.float32)
+    w[1000::4001] = 0.5
+    a = gpu_ctx.upload(w)
+    f32, i16 = gpu_ctx.pv_pitch_shift(a, st)
+    ref = pv.pitch_shift(w.astype(np.float64), st)
+    err = np.abs(f32 - ref)
+    # an impulse is all near-ties in time as well (which frame "has" it at its Hann-window edge): bounded like the noisy case
+    assert np.sqrt((err ** 2).mean()) < 2e-4 and err.max() < 2e-2, (float(np.sqrt((err ** 2).mean())), float(err.max()))
+    assert np.abs(f32).max() > 0.05 and np.array_equal(i16, (np.clip(f32, -1.0, 1.0).astype(np.float64) * 32767.0).astype(np.int16))
+    y2, _ = gpu_ctx.pv_pitch_shift(a, st)
+    assert np.array_equal(f32.view(np.uint32), y2.view(np.uint32))
+    a.free()
+
+
+@pytest.mark.gpu
 def test_gpu_noisy_input_close_to_oracle(gpu_ctx, pv):
     """Broadband input: every bin is active, so a wrap, an activity threshold or a peak decided differently by
     binary32 and binary64 rounding moves a noise bin (and, with phase locking, the few bins riding on it) — bounded
