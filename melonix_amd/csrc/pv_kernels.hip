@@ -557,22 +557,29 @@ __host__ __device__ constexpr int64_t pv_blocks(int64_t frames) {
 
 __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) void pv_synthesis(const PvArgs a) {
   using P = PV;
-  // 16 + 16 + 8 KiB: exactly a quarter of the CU's LDS (four workgroups = two waves per SIMD)
   __shared__ __attribute__((aligned(16))) float2 lds[t1_size<P>()];
-  __shared__ __attribute__((aligned(16))) float ring[P::N];  // overlap-add accumulator, stretched time mod N
   // cd[k]: the synthesis offset C of bin k's owner peak in the frame whose coefficients are formed next (0: the bin rides
   // on no peak, or on one that restarted — it keeps its analysis phase).  Written for frame f + 1 between the barriers of
   // frame f's transform (zeroed after the first, the peaks' intervals filled in after the second), so the lock costs the
   // walk no barrier of its own.
   __shared__ __attribute__((aligned(16))) uint32_t cd[P::M];
+  // the next frame's spectrum X (its row, in bin order): requested as LDS-DMA a whole frame ahead — no registers, 1 KiB per
+  // wavefront instruction — instead of 32 eight-byte loads per thread that sat in 64 registers through the last pass
+  __shared__ __attribute__((aligned(16))) float2 xbuf[P::M];
   const int t_ = threadIdx.x;
-  const bool wave0 = __builtin_amdgcn_readfirstlane(t_) < 64;
-  for (int i = t_; i < P::N; i += P::T) ring[i] = 0.f;
   const int64_t nb = pv_blocks(a.frames - a.first);
   const int64_t blk = blockIdx.x;
   const int64_t f0 = a.first + blk * kPvBlockFrames;  // local frame indices; s[0] belongs to local frame a.first
   const int64_t f1 = blk == nb - 1 ? a.frames : f0 + kPvBlockFrames;
-  float2 *ring2 = reinterpret_cast<float2 *>(ring);
+  // The overlap-add accumulator lives in registers.  The last pass runs on the columns t and t + NS3/2 (not the forward
+  // transform's t and NS3 - t: nothing is split afterwards), so this thread's sample pairs of a frame are m = t + T j,
+  // j = 0..15 — a set that a shift by one hop (T pairs) maps onto itself: pair j of frame f and pair j - 1 of frame f + 1
+  // are the same output samples.  acc[j]: the sum so far at this frame's pair j + 1; pair 0 leaves with every frame.
+  constexpr int kOla = P::N / kPvHs;  // 16 frames reach a sample
+  static_assert(kOla == 2 * P::R3 && kPvHs == 2 * P::T, "one hop = one sample pair per thread");
+  cpx acc[kOla - 1];
+#pragma unroll
+  for (int j = 0; j < kOla - 1; ++j) acc[j] = mk(0.f, 0.f);
   // Every continuing peak of frame `fr` claims its bins in cd: from the midpoint to its lower neighbour (a tie goes to
   // the lower peak) up to the midpoint to its upper neighbour, at most kPvReach either side.  A peak is served by
   // G = 2^lg lanes (as many as the frame's peak count leaves: a sweep's handful of peaks are 65-bin intervals, music's
@@ -614,20 +621,33 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
     for (int j = 0; j < P::M / 4 / P::T; ++j) reinterpret_cast<u32x4 *>(cd)[tt + P::T * j] = u32x4{0u, 0u, 0u, 0u};
   };
-  // This thread's 2 x 16 bins of a frame: c = t + T e and its mirror M - c (bin M, thread 0's mirror of c = 0, is the
-  // dropped Nyquist bin: the load is clamped and the coefficient zeroed).  The row of frame f + 1 is requested while
-  // frame f is in its last pass.
-  cpx rx[2 * P::E];
-  auto fetch_rows = [&](int64_t fr, int tt) {
-    const float2 *xrow = a.xrows + (size_t)fr * P::M;
+  // The row of frame fr -> xbuf: every wavefront moves 1 KiB per instruction (lane l: 16 bytes at l * 16 of the piece; the
+  // LDS side of an LDS-DMA load is wave-uniform base + lane * 16), 8 pieces each.  hipcc does not know of these loads: the
+  // wave that issued them waits (vmcnt(0)) in front of the barrier behind which anybody reads xbuf.
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t xbuf_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr(xbuf) + (uint32_t)(t_ >> 6) * 1024u));
+#else
+  const uint32_t xbuf_w = 0u;  // (the host pass only parses the kernel)
+#endif
+  auto request_row = [&](int64_t fr, int tt) {
+    const char *src = reinterpret_cast<const char *>(a.xrows + (size_t)fr * P::M) + (tt >> 6) * 1024 + (tt & 63) * 16;
 #pragma unroll
-    for (int e = 0; e < P::E; ++e) {
-      const int c = tt + P::T * e;
-      const int cm = (P::M - c) & (P::M - 1);  // (c = 0 -> 0: clamped)
-      rx[2 * e] = xrow[c];
-      rx[2 * e + 1] = xrow[cm];
+    for (int i = 0; i < P::M * 8 / (P::T * 16); ++i) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(src + i * (P::T * 16)), "s"(xbuf_w + (uint32_t)i * (P::T * 16))
+                   : "memory");
     }
   };
+  auto row_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  // this thread's window values at its sample pairs m = t + T j: registers for the whole walk
+  float2 hw[P::N / kPvHs];
+  {
+    const float2 *w2 = reinterpret_cast<const float2 *>(a.hann);
+#pragma unroll
+    for (int j = 0; j < P::N / kPvHs; ++j) hw[j] = w2[t_ + P::T * j];
+  }
   // (peak counts of frames f + 1, f + 2: loaded through an index the compiler cannot prove uniform, so that they stay in
   // vector registers — as wave-uniform values hipcc moves them to a scalar register the moment they are requested, behind
   // an s_waitcnt vmcnt(0) at the top of every frame)
@@ -635,7 +655,7 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
   int cnt1 = 0, cnt2 = 0;
   if (f0 < f1) {
-    fetch_rows(f0, t_);
+    request_row(f0, t_);
     zero_cd(t_);
     uint32_t r_i, cv;
     const int cnt0 = (int)a.pkcount[f0];
@@ -643,22 +663,25 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     cnt1 = f0 + 1 < f1 ? (int)a.pkcount[f0 + 1 + lane0] : 0;
     __syncthreads();
     fill_cd(f0, cnt0, t_, r_i, cv);
+    row_landed();
     __syncthreads();
   }
   const cpx wbase0 = a.wsplit[t_];  // e^{+2 pi i t/N}
   // The pass twiddles of this thread are powers of one root each: gamma^r (pass 2, r = 1..15) and delta^r (pass 3,
   // r = 1..7).  The powers 1, 2, 4 (, 8) stay in registers for the whole walk, the others are one packed product each per
   // frame: a table read per twiddle and frame — 22 L2 round trips in front of the two passes — was latency nothing hid.
-  cpx g2b[4], g3b[3];
+  cpx g2b[4], g3p[3], g3q[3];
   {
-    const int k = t_ & (P::R1 - 1), col = t_ ? t_ : P::NS3 / 2;
+    const int k = t_ & (P::R1 - 1);
     g2b[0] = a.tw2[0 * P::R1 + k];
     g2b[1] = a.tw2[1 * P::R1 + k];
     g2b[2] = a.tw2[3 * P::R1 + k];
     g2b[3] = a.tw2[7 * P::R1 + k];
-    g3b[0] = a.tw3[0 * P::NS3 + col];
-    g3b[1] = a.tw3[1 * P::NS3 + col];
-    g3b[2] = a.tw3[3 * P::NS3 + col];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      g3p[i] = a.tw3[((1 << i) - 1) * P::NS3 + t_];
+      g3q[i] = a.tw3[((1 << i) - 1) * P::NS3 + t_ + P::NS3 / 2];
+    }
   }
   for (int64_t f = f0; f < f1; ++f) {
     // LICM may keep this thread's window and split twiddles in registers for the whole walk (twice as fast as
@@ -666,8 +689,6 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int t = t_;
     int zoff = 0;
     asm volatile("" : "+s"(zoff));
-    const float2 *w2 = reinterpret_cast<const float2 *>(a.hann);
-    const int kp = k0p<P>(t), kq = k0q<P>(t);
     // (the sixteen products wbase * e^{2 pi i e/32} are rebuilt per frame: hoisted out of the walk they cost 32 registers and
     // the kernel spills — 15.3 against 13.9 ms per hour)
     cpx wbase = wbase0;
@@ -677,12 +698,18 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     fetch_fill(f + 1 < f1 ? f + 1 : f, cnt1, t, nr_i, ncv);
     cnt2 = f + 2 < f1 ? (int)a.pkcount[f + 2 + lane0] : 0;
     cpx Y[P::E], v[P::E];
+    // This thread's 2 x 16 bins of the frame: c = t + T e and its mirror M - c (bin M, thread 0's mirror of c = 0, is the
+    // dropped Nyquist bin: the read is clamped and the coefficient zeroed), and their offsets
+    cpx rx[2 * P::E];
     uint32_t cc[2 * P::E];  // (one batch of LDS reads in front of the wave-uniform branches below, not one wait per branch)
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       const int c = t + P::T * e;
+      const int cm = (P::M - c) & (P::M - 1);  // (c = 0 -> 0: clamped)
+      rx[2 * e] = xbuf[c];
+      rx[2 * e + 1] = xbuf[cm];
       cc[2 * e] = cd[c];
-      cc[2 * e + 1] = cd[(P::M - c) & (P::M - 1)];
+      cc[2 * e + 1] = cd[cm];
     }
     // Yhat[k] = X[k] e^{2 pi i C/2^32}, C the offset of the bin's owner (0: the bin keeps its analysis phase — most bins of
     // most frames: a wavefront whose bins of four slots all ride on nothing skips their phasors; multiplying by the phasor
@@ -714,7 +741,8 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       Y[e] = mk(Sm.x - wd.y, -(Sm.y + wd.x));      // conj((A+B) + i*wd)
     }
     pass1<P>(Y, v);
-    __syncthreads();  // (the previous frame's hop has left the ring; every wave has read this frame's offsets)
+    __syncthreads();  // (every wave has read this frame's row and offsets, and its T2 columns of the previous frame)
+    if (f + 1 < f1) request_row(f + 1, t);
     store_t1<P>(t, v, lds);
     zero_cd(t);
     __syncthreads();
@@ -740,62 +768,65 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // (here, not right behind the zeroing barrier: the records requested at the top of the frame have had two passes to arrive)
     if (f + 1 < f1) fill_cd(f + 1, cnt1, t, nr_i, ncv);
     cnt1 = cnt2;
+    row_landed();  // (requested three barriers ago)
     __syncthreads();
-    load_t2<P>(t, v, lds);
-    cpx w3[P::R3 - 1];
-    int tl = t_;
-    asm volatile("" : "+v"(tl));  // (or the 64 row offsets are kept in registers for the whole walk)
-    if (f + 1 < f1) fetch_rows(f + 1, tl);
-    {
-      cpx d1 = g3b[0];
-      asm volatile("" : "+v"(d1.x), "+v"(d1.y));
-      w3[0] = d1;
-      w3[1] = g3b[1];
-      w3[3] = g3b[2];
-      w3[2] = pk_cmul2(g3b[1], d1);
-      w3[4] = pk_cmul2(g3b[2], d1);
-      w3[5] = pk_cmul2(g3b[2], g3b[1]);
-      w3[6] = pk_cmul2(g3b[2], w3[2]);
-    }
-    if (wave0) pass3_reg<P, true>(t, v, w3);
-    else pass3_reg<P, false>(t, v, w3);
-    // v[r] = D[k0p + NS3 r], v[q_index(r)] = D[k0q + NS3 r]; sample pair m: y[2m] = Re D[m], y[2m+1] = -Im D[m].
-    // Pair m of frame f sits at stretched sample f*Hs + 2m: ring slot (g*Hs/2 + m) mod M, g = f - f0.  Every slot
-    // is touched by exactly one thread per frame.
-    const int g2 = (int)(((f - f0) * (kPvHs / 2)) & (P::M - 1));
+    // columns t (v[0..R3)) and t + NS3/2 (v[R3..E)) of the T2 image
 #pragma unroll
     for (int r = 0; r < P::R3; ++r) {
-      const int mp = kp + P::NS3 * r, mq = kq + P::NS3 * r;
-      const cpx dp = v[r], dq = v[q_index<P>(r)];
-      const float2 hp = w2[mp], hq = w2[mq];
-      float2 *sp = ring2 + ((g2 + mp) & (P::M - 1)), *sq = ring2 + ((g2 + mq) & (P::M - 1));
-      const float2 op = *sp, oq = *sq;
-      *sp = make_float2(op.x + dp.x * hp.x, op.y - dp.y * hp.y);
-      *sq = make_float2(oq.x + dq.x * hq.x, oq.y - dq.y * hq.y);
+      v[r] = lds[t + P::NS3 * r];
+      v[P::R3 + r] = lds[t + P::NS3 / 2 + P::NS3 * r];
     }
-    __syncthreads();
+    // pass 3 on both columns: twiddles delta^r, delta = e^{-2 pi i col/M}, from the bases delta^1, delta^2, delta^4
+    auto pass3_col = [&](const cpx (&gb)[3], int o) {
+      cpx d1 = gb[0];
+      asm volatile("" : "+v"(d1.x), "+v"(d1.y));  // (the products are not hoisted out of the walk)
+      cpx in[P::R3], w[P::R3], out[P::R3];
+      w[0] = mk(1.0f, 0.0f);
+      w[1] = d1;
+      w[2] = gb[1];
+      w[4] = gb[2];
+      w[3] = pk_cmul2(gb[1], d1);
+      w[5] = pk_cmul2(gb[2], d1);
+      w[6] = pk_cmul2(gb[2], gb[1]);
+      w[7] = pk_cmul2(gb[2], w[3]);
+#pragma unroll
+      for (int r = 0; r < P::R3; ++r) in[r] = v[o + r];
+      DftTw<P::R3, 1, 0, false>::run(in, w, out);
+#pragma unroll
+      for (int r = 0; r < P::R3; ++r) v[o + r] = out[r];
+    };
+    pass3_col(g3p, 0);
+    pass3_col(g3q, P::R3);
+    // v[r] = D[t + NS3 r], v[R3 + r] = D[t + NS3/2 + NS3 r]: pair m = t + T j is v[j / 2] (j even), v[R3 + j / 2] (j odd);
+    // y[2m] = Re D[m], y[2m+1] = -Im D[m], windowed, added to what the earlier frames left at the same samples (in frame
+    // order: the sums group exactly as they did in the LDS ring of rounds 1-3)
+    cpx hopv = mk(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < kOla; ++j) {
+      const cpx d = (j & 1) ? v[P::R3 + (j >> 1)] : v[j >> 1];
+      const float2 h = hw[j];
+      const cpx old = j < kOla - 1 ? acc[j] : mk(0.f, 0.f);
+      const cpx sum = mk(old.x + d.x * h.x, old.y - d.y * h.y);
+      if (j == 0) hopv = sum;
+      else acc[j - 1] = sum;
+    }
     // the hop [f*Hs, (f+1)*Hs) has now received every frame of this workgroup that reaches it
     {
-      float2 *slot = ring2 + ((g2 + t) & (P::M - 1));
-      const float2 accv = *slot;
-      *slot = make_float2(0.f, 0.f);
       // all 16 contributors are this workgroup's (or there are none before the signal's first frame)
       const bool final_here = (f - f0 >= kPvN / kPvHs - 1) || (blk == 0 && a.global_first);
       if (final_here) {
-        reinterpret_cast<float2 *>(a.s + (f - a.first) * kPvHs)[t] = make_float2(accv.x * kPvNorm, accv.y * kPvNorm);
+        reinterpret_cast<float2 *>(a.s + (f - a.first) * kPvHs)[t] = make_float2(hopv.x * kPvNorm, hopv.y * kPvNorm);
       } else {
-        reinterpret_cast<float2 *>(a.halo + (size_t)blk * kPvHalo + (f - f0) * kPvHs)[t] = accv;
+        reinterpret_cast<float2 *>(a.halo + (size_t)blk * kPvHalo + (f - f0) * kPvHs)[t] = make_float2(hopv.x, hopv.y);
       }
     }
   }
-  // what is left in the ring: this workgroup's share of the N - Hs samples after its last hop (raw sums; pv_fixup
+  // what is left in the accumulator: this workgroup's share of the N - Hs samples after its last hop (raw sums; pv_fixup
   // adds the next workgroup's halo and normalises)
-  __syncthreads();
-  {
-    const int g2 = (int)(((f1 - f0) * (kPvHs / 2)) & (P::M - 1));
-    for (int i = t_; i < kPvHalo / 2; i += P::T)
-      reinterpret_cast<float2 *>(a.s + (f1 - a.first) * kPvHs)[i] = ring2[(g2 + i) & (P::M - 1)];
-  }
+  static_assert(kPvHalo / 2 == (kOla - 1) * P::T, "the accumulator is the halo");
+#pragma unroll
+  for (int j = 0; j < kOla - 1; ++j)
+    reinterpret_cast<float2 *>(a.s + (f1 - a.first) * kPvHs)[t_ + P::T * j] = make_float2(acc[j].x, acc[j].y);
 }
 
 // Boundary b (0..nb): s over [f0_b*Hs, f0_b*Hs + N - Hs) holds the left workgroup's raw sums (none at b = 0); add the
