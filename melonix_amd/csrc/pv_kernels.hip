@@ -135,7 +135,9 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   __shared__ __attribute__((aligned(16))) float2 lds[P::M];
   __shared__ __attribute__((aligned(16))) float2 ltw2[kTw2];
   __shared__ uint32_t pkb[3][W + 2];  // the peak maps of frames f, f-1, f-2 (by frame mod 3), a zero word either side
-  __shared__ uint16_t plist[P::M];    // the peak bins of the frame whose records are pending, ascending
+  // the peak bins of a frame, ascending (by frame parity: the first wavefront lists frame f's while the second is still
+  // making frame f - 1's records from the other list)
+  __shared__ uint16_t plist[2][P::M];
   __shared__ float red[2][2];         // per wavefront: the largest squared magnitude (alternating frames)
   __shared__ uint32_t npk;
   const int t_ = threadIdx.x;
@@ -169,13 +171,16 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   const int64_t fw = f0 > 0 ? f0 - 1 : 0;
   cpx xr[P::E];
   load_raw<P, false>(t_, xr, a.audio + MX_AUDIO_PAD + (a.apos[fw] - P::N / 2));
+  // this thread's window values: registers for the whole walk (the kernel runs two waves per SIMD either way; reloaded per
+  // frame they were sixteen L1 round trips at the top of every transform)
+  cpx hwin[P::E];
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) hwin[e] = ld_pair<true>(a.hann_scaled, 2 * (t_ + P::T * e));
   __syncthreads();
 
   // The record of one peak of frame fr (p: its bin; xc, xq: X_fr[p], X_{fr-1}[p]; pkq: the peak map of frame fr - 1;
   // thrq: that frame's activity threshold)
-  auto make_record = [&](int64_t fr, int p, float2 xc, float2 xq, const uint32_t *pkq, float thrq, bool prev_exists) {
-    const uint32_t h = a.hop[fr];
-    const double hr = a.hratio[fr];
+  auto make_record = [&](uint32_t h, double hr, int p, float2 xc, float2 xq, const uint32_t *pkq, float thrq, bool prev_exists) {
     const uint32_t pc_ = to_turns(xc.x, xc.y), pp_ = to_turns(xq.x, xq.y);
     const bool cont = prev_exists && h >= 1 && cnorm2(xq) >= thrq;
     const int q = pv_owner(pkq, p);
@@ -193,20 +198,27 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   for (int64_t f = fw; f < f1; ++f) {
     // as in stft_kernel: re-materialise the thread index and a zero table offset per frame, or LICM hoists every
     // frame-invariant table value and address out of the loop
-    int t = t_, zoff = 0;
-    asm volatile("" : "+v"(t), "+s"(zoff));
+    int t = t_;
+    asm volatile("" : "+v"(t));
     const bool emit = f >= f0;  // (block-uniform)
+    // the pending frame's hop and stretch factor (scalar loads: requested here they return under pass 1)
+    const uint32_t ph = a.hop[f > 0 ? f - 1 : 0];
+    const double phr = a.hratio[f > 0 ? f - 1 : 0];
     const int m1 = m0 == 0 ? 2 : m0 - 1, m2 = m1 == 0 ? 2 : m1 - 1;  // maps of frames f-1, f-2
     cpx Y[P::E], v[P::E];
-    apply_window<P, 1, true>(t, Y, xr, a.hann_scaled + zoff);
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) Y[e] = pk_mul(xr[e], hwin[e]);
     pass1<P>(Y, v);
     __syncthreads();  // every wave is past the previous frame's peak numbering: plist and npk are complete
     if (pend) pend_cnt = (int)npk;
     // the pending frame's (f - 1) first record per thread: its spectrum and the one before at the peak, from their rows
     float2 ga = make_float2(0.f, 0.f), gb = make_float2(0.f, 0.f);
     int gp = 0;
-    if (pend && t < pend_cnt) {
-      gp = plist[t];
+    // (records are the second wavefront's first: the first one numbers the frame's peaks meanwhile)
+    const int ti = (t + P::T / 2) & (P::T - 1);
+    const uint16_t *pl_pend = plist[(f + 1) & 1];  // frame f - 1's list
+    if (pend && ti < pend_cnt) {
+      gp = pl_pend[ti];
       ga = a.xrows[(size_t)(f - 1) * P::M + gp];
       if (f >= 2) gb = a.xrows[(size_t)(f - 2) * P::M + gp];
     }
@@ -286,28 +298,30 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       uint32_t nib = 0;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
+        // c >= rho^2 v for each of the four neighbours <=> c >= rho^2 max(v): rounding is monotone, the decisions are the
+        // same ones bit for bit (and a bin outside the row, -1, never wins the maximum over a squared magnitude)
         const float c = v8[b + 2];
-        const bool pk = c >= thr2 && c >= kPvPeakMargin2 * v8[b + 1] && c >= kPvPeakMargin2 * v8[b] &&
-                        c >= kPvPeakMargin2 * v8[b + 3] && c >= kPvPeakMargin2 * v8[b + 4];
+        const float nb4 = __builtin_fmaxf(__builtin_fmaxf(v8[b], v8[b + 1]), __builtin_fmaxf(v8[b + 3], v8[b + 4]));
+        const bool pk = c >= __builtin_fmaxf(thr2, kPvPeakMargin2 * nb4);
         nib |= pk ? (1u << b) : 0u;
       }
       if (nib) atomicOr(&pkb[m0][1 + (j >> 3)], nib << (4 * (j & 7)));
     }
+    __syncthreads();  // this frame's peak map is complete
     // the pending frame's records (one per thread from the registers; a frame with more peaks than threads gathers the
-    // rest here), before this frame's peaks take the list over
+    // rest here): the second wavefront's lanes first — the first one has this frame's peaks to number
     if (pend) {
       uint2 *rrow = a.recs + (size_t)(f - 1) * P::M;
       const float2 *xa = a.xrows + (size_t)(f - 1) * P::M, *xb = a.xrows + (size_t)(f >= 2 ? f - 2 : 0) * P::M;
-      for (int i = t; i < pend_cnt; i += P::T) {
-        if (i != t) {
-          gp = plist[i];
+      for (int i = ti; i < pend_cnt; i += P::T) {
+        if (i != ti) {
+          gp = pl_pend[i];
           ga = xa[gp];
           gb = f >= 2 ? xb[gp] : make_float2(0.f, 0.f);
         }
-        rrow[i] = make_record(f - 1, gp, ga, gb, &pkb[m2][1], thr2_2, f >= 2);
+        rrow[i] = make_record(ph, phr, gp, ga, gb, &pkb[m2][1], thr2_2, f >= 2);
       }
     }
-    __syncthreads();
     // the first wavefront numbers this frame's peaks (exclusive scan of the words' populations through the DPP crossbar)
     // and lists their bins in ascending order
     if (wave0) {
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       while (rest) {
         const int b = __builtin_ctz(rest);
         rest &= rest - 1;
-        plist[r++] = (uint16_t)(32 * t + b);
+        plist[f & 1][r++] = (uint16_t)(32 * t + b);
       }
       if (emit) {
         a.pkmap[(size_t)f * W + t] = w;
@@ -341,9 +355,11 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     const int m1 = m0 == 0 ? 2 : m0 - 1, m2 = m1 == 0 ? 2 : m1 - 1;  // m1: frame fl's map, m2: frame fl - 1's
     uint2 *rrow = a.recs + (size_t)fl * P::M;
     const float2 *xa = a.xrows + (size_t)fl * P::M, *xb = a.xrows + (size_t)(fl >= 1 ? fl - 1 : 0) * P::M;
+    const uint32_t lh = a.hop[fl];
+    const double lhr = a.hratio[fl];
     for (int i = t_; i < pend_cnt; i += P::T) {
-      const int p = plist[i];
-      rrow[i] = make_record(fl, p, xa[p], fl >= 1 ? xb[p] : make_float2(0.f, 0.f), &pkb[m2][1], thr2_2, fl >= 1);
+      const int p = plist[fl & 1][i];
+      rrow[i] = make_record(lh, lhr, p, xa[p], fl >= 1 ? xb[p] : make_float2(0.f, 0.f), &pkb[m2][1], thr2_2, fl >= 1);
     }
   }
 }
@@ -585,7 +601,7 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   // G = 2^lg lanes (as many as the frame's peak count leaves: a sweep's handful of peaks are 65-bin intervals, music's
   // hundreds are short).  The first round's records arrive as arguments (requested a frame earlier).
   auto lanes_per_peak = [](int cnt) { return cnt <= 8 ? 4 : cnt <= 16 ? 3 : cnt <= 32 ? 2 : cnt <= 64 ? 1 : 0; };
-  auto fill_cd = [&](int64_t fr, int cnt, int tt, uint32_t r_i, uint32_t cv) {
+  auto fill_cd = [&](int64_t fr, int cnt, int tt, uint32_t r_i, uint32_t cv, uint32_t r_m, uint32_t r_n) {
     const int lg = lanes_per_peak(cnt), G = 1 << lg, sub = tt & (G - 1);
     const uint2 *rrow = a.recs + (size_t)fr * P::M;
     const uint32_t *crow = a.cvals + (size_t)fr * P::M;
@@ -594,12 +610,13 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       if (!first) {
         r_i = rrow[i].x;
         cv = crow[i];
+        r_m = i > 0 ? rrow[i - 1].x : 0u;
+        r_n = i + 1 < cnt ? rrow[i + 1].x : 0u;
       }
       first = false;
       if (!(r_i & kRecCont) || cv == 0u) continue;  // restarted (or an offset of exactly 0): nothing to write
-      // (the neighbours' bins: L2 hits, read only by the lanes that have something to write)
       const int p = (int)(r_i & 2047u);
-      const int pm = i > 0 ? (int)(rrow[i - 1].x & 2047u) : -(1 << 14), pn = i + 1 < cnt ? (int)(rrow[i + 1].x & 2047u) : (1 << 14);
+      const int pm = i > 0 ? (int)(r_m & 2047u) : -(1 << 14), pn = i + 1 < cnt ? (int)(r_n & 2047u) : (1 << 14);
       int lo = ((pm + p) >> 1) + 1, hi = (p + pn) >> 1;  // (pm + p may be negative: arithmetic shift = floor)
       lo = lo < p - kPvReach ? p - kPvReach : lo;
       hi = hi > p + kPvReach ? p + kPvReach : hi;
@@ -608,12 +625,17 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       for (int k = lo + sub; k <= hi; k += G) cd[k] = cv;
     }
   };
-  auto fetch_fill = [&](int64_t fr, int cnt, int tt, uint32_t &r_i, uint32_t &cv) {
+  // (a peak's record, its offset and its neighbours' records — their bins bound its interval —: all requested a frame ahead;
+  // read when the interval is written they were L2 round trips in front of a barrier the other wavefront was waiting at)
+  auto fetch_fill = [&](int64_t fr, int cnt, int tt, uint32_t &r_i, uint32_t &cv, uint32_t &r_m, uint32_t &r_n) {
     const int i = tt >> lanes_per_peak(cnt);
-    r_i = cv = 0u;
+    r_i = cv = r_m = r_n = 0u;
     if (i < cnt) {
-      r_i = a.recs[(size_t)fr * P::M + i].x;
+      const uint2 *rrow = a.recs + (size_t)fr * P::M;
+      r_i = rrow[i].x;
       cv = a.cvals[(size_t)fr * P::M + i];
+      if (i > 0) r_m = rrow[i - 1].x;
+      if (i + 1 < cnt) r_n = rrow[i + 1].x;
     }
   };
   auto zero_cd = [&](int tt) {
@@ -657,12 +679,12 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   if (f0 < f1) {
     request_row(f0, t_);
     zero_cd(t_);
-    uint32_t r_i, cv;
+    uint32_t r_i, cv, r_m, r_n;
     const int cnt0 = (int)a.pkcount[f0];
-    fetch_fill(f0, cnt0, t_, r_i, cv);
+    fetch_fill(f0, cnt0, t_, r_i, cv, r_m, r_n);
     cnt1 = f0 + 1 < f1 ? (int)a.pkcount[f0 + 1 + lane0] : 0;
     __syncthreads();
-    fill_cd(f0, cnt0, t_, r_i, cv);
+    fill_cd(f0, cnt0, t_, r_i, cv, r_m, r_n);
     row_landed();
     __syncthreads();
   }
@@ -684,18 +706,14 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
   }
   for (int64_t f = f0; f < f1; ++f) {
-    // LICM may keep this thread's window and split twiddles in registers for the whole walk (twice as fast as
-    // reloading them per frame), but not the pass twiddles as well: those would push the kernel past 256 VGPRs
     const int t = t_;
-    int zoff = 0;
-    asm volatile("" : "+s"(zoff));
     // (the sixteen products wbase * e^{2 pi i e/32} are rebuilt per frame: hoisted out of the walk they cost 32 registers and
     // the kernel spills — 15.3 against 13.9 ms per hour)
     cpx wbase = wbase0;
     asm volatile("" : "+v"(wbase.x), "+v"(wbase.y));
     // the next frame's first round of records (its count came a frame ago) and the count of the frame after it
-    uint32_t nr_i, ncv;
-    fetch_fill(f + 1 < f1 ? f + 1 : f, cnt1, t, nr_i, ncv);
+    uint32_t nr_i, ncv, nr_m, nr_n;
+    fetch_fill(f + 1 < f1 ? f + 1 : f, cnt1, t, nr_i, ncv, nr_m, nr_n);
     cnt2 = f + 2 < f1 ? (int)a.pkcount[f + 2 + lane0] : 0;
     cpx Y[P::E], v[P::E];
     // This thread's 2 x 16 bins of the frame: c = t + T e and its mirror M - c (bin M, thread 0's mirror of c = 0, is the
@@ -766,7 +784,7 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
     store_t2<P>(t, v, lds);
     // (here, not right behind the zeroing barrier: the records requested at the top of the frame have had two passes to arrive)
-    if (f + 1 < f1) fill_cd(f + 1, cnt1, t, nr_i, ncv);
+    if (f + 1 < f1) fill_cd(f + 1, cnt1, t, nr_i, ncv, nr_m, nr_n);
     cnt1 = cnt2;
     row_landed();  // (requested three barriers ago)
     __syncthreads();

@@ -19,9 +19,9 @@ VARIANT = os.path.join(ROOT, "melonix_amd", "lib", "variants", "timeline_pv.so")
 
 ANALYSIS = ["window + pass 1", "barrier", "gathers issued, T1 scatter", "barrier", "T1 gather + twiddles", "barrier", "pass 2 + T2 scatter",
             "barrier", "T2 gather", "barrier", "pass 3 + split", "X staged, frame max", "barrier", "next samples + row stores issued",
-            "peak search", "records", "barrier", "peak numbering (wave 0)", "-> next frame top"]
-SYNTHESIS = ["offsets read, phasors, pre-split, pass 1", "barrier", "T1 scatter, offsets zeroed", "barrier", "T1 gather", "barrier",
-             "twiddles, pass 2, T2 scatter, offsets filled", "barrier", "T2 gather, next row + window requested", "pass 3",
+            "peak search", "barrier", "records (wave 1 first)", "peak numbering (wave 0)", "-> next frame top"]
+SYNTHESIS = ["row + offsets read (LDS), phasors, pre-split, pass 1", "barrier", "next row requested (LDS-DMA), T1 scatter, offsets zeroed", "barrier", "T1 gather", "barrier",
+             "twiddles, pass 2, T2 scatter, offsets filled", "next row landed (vmcnt 0)", "barrier", "T2 gather", "pass 3",
              "overlap-add (registers), hop out", "-> next frame top"]
 
 
@@ -65,22 +65,22 @@ def build():
               "    if (t < W) pkb[m0][t + 1] = 0u;\n    MX_STAMP(0, 19, 12);\n    __syncthreads();\n    MX_STAMP(0, 19, 13);\n")
     s = patch(s, "    const float thr2 = kPvActiveRel2 * (red[cur][0] > red[cur][1] ? red[cur][0] : red[cur][1]);\n",
               "    MX_STAMP(0, 19, 14);\n    const float thr2 = kPvActiveRel2 * (red[cur][0] > red[cur][1] ? red[cur][0] : red[cur][1]);\n")
-    s = patch(s, "    // the pending frame's records (one per thread from the registers; a frame with more peaks than threads gathers the\n",
-              "    MX_STAMP(0, 19, 15);\n    // the pending frame's records (one per thread from the registers; a frame with more peaks than threads gathers the\n")
-    s = patch(s, "    __syncthreads();\n    // the first wavefront numbers this frame's peaks",
-              "    MX_STAMP(0, 19, 16);\n    __syncthreads();\n    MX_STAMP(0, 19, 17);\n    // the first wavefront numbers this frame's peaks")
+    s = patch(s, "    __syncthreads();  // this frame's peak map is complete\n",
+              "    MX_STAMP(0, 19, 15);\n    __syncthreads();\n    MX_STAMP(0, 19, 16);\n")
+    s = patch(s, "    // the first wavefront numbers this frame's peaks",
+              "    MX_STAMP(0, 19, 17);\n    // the first wavefront numbers this frame's peaks")
     s = patch(s, "    pend = emit;\n    thr2_2 = thr2_1;\n", "    MX_STAMP(0, 19, 18);\n    pend = emit;\n    thr2_2 = thr2_1;\n")
     # ---- synthesis ----
-    s = patch(s, "  for (int64_t f = f0; f < f1; ++f) {\n    // LICM may keep this thread's",
+    s = patch(s, "  for (int64_t f = f0; f < f1; ++f) {\n    const int t = t_;\n    // (the sixteen products",
               "  unsigned long long *const tl_ptr = mx_tl_buf;\n  const bool tl_on = tl_ptr != nullptr && blk == (int64_t)mx_tl_sel[2];\n  const int64_t tl_f0 = f0, tl_frm = (int64_t)mx_tl_sel[3];\n"
-              "  for (int64_t f = f0; f < f1; ++f) {\n    MX_STAMP(1, NSY, 0);\n    // LICM may keep this thread's")
-    s = patch(s, "    pass1<P>(Y, v);\n    __syncthreads();  // (every wave has read this frame's offsets and its T2 columns of the previous frame)\n    store_t1<P>(t, v, lds);\n    zero_cd(t);\n    __syncthreads();\n    load_t1<P>(t, v, lds);\n    __syncthreads();\n",
-              "    pass1<P>(Y, v);\n    MX_STAMP(1, NSY, 1);\n    __syncthreads();\n    MX_STAMP(1, NSY, 2);\n    store_t1<P>(t, v, lds);\n    zero_cd(t);\n    MX_STAMP(1, NSY, 3);\n    __syncthreads();\n    MX_STAMP(1, NSY, 4);\n    load_t1<P>(t, v, lds);\n    MX_STAMP(1, NSY, 5);\n    __syncthreads();\n    MX_STAMP(1, NSY, 6);\n")
-    s = patch(s, "    cnt1 = cnt2;\n    __syncthreads();\n", "    cnt1 = cnt2;\n    MX_STAMP(1, NSY, 7);\n    __syncthreads();\n    MX_STAMP(1, NSY, 8);\n")
+              "  for (int64_t f = f0; f < f1; ++f) {\n    MX_STAMP(1, NSY, 0);\n    const int t = t_;\n    // (the sixteen products")
+    s = patch(s, "    pass1<P>(Y, v);\n    __syncthreads();  // (every wave has read this frame's row and offsets, and its T2 columns of the previous frame)\n    if (f + 1 < f1) request_row(f + 1, t);\n    store_t1<P>(t, v, lds);\n    zero_cd(t);\n    __syncthreads();\n    load_t1<P>(t, v, lds);\n    __syncthreads();\n",
+              "    pass1<P>(Y, v);\n    MX_STAMP(1, NSY, 1);\n    __syncthreads();\n    MX_STAMP(1, NSY, 2);\n    if (f + 1 < f1) request_row(f + 1, t);\n    store_t1<P>(t, v, lds);\n    zero_cd(t);\n    MX_STAMP(1, NSY, 3);\n    __syncthreads();\n    MX_STAMP(1, NSY, 4);\n    load_t1<P>(t, v, lds);\n    MX_STAMP(1, NSY, 5);\n    __syncthreads();\n    MX_STAMP(1, NSY, 6);\n")
+    s = patch(s, "    cnt1 = cnt2;\n    row_landed();  // (requested three barriers ago)\n    __syncthreads();\n", "    cnt1 = cnt2;\n    MX_STAMP(1, NSY, 7);\n    row_landed();\n    MX_STAMP(1, NSY, 8);\n    __syncthreads();\n    MX_STAMP(1, NSY, 9);\n")
     s = patch(s, "    pass3_col(g3p, 0);\n    pass3_col(g3q, P::R3);\n",
-              "    MX_STAMP(1, NSY, 9);\n    pass3_col(g3p, 0);\n    pass3_col(g3q, P::R3);\n    MX_STAMP(1, NSY, 10);\n")
+              "    MX_STAMP(1, NSY, 10);\n    pass3_col(g3p, 0);\n    pass3_col(g3q, P::R3);\n    MX_STAMP(1, NSY, 11);\n")
     s = patch(s, "        reinterpret_cast<float2 *>(a.halo + (size_t)blk * kPvHalo + (f - f0) * kPvHs)[t] = make_float2(hopv.x, hopv.y);\n      }\n    }\n",
-              "        reinterpret_cast<float2 *>(a.halo + (size_t)blk * kPvHalo + (f - f0) * kPvHs)[t] = make_float2(hopv.x, hopv.y);\n      }\n    }\n    MX_STAMP(1, NSY, 11);\n")
+              "        reinterpret_cast<float2 *>(a.halo + (size_t)blk * kPvHalo + (f - f0) * kPvHs)[t] = make_float2(hopv.x, hopv.y);\n      }\n    }\n    MX_STAMP(1, NSY, 12);\n")
     s = s.replace("NSY", str(len(SYNTHESIS)))
     # ---- the stamp buffer and the (workgroup, frame) selection come from the environment at launch ----
     s = patch(s, "hipError_t launch_pv(const PvArgs &a, hipStream_t s) {\n  if (a.frames <= 0 || a.n <= 0) return hipSuccess;\n",
