@@ -82,6 +82,10 @@ MX_PK3(pk_fma_ywc, "op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]")
 MX_PK3S(pk_fma_ywcs, "op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]")
 // 2*a - b   (b in {2, 2}: a scalar register pair)
 MX_PK3S(pk_two_minus_, "neg_lo:[0,0,1] neg_hi:[0,0,1]")
+// the inverse transform's pre-split and overlap-add (pv_kernels.hip):
+MX_PK2(pk_cj_add_i, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]")  // conj(a + i*b) = (a.x - b.y, -a.y - b.x)
+MX_PK2(pk_cj_sub, "v_pk_add_f32", "neg_lo:[0,1] neg_hi:[1,0]")                                 // conj(a - b)   = (a.x - b.x, -a.y + b.y)
+MX_PK3(pk_fma_cj, "neg_hi:[1,0,0]")                                                            // (a.x*b.x + c.x, -a.y*b.y + c.y)
 
 MX_PK_HOST cpx pk_add(cpx a, cpx b) { return mk(a.x + b.x, a.y + b.y); }
 MX_PK_HOST cpx pk_sub(cpx a, cpx b) { return mk(a.x - b.x, a.y - b.y); }
@@ -101,6 +105,9 @@ MX_PK_HOST cpx pk_fnma_xs(cpx a, cpx b, cpx c) { return mk(__builtin_fmaf(a.x, -
 MX_PK_HOST cpx pk_fma_yw(cpx a, cpx b, cpx c) { return mk(__builtin_fmaf(a.y, -b.y, c.x), __builtin_fmaf(a.x, b.y, c.y)); }
 MX_PK_HOST cpx pk_fma_ywc(cpx a, cpx b, cpx c) { return mk(__builtin_fmaf(a.y, b.y, c.x), __builtin_fmaf(a.x, -b.y, c.y)); }
 MX_PK_HOST cpx pk_fma_ywcs(cpx a, cpx b, cpx c) { return pk_fma_ywc(a, b, c); }
+MX_PK_HOST cpx pk_cj_add_i(cpx a, cpx b) { return mk(a.x - b.y, -a.y - b.x); }
+MX_PK_HOST cpx pk_cj_sub(cpx a, cpx b) { return mk(a.x - b.x, -a.y + b.y); }
+MX_PK_HOST cpx pk_fma_cj(cpx a, cpx b, cpx c) { return mk(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(-a.y, b.y, c.y)); }
 MX_PK_HOST cpx pk_two_minus_(cpx a, cpx two, cpx b) { return mk(__builtin_fmaf(a.x, two.x, -b.x), __builtin_fmaf(a.y, two.y, -b.y)); }
 
 // 2*a - b: the second output of a butterfly whose first output b = a + t is already known (a - t = 2a - b)

@@ -739,24 +739,29 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       for (int j = 0; j < 8; ++j) any |= cc[2 * e4 + j];
       if (__ballot(any != 0u) != 0ull) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rx[2 * e4 + j] = cmul(rx[2 * e4 + j], pv_phasor(cc[2 * e4 + j]));
+        for (int j = 0; j < 8; ++j) rx[2 * e4 + j] = pk_cmul2(rx[2 * e4 + j], pv_phasor(cc[2 * e4 + j]));
       }
     }
+    // G[c] = conj((A + B) + i w_c (A - B)), A = Yhat[c], B = conj(Yhat[M - c]), w_c = e^{2 pi i c/N} = e^{2 pi i t/N} e^{2 pi i e/32}
+    // for c = t + T e: one value kept for the walk times a constant — and w_{c + 8T} = i w_c, so slots e and e + 8 share the
+    // product.  Packed arithmetic throughout: six / five instructions per slot.
 #pragma unroll
-    for (int e = 0; e < P::E; ++e) {
-      const int c = t + P::T * e;
-      cpx A = rx[2 * e], B = rx[2 * e + 1];
-      B = cconj(B);
-      // (bin 0 contributes its real part only — y is the real part of the one-sided sum — and bin M, thread 0's mirror
-      // of c = 0, is the dropped Nyquist bin)
-      if (c == 0) {
-        A = mk(A.x, 0.f);
-        B = mk(0.f, 0.f);
+    for (int e = 0; e < P::E / 2; ++e) {
+      const cpx wc = pk_rot_cs(wbase, mk(kW32[e][0], -kW32[e][1]));  // wbase * (cos + i sin)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ee = e + (P::E / 2) * h;
+        cpx A = rx[2 * ee], B = rx[2 * ee + 1];  // B: Yhat[M - c] itself (its conjugate enters below)
+        // (bin 0 contributes its real part only — y is the real part of the one-sided sum — and bin M, thread 0's mirror
+        // of c = 0, is the dropped Nyquist bin)
+        if (ee == 0 && t == 0) {
+          A = mk(A.x, 0.f);
+          B = mk(0.f, 0.f);
+        }
+        const cpx Sm = pk_add_cj(A, B), Dm = pk_sub_cj(A, B);
+        const cpx q = pk_cmul2(wc, Dm);
+        Y[ee] = h == 0 ? pk_cj_add_i(Sm, q) : pk_cj_sub(Sm, q);  // i (i w_c Dm) = -w_c Dm
       }
-      const cpx Sm = cadd(A, B), Dm = csub(A, B);
-      // w_c = e^{2 pi i c/N} = e^{2 pi i t/N} * e^{2 pi i e/32}: one hoisted value and a constant, not 16 table entries
-      const cpx wd = cmul(cmul(wbase, mk(kW32[e][0], kW32[e][1])), Dm);  // w_c (A-B)
-      Y[e] = mk(Sm.x - wd.y, -(Sm.y + wd.x));      // conj((A+B) + i*wd)
     }
     pass1<P>(Y, v);
     __syncthreads();  // (every wave has read this frame's row and offsets, and its T2 columns of the previous frame)
@@ -824,7 +829,7 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       const cpx d = (j & 1) ? v[P::R3 + (j >> 1)] : v[j >> 1];
       const float2 h = hw[j];
       const cpx old = j < kOla - 1 ? acc[j] : mk(0.f, 0.f);
-      const cpx sum = mk(old.x + d.x * h.x, old.y - d.y * h.y);
+      const cpx sum = pk_fma_cj(d, mk(h.x, h.y), old);
       if (j == 0) hopv = sum;
       else acc[j - 1] = sum;
     }
