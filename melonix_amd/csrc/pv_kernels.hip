@@ -21,8 +21,9 @@
 //                 stft_core.h -> X/N, rows [F][N/2] complex; the frame's peaks (active, not below rho times any of its
 //                 four neighbours) as a 2048-bit map and, compacted in bin order, one record per peak:
 //                 (bin p, owner q of bin p in the PREVIOUS frame's peak map, continues?, delta) with
-//                 delta = P_{f-1}[p] + inc_f[p] - P_f[p] — the previous frame's spectrum stays in LDS for that (the two
-//                 FFT images take turns), a workgroup's first frame is preceded by a warm-up transform of the frame before
+//                 delta = P_{f-1}[p] + inc_f[p] - P_f[p] — made one frame later from the two rows in HBM/L2 (the gathers
+//                 travel under the next frame's transform); a workgroup's first frame is preceded by a warm-up transform
+//                 of the frame before
 //   pv_lock_walk  the recurrence over the records of a chunk of the frame axis, one barrier per row, rows a few dozen
 //                 records long:   C_f[p] = E_{f-1}[p] + delta  (continues)  |  restart,
 //                 E_{f-1}[p] = C_{f-1}[q] where q (valid) continued itself, else 0.  A frame is therefore a map
@@ -30,12 +31,14 @@
 //                 chunks: composed chunk maps (dense again at the chunk's end: every bin's owner in the last row), a
 //                 serial pass over them (pv_lock_chunks), then the same walk with the chunk-start offsets writes the
 //                 peaks' C values, in record order
-//   pv_synthesis  a workgroup walks >= 32 consecutive frames: the frame's peaks claim their bins (interval fill of an
-//                 owner-index array in the free FFT image), every bin's coefficient is X_f[k] e^{2 pi i C/2^32} ->
-//                 inverse real FFT (the same three passes on the conjugated, pre-split spectrum) -> Hann window ->
-//                 overlap-add in an LDS ring of N samples; after each frame the oldest hop is complete and leaves as one
-//                 1 KiB store, normalised by sum w^2 = 3N/(8 Hs).  Only the N - Hs samples either side of a workgroup
-//                 boundary see two workgroups: the left one leaves its partial sums in s, the right one in a halo buffer
+//   pv_synthesis  a workgroup walks >= 32 consecutive frames: the next frame's row arrives as LDS-DMA, requested a frame
+//                 ahead; the frame's peaks claim their bins (interval fill of a per-bin offset array in LDS, between the
+//                 transform's own barriers), every bin's coefficient is X_f[k] e^{2 pi i C/2^32} -> inverse real FFT (the
+//                 same three passes on the conjugated, pre-split spectrum; the last one on the columns t and t + NS3/2) ->
+//                 Hann window -> overlap-add in REGISTERS (a thread's sample pairs map onto themselves under a shift by one
+//                 hop); after each frame the oldest hop is complete and leaves as one 1 KiB store, normalised by
+//                 sum w^2 = 3N/(8 Hs).  Only the N - Hs samples either side of a workgroup boundary see two workgroups:
+//                 the left one leaves its partial sums in s, the right one in a halo buffer
 //   pv_fixup      adds the halo to s across each boundary (in frame order: deterministic, no atomics)
 //   pv_resample   linear interpolation at i*r -> f32 / int16 PCM (pv_resample_frames: the marker-driven variant,
 //                 where each frame carries its own warped time and ratio and owns a range of output samples)
