@@ -30,7 +30,8 @@ for N, hop in sizes:
     mags = torch.empty((F, N // 2), dtype=torch.float32, device=dev)
     pitch = torch.empty((F, 2), dtype=torch.int32, device=dev)
     band = mx.pitch_band(N, SR)
-    fn = lambda: ctx.stft_hop_dev(audio, N, hop, 0, F, mags.data_ptr(), pitch.data_ptr(), band=band)  # noqa: E731
+    pp = 0 if os.environ.get("MX_NO_PITCH") else pitch.data_ptr()  # MX_NO_PITCH=1: rows only (what the pitch pick costs)
+    fn = lambda: ctx.stft_hop_dev(audio, N, hop, 0, F, mags.data_ptr(), pp, band=band)  # noqa: E731
     # (fresh output buffers fault their pages in, and a fresh box ramps for ~25 launches before the power manager settles)
     WARM, REPS = int(os.environ.get("MX_WARM", 40)), int(os.environ.get("MX_REPS", 150))
     for _ in range(WARM):
