@@ -1,9 +1,9 @@
 set -u
-timeout 900 python -m pytest tests/test_pv.py -m gpu -q -x 2>&1 | tail -3
-for lib in shipped melonix_amd/lib/variants/pv_prev.so; do
-  if [ "$lib" = shipped ]; then unset MX_AB_LIB; else export MX_AB_LIB=$lib; fi
-  echo "== $lib"
-  python tools/pv_ab.py 60 3 sweep 2>&1 | grep "^pv"
-  python tools/pv_ab.py 60 3 rich 2>&1 | grep "^pv"
-  STATS_ONLY=1 bash tools/profile_pv.sh ab sweep | grep -E "^pv_(analysis|synthesis)"
-done
+export TMPDIR=/tmp
+bash tools/profile_pv.sh r04 sweep > gpurun_out/pv_prof_sweep.txt 2>&1
+cp gpurun_out/prof_pv_r04/stats/*kernel_stats.csv gpurun_out/pv_kernel_stats_sweep.csv 2>/dev/null
+bash tools/profile_pv.sh r04rich rich > gpurun_out/pv_prof_rich.txt 2>&1
+python tools/timeline_pv.py run sweep > gpurun_out/pv_timeline_sweep.txt 2>&1
+python tools/timeline_pv.py run rich > gpurun_out/pv_timeline_rich.txt 2>&1
+python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+tail -c 600 gpurun_out/bench_final.json
