@@ -1,9 +1,12 @@
+#!/bin/bash
+# tools/run_gpu_batch.sh — what one gpurun call runs (rewritten per experiment; this is the round's closing check):
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/run_gpu_batch.sh'
 set -u
-export TMPDIR=/tmp
-bash tools/profile_pv.sh r04 sweep > gpurun_out/pv_prof_sweep.txt 2>&1
-cp gpurun_out/prof_pv_r04/stats/*kernel_stats.csv gpurun_out/pv_kernel_stats_sweep.csv 2>/dev/null
-bash tools/profile_pv.sh r04rich rich > gpurun_out/pv_prof_rich.txt 2>&1
-python tools/timeline_pv.py run sweep > gpurun_out/pv_timeline_sweep.txt 2>&1
-python tools/timeline_pv.py run rich > gpurun_out/pv_timeline_rich.txt 2>&1
-python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-tail -c 600 gpurun_out/bench_final.json
+timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -3
+python bench.py > gpurun_out/bench_check.json 2> gpurun_out/bench_check.err
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/bench_check.json"))
+print({k: d[k] for k in ("value", "ms_per_step", "outputs_ok")}, d["roofline"]["frac"], d["phase_vocoder_supplementary"]["call_ms"])
+PY
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
