@@ -59,7 +59,7 @@ def test_oracle_plan(pv):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("st", [0.0, 3.0, -4.0, 12.0, 0.37, -11.0])
+@pytest.mark.parametrize("st", [0.0, 3.0, -4.0, 12.0, 0.37, -11.0, 24.0, -24.0, 19.99])
 def test_gpu_matches_oracle(gpu_ctx, pv, st):
     """Tolerance: the GPU transforms in binary32, the oracle in binary64; the phase bookkeeping is integer on both
     sides.  2e-5 of full scale (measured: <= 4e-6)."""
