@@ -782,7 +782,7 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   size_t off = 0;
   auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_apos = take((size_t)Fl * 8), o_h = take(N * 4), o_hs = take(N * 4), o_m = take(rowsz * 8),
-               o_p = take(rowsz * 8), o_i = take(rowsz * 4), o_pc = take((size_t)Fl * 4), o_c = take((size_t)nchunks * M * 4),
+               o_p = take(rowsz * 8), o_i = take(rowsz * 4), o_pc = take((size_t)Fl * 4), o_ft = take((size_t)Fl * 4), o_c = take((size_t)nchunks * M * 4),
                o_gs = take((size_t)((nchunks + 31) / 32) * M * 4), o_go = take((size_t)((nchunks + 31) / 32) * M * 2),
                o_f = take((size_t)pv_halo_floats(Fl - first) * 4), o_s = take(((size_t)p.s_len + 1) * 4),
                o_w = take((size_t)M * 8), o_a = take((size_t)nchunks * M * 2), o_ow = take((size_t)Fl * (M / 32) * 4),
@@ -832,6 +832,7 @@ int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, i
   p.recs = reinterpret_cast<uint2 *>(arena + o_p);
   p.cvals = reinterpret_cast<uint32_t *>(arena + o_i);
   p.pkcount = reinterpret_cast<uint32_t *>(arena + o_pc);
+  p.fthr = reinterpret_cast<float *>(arena + o_ft);
   p.chunk_sums = reinterpret_cast<uint32_t *>(arena + o_c);
   p.group_sums = reinterpret_cast<uint32_t *>(arena + o_gs);
   p.group_org = reinterpret_cast<uint16_t *>(arena + o_go);

@@ -77,6 +77,7 @@ struct PvArgs {
   float2 *xrows;       // [frames][N/2]
   uint32_t *pkmap;     // [frames][N/64] bit k: bin k is a spectral peak of the frame
   uint32_t *pkcount;   // [frames] number of peaks (= records) of the frame
+  float *fthr;         // [frames] the frame's activity threshold (squared magnitude): what the next frame's records compare with
   uint2 *recs;         // [frames][N/2] the frame's records (only the first pkcount are written or read)
   uint32_t *cvals;     // [frames][N/2] out of the second sweep: C_f of the frame's peaks in record order (0 = restarted)
   uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2] a chunk's composed map: delta (or restart value) ...

@@ -126,6 +126,34 @@ __device__ __forceinline__ int wave_scan_add(int x) {
   return x;
 }
 
+// The record of one peak of a frame (h, hr: the frame's hop and stretch factor; p: the peak's bin; xc, xq: the frame's and the
+// previous frame's spectrum at p; pkq: the previous frame's peak map; thrq: that frame's activity threshold)
+__device__ __forceinline__ uint2 pv_make_record(uint32_t h, double hr, int p, float2 xc, float2 xq, const uint32_t *pkq, float thrq,
+                                                bool prev_exists) {
+  const uint32_t pc_ = to_turns(xc.x, xc.y), pp_ = to_turns(xq.x, xq.y);
+  const bool cont = prev_exists && h >= 1 && cnorm2(xq) >= thrq;
+  const int q = pv_owner(pkq, p);
+  uint2 rec;
+  rec.x = (uint32_t)p | (q != (int)kPvNoBin ? ((uint32_t)q << 11) | kRecQValid : 0u) | (cont ? kRecCont : 0u);
+  rec.y = pp_ + pv_inc(p, h, hr, pc_, pp_) - pc_;
+  return rec;
+}
+
+// The peaks of a map (W words, one per lane of the calling wavefront), numbered: their bins in ascending order into `list`,
+// their count returned in lane 63 (exclusive scan of the words' populations through the DPP crossbar).
+__device__ __forceinline__ int pv_number_peaks(uint32_t w, int lane, uint16_t *list) {
+  const int c = __builtin_popcount(w);
+  const int inc = wave_scan_add(c);
+  uint32_t rest = w;
+  int r = inc - c;
+  while (rest) {
+    const int b = __builtin_ctz(rest);
+    rest &= rest - 1;
+    list[r++] = (uint16_t)(32 * lane + b);
+  }
+  return inc;
+}
+
 __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   using P = PV;
   // the M-point image (after the transform it holds X_f in bin order, for the peak search and the row's way to HBM); the
@@ -169,11 +197,11 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   const int64_t f0 = (int64_t)lb * a.frames_per_block;
   const int64_t f1 = f0 + a.frames_per_block < a.frames ? f0 + a.frames_per_block : a.frames;
   if (f0 >= f1) return;
-  // the walk starts one frame early: frame f0's records need X_{f0-1} (this workgroup writes that row as well — the very
-  // values its owner writes — so that what it reads back is its own), its peak map and its threshold
-  const int64_t fw = f0 > 0 ? f0 - 1 : 0;
+  // The records of the workgroup's FIRST frame need the previous workgroup's last row, peak map and threshold: pv_heads
+  // makes them, behind this kernel (a warm-up transform of frame f0 - 1 in front of every sixteen frames was 6 % of the
+  // kernel's time and 0.8 GB of duplicate rows).
   cpx xr[P::E];
-  load_raw<P, false>(t_, xr, a.audio + MX_AUDIO_PAD + (a.apos[fw] - P::N / 2));
+  load_raw<P, false>(t_, xr, a.audio + MX_AUDIO_PAD + (a.apos[f0] - P::N / 2));
   // this thread's window values: registers for the whole walk (the kernel runs two waves per SIMD either way; reloaded per
   // frame they were sixteen L1 round trips at the top of every transform)
   cpx hwin[P::E];
@@ -181,29 +209,17 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   for (int e = 0; e < P::E; ++e) hwin[e] = ld_pair<true>(a.hann_scaled, 2 * (t_ + P::T * e));
   __syncthreads();
 
-  // The record of one peak of frame fr (p: its bin; xc, xq: X_fr[p], X_{fr-1}[p]; pkq: the peak map of frame fr - 1;
-  // thrq: that frame's activity threshold)
-  auto make_record = [&](uint32_t h, double hr, int p, float2 xc, float2 xq, const uint32_t *pkq, float thrq, bool prev_exists) {
-    const uint32_t pc_ = to_turns(xc.x, xc.y), pp_ = to_turns(xq.x, xq.y);
-    const bool cont = prev_exists && h >= 1 && cnorm2(xq) >= thrq;
-    const int q = pv_owner(pkq, p);
-    uint2 rec;
-    rec.x = (uint32_t)p | (q != (int)kPvNoBin ? ((uint32_t)q << 11) | kRecQValid : 0u) | (cont ? kRecCont : 0u);
-    rec.y = pp_ + pv_inc(p, h, hr, pc_, pp_) - pc_;
-    return rec;
-  };
   // pending: the frame whose peaks are listed in plist (records not yet written)
   int pend_cnt = 0;
   bool pend = false;
   float thr2_1 = 0.f, thr2_2 = 0.f;  // thresholds of frames f-1, f-2
-  int m0 = (int)(fw % 3);            // pkb index of frame f
+  int m0 = (int)(f0 % 3);            // pkb index of frame f
   int cur = 0;
-  for (int64_t f = fw; f < f1; ++f) {
+  for (int64_t f = f0; f < f1; ++f) {
     // as in stft_kernel: re-materialise the thread index and a zero table offset per frame, or LICM hoists every
     // frame-invariant table value and address out of the loop
     int t = t_;
     asm volatile("" : "+v"(t));
-    const bool emit = f >= f0;  // (block-uniform)
     // the pending frame's hop and stretch factor (scalar loads: requested here they return under pass 1)
     const uint32_t ph = a.hop[f > 0 ? f - 1 : 0];
     const double phr = a.hratio[f > 0 ? f - 1 : 0];
@@ -282,6 +298,7 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       for (int i = 0; i < P::M / 2 / P::T; ++i) __builtin_nontemporal_store(src[P::T * i], &dst[P::T * i]);
     }
     const float thr2 = kPvActiveRel2 * (red[cur][0] > red[cur][1] ? red[cur][0] : red[cur][1]);
+    if (t == 0) a.fthr[f] = thr2;
     // Peaks of the row: active and not below rho times any of its four neighbours (squared magnitudes; bins outside the
     // row never stand in the way).  Thread t looks at bins 4j .. 4j+3, j = t + T i.
     using f32x4 = float __attribute__((ext_vector_type(4)));
@@ -322,29 +339,19 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
           ga = xa[gp];
           gb = f >= 2 ? xb[gp] : make_float2(0.f, 0.f);
         }
-        rrow[i] = make_record(ph, phr, gp, ga, gb, &pkb[m2][1], thr2_2, f >= 2);
+        rrow[i] = pv_make_record(ph, phr, gp, ga, gb, &pkb[m2][1], thr2_2, f >= 2);
       }
     }
     // the first wavefront numbers this frame's peaks (exclusive scan of the words' populations through the DPP crossbar)
     // and lists their bins in ascending order
     if (wave0) {
       const uint32_t w = pkb[m0][1 + t];  // W == 64: one word per lane
-      const int c = __builtin_popcount(w);
-      const int inc = wave_scan_add(c);
+      const int inc = pv_number_peaks(w, t, plist[f & 1]);
       if (t == 63) npk = (uint32_t)inc;
-      uint32_t rest = w;
-      int r = inc - c;
-      while (rest) {
-        const int b = __builtin_ctz(rest);
-        rest &= rest - 1;
-        plist[f & 1][r++] = (uint16_t)(32 * t + b);
-      }
-      if (emit) {
-        a.pkmap[(size_t)f * W + t] = w;
-        if (t == 63) a.pkcount[f] = (uint32_t)inc;
-      }
+      a.pkmap[(size_t)f * W + t] = w;
+      if (t == 63) a.pkcount[f] = (uint32_t)inc;
     }
-    pend = emit;
+    pend = f > f0;  // (the first frame's records are pv_heads')
     thr2_2 = thr2_1;
     thr2_1 = thr2;
     m0 = m0 == 2 ? 0 : m0 + 1;
@@ -352,8 +359,8 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   }
   __syncthreads();
   pend_cnt = (int)npk;
-  // the last frame's records: no next transform to hide the gathers under
-  {
+  // the last frame's records: no next transform to hide the gathers under (a one-frame workgroup's are pv_heads')
+  if (f1 - 1 > f0) {
     const int64_t fl = f1 - 1;
     const int m1 = m0 == 0 ? 2 : m0 - 1, m2 = m1 == 0 ? 2 : m1 - 1;  // m1: frame fl's map, m2: frame fl - 1's
     uint2 *rrow = a.recs + (size_t)fl * P::M;
@@ -362,8 +369,38 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     const double lhr = a.hratio[fl];
     for (int i = t_; i < pend_cnt; i += P::T) {
       const int p = plist[fl & 1][i];
-      rrow[i] = make_record(lh, lhr, p, xa[p], fl >= 1 ? xb[p] : make_float2(0.f, 0.f), &pkb[m2][1], thr2_2, fl >= 1);
+      rrow[i] = pv_make_record(lh, lhr, p, xa[p], fl >= 1 ? xb[p] : make_float2(0.f, 0.f), &pkb[m2][1], thr2_2, fl >= 1);
     }
+  }
+}
+
+// The records of every analysis workgroup's first frame f (a multiple of the run length): the frame's peaks from its map,
+// its spectrum and the previous frame's at the peaks from their rows, the previous frame's map and threshold — everything
+// pv_analysis left in memory.  One workgroup per such frame.
+__global__ __launch_bounds__(PV::T) void pv_heads(const PvArgs a) {
+  using P = PV;
+  constexpr int W = P::M / 32;
+  __shared__ uint32_t pkq[W + 2];  // the previous frame's map, a zero word either side
+  __shared__ uint16_t plist[P::M];
+  __shared__ uint32_t npk;
+  const int t = threadIdx.x;
+  const int64_t f = (int64_t)blockIdx.x * a.frames_per_block;
+  if (f >= a.frames) return;
+  if (t < W + 2) pkq[t] = (f >= 1 && t >= 1 && t <= W) ? a.pkmap[(size_t)(f - 1) * W + (t - 1)] : 0u;
+  if (t < 64) {
+    const int inc = pv_number_peaks(a.pkmap[(size_t)f * W + t], t, plist);
+    if (t == 63) npk = (uint32_t)inc;
+  }
+  __syncthreads();
+  const int cnt = (int)npk;
+  const uint32_t h = a.hop[f];
+  const double hr = a.hratio[f];
+  const float thrq = f >= 1 ? a.fthr[f - 1] : 0.f;
+  uint2 *rrow = a.recs + (size_t)f * P::M;
+  const float2 *xa = a.xrows + (size_t)f * P::M, *xb = a.xrows + (size_t)(f >= 1 ? f - 1 : 0) * P::M;
+  for (int i = t; i < cnt; i += P::T) {
+    const int p = plist[i];
+    rrow[i] = pv_make_record(h, hr, p, xa[p], f >= 1 ? xb[p] : make_float2(0.f, 0.f), &pkq[1], thrq, f >= 1);
   }
 }
 
@@ -968,6 +1005,7 @@ hipError_t launch_pv_analyze(const PvArgs &a0, hipStream_t s) {
   const unsigned fb = (unsigned)((a.frames + a.frames_per_block - 1) / a.frames_per_block);
   const int64_t nchunks = pv_chunks(a);
   hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
+  hipLaunchKernelGGL(pv_heads, dim3(fb), dim3(PV::T), 0, s, a);
   hipLaunchKernelGGL(pv_lock_walk<false>, dim3((unsigned)nchunks), dim3(kLockT), 0, s, a);
   if (a.tot_sums) {  // this rank's total map: the composition of its group maps
     launch_group_maps(a, nchunks, s);

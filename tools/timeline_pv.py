@@ -51,9 +51,9 @@ def build():
               "const unsigned long long tm_ = __builtin_amdgcn_s_memtime(); if ((t_ & 63) == 0) tl_ptr[(K) * 256 + ((int)df_ * (NST) + (i)) * 2 + (t_ >> 6)] = tm_; } } while (0)\n"
               "__global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {")
     # ---- analysis ----
-    s = patch(s, "  int cur = 0;\n  for (int64_t f = fw; f < f1; ++f) {\n",
-              "  int cur = 0;\n  unsigned long long *const tl_ptr = mx_tl_buf;\n  const bool tl_on = tl_ptr != nullptr && lb == mx_tl_sel[0];\n  const int64_t tl_f0 = fw, tl_frm = (int64_t)mx_tl_sel[1];\n"
-              "  for (int64_t f = fw; f < f1; ++f) {\n    MX_STAMP(0, 19, 0);\n")
+    s = patch(s, "  int cur = 0;\n  for (int64_t f = f0; f < f1; ++f) {\n",
+              "  int cur = 0;\n  unsigned long long *const tl_ptr = mx_tl_buf;\n  const bool tl_on = tl_ptr != nullptr && lb == mx_tl_sel[0];\n  const int64_t tl_f0 = f0, tl_frm = (int64_t)mx_tl_sel[1];\n"
+              "  for (int64_t f = f0; f < f1; ++f) {\n    MX_STAMP(0, 19, 0);\n")
     s = patch(s, "    pass1<P>(Y, v);\n    __syncthreads();  // every wave is past the previous frame's peak numbering: plist and npk are complete\n",
               "    pass1<P>(Y, v);\n    MX_STAMP(0, 19, 1);\n    __syncthreads();\n    MX_STAMP(0, 19, 2);\n")
     s = patch(s, "    store_t1<P>(t, v, lds);\n    __syncthreads();\n    cpx w2[P::R2 - 1];\n    load_t1_tw2<P>(t, v, lds, ltw2, w2);\n    __syncthreads();\n    pass2_reg<P>(v, w2);\n    store_t2<P>(t, v, lds);\n    __syncthreads();\n    load_t2<P>(t, v, lds);\n    __syncthreads();  // every wave has its T2 read: the image is free for X_f\n",
@@ -69,7 +69,7 @@ def build():
               "    MX_STAMP(0, 19, 15);\n    __syncthreads();\n    MX_STAMP(0, 19, 16);\n")
     s = patch(s, "    // the first wavefront numbers this frame's peaks",
               "    MX_STAMP(0, 19, 17);\n    // the first wavefront numbers this frame's peaks")
-    s = patch(s, "    pend = emit;\n    thr2_2 = thr2_1;\n", "    MX_STAMP(0, 19, 18);\n    pend = emit;\n    thr2_2 = thr2_1;\n")
+    s = patch(s, "    pend = f > f0;  // (the first frame's records are pv_heads')\n", "    MX_STAMP(0, 19, 18);\n    pend = f > f0;\n")
     # ---- synthesis ----
     s = patch(s, "  for (int64_t f = f0; f < f1; ++f) {\n    const int t = t_;\n    // (the sixteen products",
               "  unsigned long long *const tl_ptr = mx_tl_buf;\n  const bool tl_on = tl_ptr != nullptr && blk == (int64_t)mx_tl_sel[2];\n  const int64_t tl_f0 = f0, tl_frm = (int64_t)mx_tl_sel[3];\n"
