@@ -22,8 +22,9 @@
 //                 four neighbours) as a 2048-bit map and, compacted in bin order, one record per peak:
 //                 (bin p, owner q of bin p in the PREVIOUS frame's peak map, continues?, delta) with
 //                 delta = P_{f-1}[p] + inc_f[p] - P_f[p] — made one frame later from the two rows in HBM/L2 (the gathers
-//                 travel under the next frame's transform); a workgroup's first frame is preceded by a warm-up transform
-//                 of the frame before
+//                 travel under the next frame's transform)
+//   pv_heads      the records of every analysis workgroup's FIRST frame (they need the previous workgroup's last row, map and
+//                 threshold): from memory, behind the analysis
 //   pv_lock_walk  the recurrence over the records of a chunk of the frame axis, one barrier per row, rows a few dozen
 //                 records long:   C_f[p] = E_{f-1}[p] + delta  (continues)  |  restart,
 //                 E_{f-1}[p] = C_{f-1}[q] where q (valid) continued itself, else 0.  A frame is therefore a map
@@ -1001,7 +1002,7 @@ void launch_group_maps(const PvArgs &a, int64_t nchunks, hipStream_t s) {
 hipError_t launch_pv_analyze(const PvArgs &a0, hipStream_t s) {
   PvArgs a = a0;
   if (a.frames - a.first <= 0) return hipSuccess;
-  a.frames_per_block = 16;  // (measured with the XCD-aware map, 4/8/16/32 frames: 5.61/5.59/5.40/5.59 ms per 60 min)
+  a.frames_per_block = 16;  // (8 / 12 / 16 / 24 frames per workgroup: 4.80 / 4.78 / 4.80 / 4.81 ms per 60 min — flat since the warm-up frame went)
   const unsigned fb = (unsigned)((a.frames + a.frames_per_block - 1) / a.frames_per_block);
   const int64_t nchunks = pv_chunks(a);
   hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
