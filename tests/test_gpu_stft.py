@@ -323,3 +323,32 @@ def test_kept_rows(gpu_ctx, oracle, mxlib, N):
     rows.free()
     rows2.free()
     a.free()
+
+
+@pytest.mark.parametrize("N,hop", [(4096, 256), (4096, 375), (16384, 512), (32768, 375), (32768, 1024)])
+def test_pitch_pick_is_the_argmax_of_its_own_row_for_any_band(gpu_ctx, N, hop):
+    """The pick against the kernel's OWN magnitude rows, bit for bit: bin = lowest k in [kmin, kmax] holding the row's largest
+    value there, mag = the row's value at that bin — for bands that start at bin 0, end at the last bin, consist of one bin,
+    sit on the bins thread 0 owns (multiples of NS3 / 2) and for random ones; on silence (every in-band value equal: the pick
+    is kmin), a sweep and noise.  Independent of the oracle: no tolerance."""
+    M = N // 2
+    rng = np.random.default_rng(N + hop)
+    w = noisy(accum_sweep(3 * SR), level=0.02)
+    w[:2 * N] = 0.0                      # whole frames of exact zeros: rows of zeros
+    w[SR:SR + 3 * N] = 0.0
+    a = gpu_ctx.upload(w)
+    ns3 = M // (8 if N == 4096 else 16)
+    bands = [(0, M - 1), (0, 0), (M - 1, M - 1), (1, 1), (ns3 // 2, ns3 // 2 + 3), (ns3, ns3), (0, ns3 // 2), (M // 2 - 1, M // 2 + 1),
+             (M - ns3, M - 1)]
+    for _ in range(6):
+        lo = int(rng.integers(0, M))
+        bands.append((lo, int(rng.integers(lo, M))))
+    for kmin, kmax in bands:
+        mags, pitch = gpu_ctx.stft_hop(a, N, hop, band=(kmin, kmax))
+        sub = mags[:, kmin:kmax + 1]
+        want = sub.argmax(axis=1) + kmin  # numpy: the first maximum = the lowest bin on ties
+        assert np.array_equal(pitch["bin"], want), (kmin, kmax, int(np.nonzero(pitch["bin"] != want)[0][0]))
+        assert np.array_equal(pitch["mag"], mags[np.arange(len(mags)), want])
+        zero_rows = ~mags.any(axis=1)
+        assert zero_rows.any() and (pitch["bin"][zero_rows] == kmin).all()
+    a.free()
