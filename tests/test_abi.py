@@ -126,3 +126,19 @@ def test_hand_issued_lds_reads_are_covered_by_their_waits(unit, tmp_path):
     assert aud.returncode == 0, aud.stdout[-3000:]
     m = re.fullmatch(r"(\d+) kernel\(s\) audited, 0 finding\(s\)", aud.stdout.splitlines()[-1])
     assert m and int(m.group(1)) >= 7, aud.stdout[-500:]
+
+
+def test_kept_traffic_figure_belongs_to_the_shipped_kernel_sources():
+    """bench.py quotes roofline.traffic from profiles/pmc_latest.json only while the sha1 in it equals that of the STFT
+    kernel's sources (pk_math.h among them, which the phase vocoder shares): an edit there without a new
+    tools/profile_gpu.sh run would silently turn the bench line's traffic into null."""
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
+        kept = json.load(fh)
+    assert kept["kernel_source_sha1"] == bench.kernel_source_hash(), "re-take profiles/pmc_latest.json (tools/profile_gpu.sh)"
+    assert kept["fft"] == 4096 and kept["hop"] == 256 and 6.2e9 < kept["hbm_bytes_per_launch"] < 7.5e9
