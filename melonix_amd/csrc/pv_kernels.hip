@@ -897,39 +897,64 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 // right workgroup's halo (none at b = nb) and normalise.  Across ranks (multi-GPU) the missing side comes from the
 // neighbour: prev_tail at b = 0, next_head at b = nb — the overlap-add seams of SURVEY 8e(3).
 __global__ __launch_bounds__(256) void pv_fixup(const PvArgs a) {
+  using f32x4 = float __attribute__((ext_vector_type(4)));
   const int64_t fs = a.frames - a.first;
   const int64_t nb = pv_blocks(fs);
-  // boundary and offset both come from blockIdx.x (gridDim.y stops at 65535: 2.1 M frames, an hour at +20 semitones)
-  constexpr int kPerB = (kPvHalo + 255) / 256;
+  // boundary and offset both come from blockIdx.x (gridDim.y stops at 65535: 2.1 M frames, an hour at +20 semitones);
+  // four samples per thread (s, the halos and the seams are 16-byte aligned: arena offsets, multiples of the hop)
+  static_assert(kPvHalo % 4 == 0, "whole 16-byte pieces");
+  constexpr int kPerB = (kPvHalo / 4 + 255) / 256;
   const int64_t b = (int64_t)(blockIdx.x / kPerB);
-  const int i = (int)(blockIdx.x % kPerB) * 256 + threadIdx.x;
+  const int i = ((int)(blockIdx.x % kPerB) * 256 + threadIdx.x) * 4;
   if (i >= kPvHalo) return;
   if (b == 0) {
-    if (a.global_first) return;  // the first hops of the signal were complete when they left the ring
-    const float v = a.halo[i] + (a.prev_tail ? a.prev_tail[i] : 0.f);
-    a.s[i] = v * kPvNorm;
+    if (a.global_first) return;  // the first hops of the signal were complete when they left the accumulator
+    f32x4 v = *reinterpret_cast<const f32x4 *>(a.halo + i);
+    if (a.prev_tail) v += *reinterpret_cast<const f32x4 *>(a.prev_tail + i);
+    *reinterpret_cast<f32x4 *>(a.s + i) = v * kPvNorm;
     return;
   }
   const int64_t fb = b == nb ? fs : b * kPvBlockFrames;
-  float v = a.s[fb * kPvHs + i];
-  if (b < nb) v += a.halo[(size_t)b * kPvHalo + i];
-  else if (a.next_head) v += a.next_head[i];
-  a.s[fb * kPvHs + i] = v * kPvNorm;
+  f32x4 v = *reinterpret_cast<const f32x4 *>(a.s + fb * kPvHs + i);
+  if (b < nb) v += *reinterpret_cast<const f32x4 *>(a.halo + (size_t)b * kPvHalo + i);
+  else if (a.next_head) v += *reinterpret_cast<const f32x4 *>(a.next_head + i);
+  *reinterpret_cast<f32x4 *>(a.s + fb * kPvHs + i) = v * kPvNorm;
 }
 
+// Four consecutive output samples per thread: the two outputs leave as 16- and 8-byte stores (a wavefront's 4- and 2-byte
+// stores were 256 and 128 bytes per instruction).
 __global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;  // output sample out_lo + j of the whole signal
-  const int64_t i = a.out_lo + j;
-  if (i >= a.out_hi) return;
-  const double pos = (double)i * a.ratio + (double)(kPvN / 2);
-  const double fl = floor(pos);
-  const int64_t m = (int64_t)fl - a.s_origin;  // s[0] is stretched sample s_origin of the whole signal
-  const float tt = (float)(pos - fl);
-  const float v = (1.0f - tt) * a.s[m] + tt * a.s[m + 1];
-  if (a.pcm_f32) a.pcm_f32[j] = v;
-  if (a.pcm_i16) {
-    const float c = v < -1.f ? -1.f : (1.f < v ? 1.f : v);  // the reference's cast is UB beyond +-1 (app.cpp:1211)
-    a.pcm_i16[j] = (int16_t)((double)c * 32767.);
+  const int64_t j0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;  // output samples out_lo + j0 .. + 3 of the whole signal
+  const int64_t left = a.out_hi - a.out_lo - j0;
+  if (left <= 0) return;
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t i = a.out_lo + j0 + (q < left ? q : 0);
+    const double pos = (double)i * a.ratio + (double)(kPvN / 2);
+    const double fl = floor(pos);
+    const int64_t m = (int64_t)fl - a.s_origin;  // s[0] is stretched sample s_origin of the whole signal
+    const float tt = (float)(pos - fl);
+    v[q] = (1.0f - tt) * a.s[m] + tt * a.s[m + 1];
+  }
+  int16_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float c = v[q] < -1.f ? -1.f : (1.f < v[q] ? 1.f : v[q]);  // the reference's cast is UB beyond +-1 (app.cpp:1211)
+    w[q] = (int16_t)((double)c * 32767.);
+  }
+  // (a caller's output pointers need not be aligned for the wide stores: then sample by sample)
+  const bool wide = (((uintptr_t)a.pcm_f32 & 15u) | ((uintptr_t)a.pcm_i16 & 7u)) == 0u;
+  if (left >= 4 && wide) {
+    using f32x4 = float __attribute__((ext_vector_type(4)));
+    using i16x4 = short __attribute__((ext_vector_type(4)));
+    if (a.pcm_f32) *reinterpret_cast<f32x4 *>(a.pcm_f32 + j0) = f32x4{v[0], v[1], v[2], v[3]};
+    if (a.pcm_i16) *reinterpret_cast<i16x4 *>(a.pcm_i16 + j0) = i16x4{w[0], w[1], w[2], w[3]};
+  } else {
+    for (int q = 0; q < (left < 4 ? (int)left : 4); ++q) {
+      if (a.pcm_f32) a.pcm_f32[j0 + q] = v[q];
+      if (a.pcm_i16) a.pcm_i16[j0 + q] = w[q];
+    }
   }
 }
 
@@ -1034,12 +1059,13 @@ hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s) {
 hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
   const int64_t nb = pv_blocks(a.frames - a.first);
-  if ((nb + 1) * (int64_t)((kPvHalo + 255) / 256) > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pv_fixup, dim3((unsigned)((nb + 1) * ((kPvHalo + 255) / 256))), dim3(256), 0, s, a);
+  constexpr int kPerB = (kPvHalo / 4 + 255) / 256;
+  if ((nb + 1) * (int64_t)kPerB > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pv_fixup, dim3((unsigned)((nb + 1) * kPerB)), dim3(256), 0, s, a);
   if (a.i0)  // marker-driven: one workgroup per frame
     hipLaunchKernelGGL(pv_resample_frames, dim3((unsigned)(a.frames - a.first)), dim3(256), 0, s, a);
   else if (a.out_hi > a.out_lo)
-    hipLaunchKernelGGL(pv_resample, dim3((unsigned)((a.out_hi - a.out_lo + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pv_resample, dim3((unsigned)((a.out_hi - a.out_lo + 1023) / 1024)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_pv(const PvArgs &a, hipStream_t s) {
