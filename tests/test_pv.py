@@ -305,36 +305,46 @@ def test_gpu_marker_render_matches_oracle(gpu_ctx, pv, mk):
     a.free()
 
 
-@pytest.mark.gpu
-def test_gpu_output_pointers_need_not_be_aligned(gpu_ctx):
-    """mx_pv_pitch_shift_dev takes the caller's device pointers as they are: the resampler's 16- / 8-byte stores are for aligned
-    outputs only, anything else is written sample by sample — the same values either way.  (Device buffers through the HIP
-    runtime the library already loaded: no second runtime in the process.)"""
-    import ctypes as C
+_UNALIGNED_OUTPUTS = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+from conftest import SR, accum_sweep
+import melonix_amd as mx
+ctx = mx.Context(0)
+hip = C.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+n = 5 * SR + 3
+a = ctx.upload(accum_sweep(n))
+want_f, want_i = ctx.pv_pitch_shift(a, 3.0)
+assert np.abs(want_f).max() > 0.1
+df, di = C.c_void_p(), C.c_void_p()
+assert hip.hipMalloc(C.byref(df), (n + 8) * 4) == 0 and hip.hipMalloc(C.byref(di), (n + 8) * 2) == 0
+for off in (0, 1, 2, 3):
+    assert hip.hipMemset(df, 0x55, (n + 8) * 4) == 0 and hip.hipMemset(di, 0x55, (n + 8) * 2) == 0
+    ctx.pv_pitch_shift_dev(a, 3.0, df.value + 4 * off, di.value + 2 * off)
+    ctx.synchronize()
+    got_f, got_i = np.empty(n + 8, np.float32), np.empty(n + 8, np.int16)
+    assert hip.hipMemcpy(got_f.ctypes.data, df, (n + 8) * 4, 2) == 0 and hip.hipMemcpy(got_i.ctypes.data, di, (n + 8) * 2, 2) == 0
+    assert np.array_equal(got_f[off:off + n], want_f) and np.array_equal(got_i[off:off + n], want_i), off
+    pad = got_f.view(np.uint32)  # nothing outside the n samples was touched
+    assert (pad[:off] == 0x55555555).all() and (pad[off + n:] == 0x55555555).all()
+    assert (got_i[:off] == 0x5555).all() and (got_i[off + n:] == 0x5555).all()
+print("unaligned outputs ok")
+"""
 
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
-    hip.hipFree.argtypes = [C.c_void_p]
-    n = 5 * SR + 3
-    w = accum_sweep(n)
-    a = gpu_ctx.upload(w)
-    want_f, want_i = gpu_ctx.pv_pitch_shift(a, 3.0)
-    assert np.abs(want_f).max() > 0.1
-    df, di = C.c_void_p(), C.c_void_p()
-    assert hip.hipMalloc(C.byref(df), (n + 8) * 4) == 0 and hip.hipMalloc(C.byref(di), (n + 8) * 2) == 0
-    for off in (0, 1, 2, 3):
-        assert hip.hipMemset(df, 0x55, (n + 8) * 4) == 0 and hip.hipMemset(di, 0x55, (n + 8) * 2) == 0
-        gpu_ctx.pv_pitch_shift_dev(a, 3.0, df.value + 4 * off, di.value + 2 * off)
-        gpu_ctx.synchronize()
-        got_f, got_i = np.empty(n + 8, np.float32), np.empty(n + 8, np.int16)
-        assert hip.hipMemcpy(got_f.ctypes.data, df, (n + 8) * 4, 2) == 0 and hip.hipMemcpy(got_i.ctypes.data, di, (n + 8) * 2, 2) == 0
-        assert np.array_equal(got_f[off:off + n], want_f) and np.array_equal(got_i[off:off + n], want_i), off
-        # nothing outside the n samples was touched
-        pad = got_f.view(np.uint32)
-        assert (pad[:off] == 0x55555555).all() and (pad[off + n:] == 0x55555555).all()
-        assert (got_i[:off] == 0x5555).all() and (got_i[off + n:] == 0x5555).all()
-    hip.hipFree(df)
-    hip.hipFree(di)
-    a.free()
+
+@pytest.mark.gpu
+def test_gpu_output_pointers_need_not_be_aligned():
+    """mx_pv_pitch_shift_dev takes the caller's device pointers as they are: the resampler's 16- / 8-byte stores are for aligned
+    outputs only, anything else is written sample by sample — the same values either way.  In a process of its own: the
+    device buffers come from the HIP runtime the library loaded, and a test process that has imported torch holds a second one."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _UNALIGNED_OUTPUTS], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "unaligned outputs ok" in r.stdout, r.stderr[-2000:]
