@@ -34,12 +34,17 @@ UNITS = [
     ("grain_chain.hip", "hip", []),
     # build-defined phase vocoder: shares the FFT passes of stft_core.h (explicit FMAs)
     ("pv_kernels.hip", "hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
-    ("capi.cpp", "hip", []),
+    ("capi_ctx.cpp", "hip", []),
+    ("capi_stft.cpp", "hip", []),
+    ("capi_rows.cpp", "hip", []),
+    ("capi_pv.cpp", "hip", []),
+    ("capi_resynth.cpp", "hip", []),
+    ("capi_pyramid.cpp", "hip", []),
     # pure host logic: plain g++, no contraction, no -march (SURVEY §7 "Bit-exact schedule")
     ("host_logic.cpp", "cxx", ["-ffp-contract=off"]),
 ]
 HEADERS = ["kernels.h", "colormap_core.h", "stft_kernel_impl.h", "stft_core.h", "pk_math.h", "stft_tables.h", "stft_consts.inc",
-           "host_logic.h",
+           "host_logic.h", "capi_internal.h",
            os.path.join("..", "..", "include", "melonix_amd.h")]
 
 

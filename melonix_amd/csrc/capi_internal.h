@@ -1,0 +1,102 @@
+// capi_internal.h — what the units of the C-ABI implementation (capi_*.cpp) share: the context and audio handle
+// types, the error slot behind mx_last_error, the per-N table cache.  Not installed; include/melonix_amd.h is the boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <chrono>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/melonix_amd.h"
+#include "host_logic.h"
+#include "kernels.h"
+
+namespace mx {
+
+// records the message mx_last_error returns on this thread and hands `code` back
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return ::mx::fail(MX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct NTables {
+  float2 *tw2 = nullptr, *tw3 = nullptr, *ubase = nullptr;
+  float *wext = nullptr;  // d-indexed window weights, pre-scaled by 1/(2N)
+  std::vector<float> wext_host;
+};
+
+struct PvPipe;  // capi_pv.cpp: the phase vocoder's bounded work arena, streams and events
+
+}  // namespace mx
+
+struct mx_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::map<int, mx::NTables> tables;
+  std::map<std::pair<int, int>, float *> wtabs;  // (N, hop) -> forward weights
+  int frames_per_block = 0;  // 0 = per-N default
+  std::mutex mu;
+  // host landing zone of the zero-crossing bitmaps (mx_grains_dev), kept between calls: a copy into
+  // pages that are already mapped runs at PCIe rate, a fresh 2 x n/8-byte buffer pays ~3 ms of faults
+  std::mutex zc_mu;
+  mx::ZcBitmaps zc_scratch;
+  // device staging of the host-pointer entry points (mx_stft_ranges, mx_stft_hop, mx_stft_ranges_rgb*):
+  // grow-only buffers kept between calls — a screen-sized batch otherwise spends more time in
+  // hipMalloc/hipFree than in the kernel.  One host-staged call per context at a time.
+  std::mutex stage_mu;
+  struct Stage {
+    void *p = nullptr;
+    size_t cap = 0;
+  } stage[4];
+  // device work buffers of the grain chain (mx_grains_dev): the two predicate bitmaps, the rank tables, the lifting
+  // tables — kept between calls like the staging buffers (guarded by zc_mu)
+  Stage chain[4];
+  // work buffers of the phase vocoder (tens of GB for an hour of audio): hipMalloc of that size takes of the
+  // order of a second, so the arena is kept for the next call; mx_ctx_destroy releases it
+  std::mutex pv_mu;
+  Stage pv_arena;
+  // the staged (one rank of a multi-GPU run) phase-vocoder job between mx_pv_shard_analyze and _finish
+  mx::PvArgs pv_job{};
+  bool pv_job_active = false, pv_job_last = false;
+  char *pv_slot_carry = nullptr, *pv_slot_prev_tail = nullptr, *pv_slot_next_head = nullptr;
+};
+
+struct mx_audio {
+  float *d_padded = nullptr;
+  int64_t n = 0;
+  bool owned = false;
+};
+
+namespace mx {
+
+int default_frames_per_block(int N, int mode, int hop, int64_t count);
+int get_tables(mx_ctx *ctx, int N, NTables &out);
+int get_wtab(mx_ctx *ctx, int N, int hop, const NTables &nt, const float **out);
+int check_common(mx_ctx *ctx, const mx_audio *a, int N, int64_t count, int &kmin, int &kmax);
+int stft_launch(mx_ctx *ctx, const mx_audio *a, int N, int mode, int hop, int64_t first_frame, const int32_t *d_ranges,
+                int64_t count, int kmin, int kmax, float *d_mags, mx_pitch *d_pitch, uint8_t *d_rgb, float cmap_k,
+                int run_length = 0);
+// frames per host-staging chunk: keep the device staging buffer <= ~1 GiB
+int64_t chunk_frames(int N);
+// Staging slot `i` with room for `bytes` (contents undefined).  Caller holds ctx->stage_mu.
+hipError_t stage_get(mx_ctx *ctx, int i, size_t bytes, void **out);
+// Bulk jobs stage up to 1 GiB per buffer: give those back, keep what a screen of columns needs.
+void stage_trim(mx_ctx *ctx);
+// phase-vocoder arena of a context (capi_pv.cpp); called by mx_ctx_destroy / mx_ctx_release_scratch with pv_mu held or
+// with the context quiescent
+void pv_release(mx_ctx *ctx);
+
+}  // namespace mx

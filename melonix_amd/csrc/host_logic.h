@@ -1,7 +1,7 @@
 // host_logic.h — the serial, scalar part of the hot path that stays on the host:
 // marker time maps, grain chain, the cursor recurrence of the export loop and
 // the RIFF writer.  These are the product's own implementations (C++17), used
-// by capi.cpp; they feed the GPU kernels with the per-step schedule.
+// by capi_*.cpp; they feed the GPU kernels with the per-step schedule.
 //
 // Reference (relative to the reference tree): app.cpp:1020-1122 (time maps),
 // app.cpp:153-235 (grains), app.cpp:294-331 + 1200-1207 (cursor recurrence),

@@ -1,4 +1,4 @@
-// kernels.h — internal launch interface between the C-ABI layer (capi.cpp) and
+// kernels.h — internal launch interface between the C-ABI layer (capi_*.cpp) and
 // the gfx950 kernels (*.hip).  Not part of the public boundary.
 #pragma once
 #include <hip/hip_runtime.h>

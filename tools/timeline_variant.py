@@ -32,7 +32,7 @@ def main():
             shutil.copy(os.path.join(ROOT, "melonix_amd", f), os.path.join(tmp, "melonix_amd", f))
     os.makedirs(os.path.join(tmp, "melonix_amd", "build"))
     for f in os.listdir(os.path.join(ROOT, "melonix_amd", "build")):
-        if f.endswith(".o") and not f.startswith(("stft_kernels", "capi")):
+        if f.endswith(".o") and not f.startswith(("stft_kernels", "capi_ctx")):
             shutil.copy(os.path.join(ROOT, "melonix_amd", "build", f), os.path.join(tmp, "melonix_amd", "build", f))
 
     p = os.path.join(tmp, "melonix_amd", "csrc", "stft_kernel_impl.h")
@@ -58,7 +58,7 @@ def main():
               "    MX_STAMP(12);\n    if constexpr (!DEFER && !DIRECT) {\n      if (want_rows) {\n        MX_BARRIER();")
     open(p, "w").write(s)
 
-    p = os.path.join(tmp, "melonix_amd", "csrc", "capi.cpp")
+    p = os.path.join(tmp, "melonix_amd", "csrc", "capi_ctx.cpp")  # stft_launch lives in the context unit
     s = open(p).read()
     s = patch(s, "  s.rgb = d_rgb;",
               "  s.rgb = d_rgb;\n"
