@@ -74,7 +74,7 @@ int mx_ctx_set_stream(mx_ctx *ctx, void *hip_stream);
 int mx_ctx_use_own_stream(mx_ctx *ctx);
 int mx_ctx_synchronize(mx_ctx *ctx);
 /* The context keeps its work buffers between calls (device staging of the host-pointer entry points, the phase
- * vocoder's arena — tens of GB for an hour of audio —, the host landing zone of mx_grains_dev); this releases them.
+ * vocoder's arena — 2.4 GB whatever the signal's length —, the host landing zone of mx_grains_dev); this releases them.
  * mx_ctx_destroy does so too. */
 int mx_ctx_release_scratch(mx_ctx *ctx);
 /* Run length: consecutive frames one workgroup of a bulk (uniform-hop) launch walks.  The sliding-window kernels
@@ -270,8 +270,20 @@ int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate,
  * Parity is unpinned by construction: the only oracle is the build's own CPU restatement. */
 int mx_pv_pitch_shift(mx_ctx *ctx, const mx_audio *a, double semitones, float *pcm_f32_out,
                       int16_t *pcm_i16_out);
-/* Same, outputs stay in HBM (either may be NULL); blocks until done.  The work buffers (about 44 KiB per
- * 256 output samples) stay with the context for the next call and are released by mx_ctx_destroy. */
+/* Same, outputs stay in HBM (either may be NULL); blocks until done.
+ * WORK ARENA: bounded, whatever the signal's length.  The vocoder walks the signal in chunks of 32768 frames (8.4 M
+ * stretched samples) through two slots of spectra + peak records (32.3 KiB per frame of a chunk) and a ring of three
+ * stretched-signal buffers: 2.36 GB in one allocation, made at the first call, kept by the context for the next one and
+ * released by mx_ctx_release_scratch / mx_ctx_destroy; MX_ERR_NOMEM (checked against hipMemGetInfo before allocating) if
+ * the device cannot give that much.  Chunks meet on multiples of 32 frames — the synthesis workgroups — and hand each
+ * other the phase row and the overlap-add seam the way the ranks of a multi-GPU run do (below): the output is bit-identical
+ * whatever the chunk length.  mx_pv_set_chunk_frames changes it (rounded up to a multiple of 32; 0 = the default; the
+ * environment variable MELONIX_PV_CHUNK_FRAMES sets the default): a smaller arena for a small GPU share, or a test that
+ * wants many chunk boundaries in a short signal.  mx_pv_arena_bytes: what the context holds right now (0 before the
+ * first call).  While a call runs, a second internal stream carries the next chunk's analysis; both are joined before
+ * the call returns. */
+int mx_pv_set_chunk_frames(mx_ctx *ctx, int64_t frames);
+int64_t mx_pv_arena_bytes(mx_ctx *ctx);
 int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32,
                           int16_t *d_pcm_i16);
 
@@ -294,7 +306,11 @@ int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_ma
  * input and takes a contiguous range of frames (boundaries on multiples of 32 frames, so the sums group exactly
  * as in a single-GPU run and the concatenated outputs are bit-identical to mx_pv_pitch_shift's).  The caller does
  * the two small exchanges between the stages with its own collective (melonix_amd/shard.py: RCCL / gloo
- * all-gathers): the per-rank phase totals after stage 1, the seams after stage 2.
+ * all-gathers): the per-rank phase totals after stage 1, the seams after stage 2.  A rank walks its range through the
+ * same bounded arena as a single GPU walks the whole signal; a rank whose range is longer than one chunk therefore
+ * analyses its frames twice (stage 1 keeps the maps only, stage 2 analyses again with the carry), a range of one chunk
+ * once.  Between stage 2 and stage 3 the rank's outputs wait on the device (6 bytes per output sample).  Every rank needs
+ * at least 32 frames of its own.
  *   mx_pv_shard_frames      the rank's frame range and the output samples [out_lo, out_hi) it will deliver
  *   mx_pv_shard_analyze     stage 1; tot_sums_out[2048] / tot_org_out[2048]: this rank's frames as one map of the
  *                           phase row: bin k ends at value[org[k]] + sums[k] (mod 2^32), or at sums[k] where

@@ -259,6 +259,14 @@ class Context:
         _capi.check(_capi.lib().mx_resynth_dev(self.handle, audio.handle, C.c_void_p(d_steps), nsteps, nsamples,
                                                C.c_void_p(d_f32 or 0), C.c_void_p(d_i16 or 0)))
 
+    def pv_set_chunk_frames(self, frames: int):
+        """Frames per chunk of the phase vocoder's pipeline (rounded up to a multiple of 32; 0 = the default, 32768)."""
+        _capi.check(_capi.lib().mx_pv_set_chunk_frames(self.handle, int(frames)))
+
+    def pv_arena_bytes(self) -> int:
+        """Bytes of the phase vocoder's work arena this context holds (0 before the first call)."""
+        return int(_capi.lib().mx_pv_arena_bytes(self.handle))
+
     def pv_pitch_shift(self, audio: Audio, semitones: float, want_f32: bool = True, want_i16: bool = True):
         """Build-defined phase-vocoder pitch shift (no reference counterpart) -> (f32 | None, int16 | None)."""
         f32 = np.empty(audio.n, dtype=np.float32) if want_f32 else None

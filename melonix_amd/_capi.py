@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmelonix_amd.so")
+_DEFAULT_LIB_PATH = LIB_PATH  # (tools that A/B another build point LIB_PATH elsewhere: no identity check there)
 
 MX_OK = 0
 MX_ERR_INVALID, MX_ERR_DEVICE, MX_ERR_NOMEM, MX_ERR_IO = -1, -2, -3, -4
@@ -99,6 +100,8 @@ SIGNATURES = {
     "mx_resynth_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mx_resynth_to_wav": (_i, [_vp, _vp, _vp, _i64, _i64, C.c_char_p, _i, _i]),
     "mx_export_wav": (_i, [_vp, _vp, _i64, _i, _vp, _i, C.c_char_p, _i]),
+    "mx_pv_set_chunk_frames": (_i, [_vp, _i64]),
+    "mx_pv_arena_bytes": (_i64, [_vp]),
     "mx_pv_pitch_shift": (_i, [_vp, _vp, _d, _vp, _vp]),
     "mx_pv_pitch_shift_dev": (_i, [_vp, _vp, _d, _vp, _vp]),
     "mx_pv_render_length": (_i64, [_i64, _i, _vp, _i]),
@@ -132,8 +135,30 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        check_identity(L.mx_version().decode(), LIB_PATH)
         _LIB = L
     return _LIB
+
+
+def library_src_sha(version: str) -> str:
+    """The `src:<12 hex>` digits of an mx_version() string ('' if it carries none)."""
+    tail = version.rsplit("src:", 1)
+    return tail[1].strip() if len(tail) == 2 else ""
+
+
+def check_identity(version: str, path: str) -> None:
+    """A library that was not built from the sources beside it is refused: the GPU box runs whatever .so travelled with the
+    snapshot, and a kernel edit without a rebuild would otherwise be measured (and graded) as the old kernel.
+    MELONIX_ALLOW_STALE=1 loads it anyway (A/B runs against an older build: tools/ab_variant.sh, MX_AB_LIB)."""
+    from . import build as _build
+
+    if os.environ.get("MELONIX_ALLOW_STALE") == "1" or os.path.abspath(path) != os.path.abspath(_DEFAULT_LIB_PATH):
+        return
+    want, have = _build.source_sha(), library_src_sha(version)
+    if have != want:
+        raise ImportError(
+            f"{path} was built from other sources than the ones beside it (library src:{have or '?'}, tree src:{want}): "
+            "rebuild with `python -m melonix_amd.build`, or set MELONIX_ALLOW_STALE=1 to load it anyway.")
 
 
 def check(rc: int) -> None:

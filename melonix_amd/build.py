@@ -6,6 +6,7 @@ than the library.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -43,9 +44,25 @@ UNITS = [
     # pure host logic: plain g++, no contraction, no -march (SURVEY §7 "Bit-exact schedule")
     ("host_logic.cpp", "cxx", ["-ffp-contract=off"]),
 ]
+IDENTITY_UNIT = "capi_ctx.cpp"
 HEADERS = ["kernels.h", "colormap_core.h", "stft_kernel_impl.h", "stft_core.h", "pk_math.h", "stft_tables.h", "stft_consts.inc",
            "host_logic.h", "capi_internal.h",
            os.path.join("..", "..", "include", "melonix_amd.h")]
+
+
+def source_sha(csrc: str | None = None, extra_defines: list[str] | None = None) -> str:
+    """Identity of a build: sha1 over every source and header the library is made of (names and bytes, in a fixed order)
+    and the compile flags.  build() bakes the first 12 hex digits into the library (mx_version() ends in `src:<12 hex>`);
+    melonix_amd._capi.lib() refuses a library whose digits differ from the tree it is loaded from."""
+    csrc = csrc or CSRC
+    h = hashlib.sha1()
+    for name in sorted([u[0] for u in UNITS] + HEADERS):
+        h.update(os.path.basename(name).encode() + b"\0")
+        with open(os.path.join(csrc, name), "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(repr((ARCH, COMMON, [(u[0], u[1], u[2]) for u in UNITS], sorted(extra_defines or []))).encode())
+    return h.hexdigest()[:12]
 
 
 def _newest_header() -> float:
@@ -56,16 +73,23 @@ def build(force: bool = False, verbose: bool = False, extra_defines: list[str] |
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hdr_t = _newest_header()
+    sha = source_sha(extra_defines=extra_defines)
+    sha_file = os.path.join(OBJDIR, "src_sha.txt")
+    sha_was = open(sha_file).read().strip() if os.path.exists(sha_file) else ""
     objs, relink = [], force or not os.path.exists(LIB)
     for src, kind, extra in UNITS:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
         objs.append(op)
         stale = force or (not os.path.exists(op)) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t)
+        ident = src == IDENTITY_UNIT  # the unit that carries the digits: rebuilt whenever they change
+        if ident and sha != sha_was:
+            stale = True
         if not stale:
             continue
         if kind == "hip":
-            cmd = [HIPCC, f"--offload-arch={ARCH}", "-x", "hip"] + COMMON + extra + (extra_defines or []) + ["-c", sp, "-o", op]
+            cmd = [HIPCC, f"--offload-arch={ARCH}", "-x", "hip"] + COMMON + extra + (extra_defines or []) + \
+                  ([f'-DMX_SRC_SHA="{sha}"'] if ident else []) + ["-c", sp, "-o", op]
         else:
             cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-Wall"] + extra + ["-c", sp, "-o", op]
         if verbose:
@@ -77,6 +101,8 @@ def build(force: bool = False, verbose: bool = False, extra_defines: list[str] |
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    with open(sha_file, "w") as fh:
+        fh.write(sha + "\n")
     return LIB
 
 

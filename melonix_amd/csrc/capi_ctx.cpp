@@ -181,7 +181,11 @@ void stage_trim(mx_ctx *ctx) {
 extern "C" {
 
 const char *mx_last_error(void) { return g_err.c_str(); }
-const char *mx_version(void) { return "melonix_amd 0.1.0 gfx950"; }
+// (MX_SRC_SHA: melonix_amd/build.py source_sha() — 12 hex digits of the sha1 over the library's sources and compile flags)
+#ifndef MX_SRC_SHA
+#define MX_SRC_SHA "unknown"
+#endif
+const char *mx_version(void) { return "melonix_amd 0.1.0 gfx950 src:" MX_SRC_SHA; }
 
 int mx_ctx_create(int device, mx_ctx **out) {
   if (!out) return fail(MX_ERR_INVALID, "out is null");
@@ -224,7 +228,7 @@ void mx_ctx_destroy(mx_ctx *ctx) {
   for (auto &kv : ctx->wtabs) hipFree(kv.second);
   for (auto &st : ctx->stage) hipFree(st.p);
   for (auto &st : ctx->chain) hipFree(st.p);
-  hipFree(ctx->pv_arena.p);
+  pv_release(ctx);
   hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -259,9 +263,7 @@ int mx_ctx_release_scratch(mx_ctx *ctx) {
   }
   {
     std::lock_guard<std::mutex> lk(ctx->pv_mu);
-    hipFree(ctx->pv_arena.p);
-    ctx->pv_arena = {};
-    ctx->pv_job_active = false;  // a staged phase-vocoder job lives in that arena
+    pv_release(ctx);  // (a staged multi-GPU job lives in that arena: it ends here)
   }
   {
     std::lock_guard<std::mutex> lk(ctx->zc_mu);

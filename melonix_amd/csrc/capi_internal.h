@@ -64,14 +64,11 @@ struct mx_ctx {
   // device work buffers of the grain chain (mx_grains_dev): the two predicate bitmaps, the rank tables, the lifting
   // tables — kept between calls like the staging buffers (guarded by zc_mu)
   Stage chain[4];
-  // work buffers of the phase vocoder (tens of GB for an hour of audio): hipMalloc of that size takes of the
-  // order of a second, so the arena is kept for the next call; mx_ctx_destroy releases it
+  // the phase vocoder's bounded work arena, second stream and events (capi_pv.cpp): built on first use, kept for the next
+  // call, released by mx_ctx_release_scratch / mx_ctx_destroy; pv_chunk_frames = 0: the default chunk length
   std::mutex pv_mu;
-  Stage pv_arena;
-  // the staged (one rank of a multi-GPU run) phase-vocoder job between mx_pv_shard_analyze and _finish
-  mx::PvArgs pv_job{};
-  bool pv_job_active = false, pv_job_last = false;
-  char *pv_slot_carry = nullptr, *pv_slot_prev_tail = nullptr, *pv_slot_next_head = nullptr;
+  mx::PvPipe *pv = nullptr;
+  int64_t pv_chunk_frames = 0;
 };
 
 struct mx_audio {
@@ -95,8 +92,8 @@ int64_t chunk_frames(int N);
 hipError_t stage_get(mx_ctx *ctx, int i, size_t bytes, void **out);
 // Bulk jobs stage up to 1 GiB per buffer: give those back, keep what a screen of columns needs.
 void stage_trim(mx_ctx *ctx);
-// phase-vocoder arena of a context (capi_pv.cpp); called by mx_ctx_destroy / mx_ctx_release_scratch with pv_mu held or
-// with the context quiescent
+// gives the phase vocoder's arena, stream and events back (capi_pv.cpp); the caller holds ctx->pv_mu or owns the context
+// outright (mx_ctx_destroy)
 void pv_release(mx_ctx *ctx);
 
 }  // namespace mx

@@ -1,14 +1,38 @@
 // capi_pv.cpp — the build-defined phase-vocoder pitch shift (no reference counterpart).
 // One unit of the C-ABI implementation behind include/melonix_amd.h (see capi_internal.h).  There is no CPU compute path:
 // every transform entry point needs a live gfx950 device and fails with MX_ERR_DEVICE otherwise.
+//
+// The vocoder walks the signal CHUNK BY CHUNK through a work arena whose size does not depend on the signal's length
+// (round 5; rounds 1-4 laid the whole signal's spectra, records and offsets out at once: 41 KiB per frame, 33 GB for an
+// hour at +3 st, and an 8-hour signal did not fit the GPU).  What one chunk hands the next is what one rank of a
+// multi-GPU run hands its neighbour (pv_kernels.hip, mx_pv_shard_*): the frame before the chunk is analysed again as its
+// row 0, the dense offset row behind the chunk's last frame is the next chunk's carry_in, and the N - Hs samples across
+// the boundary are the left chunk's raw tail plus the right chunk's raw head.  Chunks start on multiples of 32 frames
+// (= the synthesis workgroups), so every float sum groups exactly as in one launch over the whole signal: outputs are
+// bit-identical whatever the chunk length (tests/test_pv.py::test_gpu_chunked_equals_whole).
+//
+//   the context's stream   the two big kernels, one at a time:  A(0) A(1) S(0) A(2) S(1) A(3) S(2) ...
+//   a side stream          everything small, beside an analysis: while A(k + 1) runs, the first-frame records, chunk maps
+//                          and offsets of chunk k (pv_heads, pv_lock_walk, pv_lock_chunks), then pv_fixup + pv_resample of
+//                          chunk k - 2
+// Two slots of spectra + records alternate (chunk k + 1's analysis follows chunk k - 1's synthesis on the stream); the
+// stretched signal and the workgroup halos of a chunk live in a ring of four.  Why nothing runs beside a synthesis, and
+// why the two big kernels do not overlap each other: profiles/timeline_r05_pv_pipeline.log.
 #include "capi_internal.h"
 #include "stft_tables.h"
 
 using namespace mx;
 
-// ---- build-defined phase-vocoder pitch shift (no reference counterpart) ---------------------------
+namespace mx {
+
 namespace {
 constexpr int kPvN = 4096, kPvM = kPvN / 2, kPvHs = 256, kPvSeam = kPvN - kPvHs;
+constexpr int64_t kPvDefaultChunk = 32768;  // frames: two slots of 32.3 KiB per frame + the ring = 2.36 GB
+constexpr int64_t kPvMaxChunk = 1 << 22;
+constexpr int kPvMaxSlots = 4;
+constexpr int kPvOutRing = 4;  // chunk k's synthesis writes while chunk k - 2's fix-up reads k - 2, k - 1 (head) and k - 3 (boundary)
+constexpr int kPvMinScan = 64;              // frames per scan chunk of the phase recurrence, at least
+constexpr int64_t kPvMaxScanChunks = 1536;  // one round of row-walking workgroups, six per CU
 
 int64_t pv_frame_count(int64_t n, double r) { return (int64_t)std::ceil((double)n * r / kPvHs) + 1; }
 // smallest output sample whose interpolation base floor(i*r + N/2) reaches stretched sample q (same binary64
@@ -20,160 +44,478 @@ int64_t pv_first_output_at(int64_t q, double r, int64_t n) {
   while (i < n && (int64_t)std::floor((double)i * r + (double)(kPvN / 2)) < q) ++i;
   return i < n ? i : n;
 }
-
-// Lays out the work arena for frames [F_lo, F_hi) of the signal's F frames (plus, when F_lo > 0, the frame before
-// them as local row 0) and fills every PvArgs field but the output pointers.  Caller holds ctx->pv_mu.
-// `plan` (marker-driven variant, whole signal only): the analysis positions come from it instead of floor(f*Hs/r).
-int pv_prepare(mx_ctx *ctx, const mx_audio *a, double semitones, int64_t F_lo, int64_t F_hi, bool want_totals,
-               PvArgs &p, const PvPlan *plan = nullptr) {
-  constexpr int N = kPvN, M = kPvM, Hs = kPvHs;
-  HIP_TRY(hipSetDevice(ctx->device));  // before any table allocation: HIP's current device is per thread
-  NTables t;
-  int rc = get_tables(ctx, N, t);
-  if (rc) return rc;
-  const double r = std::pow(2.0, semitones / 12.0);
-  const int64_t first = F_lo > 0 ? 1 : 0;
-  const int64_t Fl = F_hi - F_lo + first;  // local rows
-  // the constant-ratio plan (analysis positions, hops, Hs/hop) is written on the device; a marker plan comes from the host
-  std::vector<uint32_t> hop;
-  std::vector<double> hratio;
-  if (plan) {
-    hop.assign((size_t)Fl, 0u);
-    hratio.assign((size_t)Fl, 0.0);
-    for (int64_t j = 1; j < Fl; ++j) {
-      const int64_t h = plan->apos[(size_t)j] - plan->apos[(size_t)j - 1];
-      if (h >= 1 && h <= 0x7fffffffLL) {
-        hop[(size_t)j] = (uint32_t)h;
-        hratio[(size_t)j] = (double)Hs / (double)h;
-      }
-    }
-  }
-  std::vector<float> hann((size_t)N), hann_sc((size_t)N);
-  for (int j = 0; j < N; ++j) {
-    hann[(size_t)j] = (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * j / N));
-    hann_sc[(size_t)j] = hann[(size_t)j] * fold_scale(N);  // exact: a power of two
-  }
-  std::vector<float2> wsplit((size_t)M);
-  for (int c = 0; c < M; ++c) {
-    const double ang = 2.0 * 3.14159265358979323846 * c / N;
-    wsplit[(size_t)c] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-  }
-  p = PvArgs{};
-  p.audio = a->d_padded;
-  p.n = a->n;
-  p.ratio = r;
-  p.frames = Fl;
-  p.first = first;
-  p.global_first = F_lo == 0;
-  p.tw2 = t.tw2;
-  p.tw3 = t.tw3;
-  p.ubase = t.ubase;
-  // chunks of the frame axis for the scan: about 1536 of them (their maps are composed in groups of 32), at least 64 frames each
-  p.scan_chunk = (int)std::max<int64_t>(64, (Fl - first + 1535) / 1536);  // (one round of row-walking workgroups, six per CU)
-  p.s_len = (Fl - first) * Hs + N;
-  p.s_origin = F_lo * Hs;
-  const int64_t nchunks = (Fl - first + p.scan_chunk - 1) / p.scan_chunk;
-  // one arena: apos, the two windows, the complex spectra, the peak records, the peaks' synthesis offsets, chunk sums,
-  // boundary halos, s (+1 for s[m+1]), split twiddles, source bins of the chunk maps, peak maps and counts, this rank's
-  // total map, carry-in, the neighbours' seams.  (Records and offsets have room for a peak in every bin — silence, an
-  // impulse — but only a frame's first pkcount entries are ever touched.)
-  const size_t rowsz = (size_t)Fl * M;
-  size_t off = 0;
-  auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_apos = take((size_t)Fl * 8), o_h = take(N * 4), o_hs = take(N * 4), o_m = take(rowsz * 8),
-               o_p = take(rowsz * 8), o_i = take(rowsz * 4), o_pc = take((size_t)Fl * 4), o_ft = take((size_t)Fl * 4), o_c = take((size_t)nchunks * M * 4),
-               o_gs = take((size_t)((nchunks + 31) / 32) * M * 4), o_go = take((size_t)((nchunks + 31) / 32) * M * 2),
-               o_f = take((size_t)pv_halo_floats(Fl - first) * 4), o_s = take(((size_t)p.s_len + 1) * 4),
-               o_w = take((size_t)M * 8), o_a = take((size_t)nchunks * M * 2), o_ow = take((size_t)Fl * (M / 32) * 4),
-               o_ts = take((size_t)M * 4), o_ta = take((size_t)M * 2), o_ci = take((size_t)M * 4),
-               o_pt = take((size_t)kPvSeam * 4), o_nh = take((size_t)kPvSeam * 4),
-               o_tf = take(plan ? (size_t)Fl * 8 : 0), o_rf = take(plan ? (size_t)Fl * 8 : 0),
-               o_i0 = take(plan ? ((size_t)Fl + 1) * 8 : 0), o_hp = take((size_t)Fl * 4), o_hr = take((size_t)Fl * 8);
-  if (ctx->pv_arena.cap < off) {
-    if (ctx->pv_arena.p) hipFree(ctx->pv_arena.p);
-    ctx->pv_arena = {};
-    const hipError_t em = hipMalloc(&ctx->pv_arena.p, off);
-    if (em != hipSuccess) {
-      ctx->pv_arena = {};
-      return fail(MX_ERR_NOMEM, "phase-vocoder work buffers (%zu MiB): %s", off >> 20, hipGetErrorString(em));
-    }
-    ctx->pv_arena.cap = off;
-  }
-  char *arena = static_cast<char *>(ctx->pv_arena.p);
-  hipError_t e = plan ? hipMemcpyAsync(arena + o_apos, plan->apos.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream)
-                      : launch_pv_plan_const(reinterpret_cast<int64_t *>(arena + o_apos), reinterpret_cast<uint32_t *>(arena + o_hp),
-                                             reinterpret_cast<double *>(arena + o_hr), Fl, F_lo - first, r, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(arena + o_h, hann.data(), N * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hs, hann_sc.data(), N * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(arena + o_w, wsplit.data(), (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream);
-  // the last hop of s is beyond every frame, and s[s_len] backs the interpolation's m+1
-  if (e == hipSuccess) e = hipMemsetAsync(arena + o_s + (size_t)(p.s_len - Hs) * 4, 0, (size_t)(Hs + 1) * 4, ctx->stream);
-  if (plan) {
-    if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hp, hop.data(), (size_t)Fl * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(arena + o_hr, hratio.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
-  }
-  if (plan) {
-    if (e == hipSuccess) e = hipMemcpyAsync(arena + o_tf, plan->tf.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(arena + o_rf, plan->rf.data(), (size_t)Fl * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(arena + o_i0, plan->i0.data(), ((size_t)Fl + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host tables above die with this frame
-  if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder setup: %s", hipGetErrorString(e));
-  p.chunk_org = reinterpret_cast<uint16_t *>(arena + o_a);
-  p.pkmap = reinterpret_cast<uint32_t *>(arena + o_ow);
-  p.apos = reinterpret_cast<const int64_t *>(arena + o_apos);
-  p.hop = reinterpret_cast<const uint32_t *>(arena + o_hp);
-  p.hratio = reinterpret_cast<const double *>(arena + o_hr);
-  p.hann = reinterpret_cast<const float *>(arena + o_h);
-  p.hann_scaled = reinterpret_cast<const float *>(arena + o_hs);
-  p.xrows = reinterpret_cast<float2 *>(arena + o_m);
-  p.recs = reinterpret_cast<uint2 *>(arena + o_p);
-  p.cvals = reinterpret_cast<uint32_t *>(arena + o_i);
-  p.pkcount = reinterpret_cast<uint32_t *>(arena + o_pc);
-  p.fthr = reinterpret_cast<float *>(arena + o_ft);
-  p.chunk_sums = reinterpret_cast<uint32_t *>(arena + o_c);
-  p.group_sums = reinterpret_cast<uint32_t *>(arena + o_gs);
-  p.group_org = reinterpret_cast<uint16_t *>(arena + o_go);
-  p.halo = reinterpret_cast<float *>(arena + o_f);
-  p.wsplit = reinterpret_cast<const float2 *>(arena + o_w);
-  p.s = reinterpret_cast<float *>(arena + o_s);
-  if (plan) {
-    p.tf = reinterpret_cast<const double *>(arena + o_tf);
-    p.rf = reinterpret_cast<const double *>(arena + o_rf);
-    p.i0 = reinterpret_cast<const int64_t *>(arena + o_i0);
-  }
-  if (want_totals) {
-    p.tot_sums = reinterpret_cast<uint32_t *>(arena + o_ts);
-    p.tot_org = reinterpret_cast<uint16_t *>(arena + o_ta);
-  }
-  // slots the staged (multi-GPU) entry points fill from host data
-  ctx->pv_slot_carry = arena + o_ci;
-  ctx->pv_slot_prev_tail = arena + o_pt;
-  ctx->pv_slot_next_head = arena + o_nh;
-  return MX_OK;
-}
 }  // namespace
 
+struct PvPipe {
+  int64_t C = 0;  // frames per chunk (a multiple of 32); a slot has room for C + 32 frames and the row before them
+  char *base = nullptr;
+  size_t bytes = 0;
+  // constants: the two windows, the split twiddles of the inverse transform
+  float *hann = nullptr, *hann_scaled = nullptr;
+  float2 *wsplit = nullptr;
+  struct Slot {  // what the analysis of a chunk leaves and its synthesis reads
+    int64_t *apos;
+    uint32_t *hop;
+    double *hratio;
+    float2 *xrows;
+    uint2 *recs;
+    uint32_t *pkmap, *pkcount;
+    float *fthr;
+    uint32_t *chunk_sums, *group_sums, *tot_sums;
+    uint16_t *chunk_org, *group_org, *tot_org;
+  } slot[kPvMaxSlots];
+  int NS = 2;  // slots in use
+  int analysis_run = 0;  // frames per analysis workgroup (0: the kernels' default)
+  struct Out {  // what the synthesis of a chunk leaves and the fix-up / resampler read (+ the resampler's plan rows)
+    float *halo, *s;
+    double *tf, *rf;
+    int64_t *i0;
+  } out[kPvOutRing];
+  uint32_t *carry[2];  // the dense offset row behind chunk k's last frame: carry[k & 1]
+  // one rank of a multi-GPU run: what it gets from its neighbours and owes them
+  uint32_t *carry_in = nullptr;
+  float *prev_tail = nullptr, *next_head = nullptr, *head_raw = nullptr, *tail_raw = nullptr, *edge_head = nullptr, *edge_tail = nullptr;
+  hipStream_t ss = nullptr, sf = nullptr;  // the side streams: the recurrence; fix-up + resampling
+  int min_scan = kPvMinScan;
+  hipEvent_t ev_begin = nullptr, ev_fin = nullptr, ev_an[kPvMaxSlots] = {}, ev_lock[kPvMaxSlots] = {}, ev_syn[kPvMaxSlots] = {},
+             ev_plan[kPvMaxSlots] = {};
+  // the staged job between mx_pv_shard_analyze and _finish
+  struct Shard {
+    bool active = false, first = false, last = false, single = false;
+    const mx_audio *a = nullptr;
+    double semitones = 0., r = 1.;
+    int64_t F_lo = 0, F_hi = 0, out_lo = 0, out_hi = 0;
+    bool synthesized = false;
+    int64_t head_hi = 0, tail_lo = 0;  // the outputs [out_lo, head_hi) and [tail_lo, out_hi) wait for the neighbours' seams
+    float *d_f = nullptr;  // the rank's outputs between stage 2 and stage 3 (device)
+    int16_t *d_i = nullptr;
+  } job;
+};
+
+namespace {
+
+size_t pv_layout(PvPipe &p, int64_t C, char *base) {
+  const int64_t rows = C + 32 + 1;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return base ? base + o : nullptr;
+  };
+  p.hann = reinterpret_cast<float *>(take(kPvN * 4));
+  p.hann_scaled = reinterpret_cast<float *>(take(kPvN * 4));
+  p.wsplit = reinterpret_cast<float2 *>(take(kPvM * 8));
+  const size_t nmaps = (size_t)kPvMaxScanChunks + 1, ngroups = (nmaps + 31) / 32;
+  for (int si = 0; si < p.NS; ++si) {
+    PvPipe::Slot &sl = p.slot[si];
+    sl.apos = reinterpret_cast<int64_t *>(take((size_t)rows * 8));
+    sl.hop = reinterpret_cast<uint32_t *>(take((size_t)rows * 4));
+    sl.hratio = reinterpret_cast<double *>(take((size_t)rows * 8));
+    sl.xrows = reinterpret_cast<float2 *>(take((size_t)rows * kPvM * 8));
+    // (room for a peak in every bin — silence, an impulse —: only a frame's first pkcount records are ever touched)
+    sl.recs = reinterpret_cast<uint2 *>(take((size_t)rows * kPvM * 8));
+    sl.pkmap = reinterpret_cast<uint32_t *>(take((size_t)rows * (kPvM / 32) * 4));
+    sl.pkcount = reinterpret_cast<uint32_t *>(take((size_t)rows * 4));
+    sl.fthr = reinterpret_cast<float *>(take((size_t)rows * 4));
+    sl.chunk_sums = reinterpret_cast<uint32_t *>(take(nmaps * kPvM * 4));
+    sl.chunk_org = reinterpret_cast<uint16_t *>(take(nmaps * kPvM * 2));
+    sl.group_sums = reinterpret_cast<uint32_t *>(take(ngroups * kPvM * 4));
+    sl.group_org = reinterpret_cast<uint16_t *>(take(ngroups * kPvM * 2));
+    sl.tot_sums = reinterpret_cast<uint32_t *>(take(kPvM * 4));
+    sl.tot_org = reinterpret_cast<uint16_t *>(take(kPvM * 2));
+  }
+  for (auto &o : p.out) {
+    o.halo = reinterpret_cast<float *>(take((size_t)pv_halo_floats(C + 32) * 4));
+    o.s = reinterpret_cast<float *>(take(((size_t)(C + 32) * kPvHs + kPvN + 8) * 4));
+    o.tf = reinterpret_cast<double *>(take((size_t)rows * 8));
+    o.rf = reinterpret_cast<double *>(take((size_t)rows * 8));
+    o.i0 = reinterpret_cast<int64_t *>(take((size_t)(rows + 1) * 8));
+  }
+  for (auto &c : p.carry) c = reinterpret_cast<uint32_t *>(take(kPvM * 4));
+  p.carry_in = reinterpret_cast<uint32_t *>(take(kPvM * 4));
+  p.prev_tail = reinterpret_cast<float *>(take(kPvSeam * 4));
+  p.next_head = reinterpret_cast<float *>(take(kPvSeam * 4));
+  p.head_raw = reinterpret_cast<float *>(take(kPvSeam * 4));
+  p.tail_raw = reinterpret_cast<float *>(take(kPvSeam * 4));
+  p.edge_head = reinterpret_cast<float *>(take((kPvSeam + 8) * 4));
+  p.edge_tail = reinterpret_cast<float *>(take((kPvSeam + 8) * 4));
+  return off;
+}
+
+void pv_shard_drop(PvPipe &p) {
+  hipFree(p.job.d_f);
+  hipFree(p.job.d_i);
+  p.job = PvPipe::Shard{};
+}
+
+int64_t pv_chunk_setting(const mx_ctx *ctx) {
+  int64_t C = ctx->pv_chunk_frames;
+  if (C <= 0)
+    if (const char *e = getenv("MELONIX_PV_CHUNK_FRAMES")) C = atoll(e);
+  if (C <= 0) C = kPvDefaultChunk;
+  C = std::min<int64_t>(kPvMaxChunk, (C + 31) / 32 * 32);
+  return C;
+}
+
+// The pipe of the context, built (or rebuilt for another chunk length) on demand.  Caller holds ctx->pv_mu.
+int pv_pipe(mx_ctx *ctx, PvPipe **out) {
+  HIP_TRY(hipSetDevice(ctx->device));  // HIP's current device is per thread
+  const int64_t C = pv_chunk_setting(ctx);
+  if (ctx->pv && ctx->pv->C == C) {
+    *out = ctx->pv;
+    return MX_OK;
+  }
+  pv_release(ctx);
+  std::unique_ptr<PvPipe> p(new (std::nothrow) PvPipe());
+  if (!p) return fail(MX_ERR_NOMEM, "out of host memory");
+  p->C = C;
+  if (const char *e = getenv("MELONIX_PV_SLOTS")) p->NS = std::max(2, std::min(kPvMaxSlots, atoi(e)));
+  if (const char *e = getenv("MELONIX_PV_MIN_SCAN")) p->min_scan = std::max(16, std::min(4096, atoi(e)));
+  if (const char *e = getenv("MELONIX_PV_ANALYSIS_RUN")) p->analysis_run = std::max(0, std::min(64, atoi(e)));
+  p->bytes = pv_layout(*p, C, nullptr);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < p->bytes)
+    return fail(MX_ERR_NOMEM, "phase-vocoder work arena: %zu MiB needed for chunks of %lld frames, %zu MiB free", p->bytes >> 20,
+                (long long)C, free_b >> 20);
+  void *mem = nullptr;
+  const hipError_t em = hipMalloc(&mem, p->bytes);
+  if (em != hipSuccess) return fail(MX_ERR_NOMEM, "phase-vocoder work arena (%zu MiB): %s", p->bytes >> 20, hipGetErrorString(em));
+  p->base = static_cast<char *>(mem);
+  pv_layout(*p, C, p->base);
+  ctx->pv = p.release();
+  PvPipe &q = *ctx->pv;
+  hipError_t e = hipSuccess;
+  {
+    int lo_p = 0, hi_p = 0;
+    const bool prio = !getenv("MELONIX_PV_SIDE_PRIO") || atoi(getenv("MELONIX_PV_SIDE_PRIO")) != 0;
+    e = hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+    // (the side stream's kernels are a few waves each and wait on each other: ahead of the big kernel in the dispatcher)
+    if (e == hipSuccess) e = prio ? hipStreamCreateWithPriority(&q.ss, hipStreamNonBlocking, hi_p) : hipStreamCreateWithFlags(&q.ss, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&q.sf, hipStreamNonBlocking);
+  }
+  std::vector<hipEvent_t *> evs = {&q.ev_begin, &q.ev_fin};
+  for (int i = 0; i < kPvMaxSlots; ++i) {
+    evs.push_back(&q.ev_an[i]);
+    evs.push_back(&q.ev_lock[i]);
+    evs.push_back(&q.ev_syn[i]);
+    evs.push_back(&q.ev_plan[i]);
+  }
+  for (hipEvent_t *ev : evs)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  // the constants
+  std::vector<float> hann((size_t)kPvN), hann_sc((size_t)kPvN);
+  for (int j = 0; j < kPvN; ++j) {
+    hann[(size_t)j] = (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * j / kPvN));
+    hann_sc[(size_t)j] = hann[(size_t)j] * fold_scale(kPvN);  // exact: a power of two
+  }
+  std::vector<float2> wsplit((size_t)kPvM);
+  for (int c = 0; c < kPvM; ++c) {
+    const double ang = 2.0 * 3.14159265358979323846 * c / kPvN;
+    wsplit[(size_t)c] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+  }
+  if (e == hipSuccess) e = hipMemcpy(q.hann, hann.data(), kPvN * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(q.hann_scaled, hann_sc.data(), kPvN * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(q.wsplit, wsplit.data(), (size_t)kPvM * 8, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    pv_release(ctx);
+    return fail(MX_ERR_DEVICE, "phase vocoder setup: %s", hipGetErrorString(e));
+  }
+  *out = ctx->pv;
+  return MX_OK;
+}
+
+// One run of the pipeline: the frames [F_lo, F_hi) of a signal of F frames.
+struct PvRun {
+  const mx_audio *a = nullptr;
+  double r = 1.;                 // constant ratio (ignored with a plan)
+  const PvPlan *plan = nullptr;  // marker-driven variant (whole signal only)
+  const std::vector<uint32_t> *plan_hop = nullptr;
+  const std::vector<double> *plan_hratio = nullptr;
+  int sample_rate = 0;
+  int64_t F_lo = 0, F_hi = 0;
+  const uint32_t *carry_in = nullptr;  // device; null where the run starts at frame 0
+  bool totals_only = false;            // stage 1 of a rank: analysis and maps, nothing synthesised
+  uint32_t *totmaps_sums = nullptr;    // [chunks][M] per-chunk total maps (totals_only)
+  uint16_t *totmaps_org = nullptr;
+  bool reuse_analysis = false;         // the run is one chunk and slot 0 still holds its analysis (stage 2 behind stage 1)
+  bool defer_head = false, defer_tail = false;  // a rank's edges wait for its neighbours' seams
+  bool seams = false;                           // keep the raw sums behind the last hop (tail_raw)
+  int64_t head_hi = 0, tail_lo = 0;             // out: the outputs [out_lo, head_hi) and [tail_lo, out_hi) were deferred
+  float *pcm_f32 = nullptr;
+  int16_t *pcm_i16 = nullptr;
+  int64_t pcm_base = 0, out_lo = 0, out_hi = 0;
+};
+
+struct PvChunk {
+  int64_t lo, hi;
+};
+std::vector<PvChunk> pv_chunks_of(int64_t F_lo, int64_t F_hi, int64_t C) {
+  std::vector<PvChunk> v;
+  for (int64_t lo = F_lo; lo < F_hi;) {
+    int64_t hi = std::min(F_hi, lo + C);
+    if (F_hi - hi < 32) hi = F_hi;  // a remainder shorter than one synthesis workgroup rides with the last chunk
+    v.push_back({lo, hi});
+    lo = hi;
+  }
+  return v;
+}
+
+#define PV_TRY(expr)                 \
+  do {                               \
+    if (e == hipSuccess) e = (expr); \
+  } while (0)
+
+int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
+  NTables t;
+  int rc = get_tables(ctx, kPvN, t);
+  if (rc) return rc;
+  const hipStream_t sm = ctx->stream, ss = p.ss, sf = p.sf;
+  const std::vector<PvChunk> chunks = pv_chunks_of(run.F_lo, run.F_hi, p.C);
+  const int64_t K = (int64_t)chunks.size();
+  hipError_t e = hipSuccess;
+  std::vector<PvArgs> args((size_t)K);
+  for (int64_t k = 0; k < K; ++k) {
+    const PvChunk c = chunks[(size_t)k];
+    PvPipe::Slot &sl = p.slot[k % p.NS];
+    PvPipe::Out &o = p.out[k % kPvOutRing];
+    const int64_t first = c.lo > 0 ? 1 : 0, Fl = c.hi - c.lo + first;
+    PvArgs &g = args[(size_t)k];
+    g = PvArgs{};
+    g.audio = run.a->d_padded;
+    g.n = run.a->n;
+    g.ratio = run.r;
+    g.frames = Fl;
+    g.first = first;
+    g.global_first = c.lo == 0;
+    g.frame_base = c.lo;
+    g.tw2 = t.tw2;
+    g.tw3 = t.tw3;
+    g.ubase = t.ubase;
+    g.hann = p.hann;
+    g.hann_scaled = p.hann_scaled;
+    g.wsplit = p.wsplit;
+    g.apos = sl.apos;
+    g.hop = sl.hop;
+    g.hratio = sl.hratio;
+    g.xrows = sl.xrows;
+    g.recs = sl.recs;
+    g.pkmap = sl.pkmap;
+    g.pkcount = sl.pkcount;
+    g.fthr = sl.fthr;
+    g.chunk_sums = sl.chunk_sums;
+    g.chunk_org = sl.chunk_org;
+    g.group_sums = sl.group_sums;
+    g.group_org = sl.group_org;
+    g.scan_chunk = (int)std::max<int64_t>(p.min_scan, (Fl - first + kPvMaxScanChunks - 1) / kPvMaxScanChunks);
+    g.halo = o.halo;
+    g.s = o.s;
+    g.s_len = (Fl - first) * kPvHs + kPvN;
+    g.s_origin = c.lo * kPvHs;
+    g.sample_rate = run.sample_rate;
+    g.frames_per_block = p.analysis_run;
+    if (run.plan) {
+      g.tf = o.tf;
+      g.rf = o.rf;
+      g.i0 = o.i0;
+    }
+    if (run.totals_only) {
+      g.tot_sums = run.totmaps_sums + (size_t)k * kPvM;
+      g.tot_org = run.totmaps_org + (size_t)k * kPvM;
+    }
+    g.carry_in = k > 0 ? p.carry[(k - 1) & 1] : run.carry_in;
+    g.carry_out = p.carry[k & 1];
+    // outputs of the chunk: those whose interpolation starts inside its hops (marker-driven: every frame owns its samples)
+    if (!run.plan) {
+      g.out_lo = k == 0 ? run.out_lo : pv_first_output_at(c.lo * kPvHs, run.r, run.a->n);
+      g.out_hi = k == K - 1 ? run.out_hi : pv_first_output_at(c.hi * kPvHs, run.r, run.a->n);
+    }
+    g.pcm_f32 = run.pcm_f32;
+    g.pcm_i16 = run.pcm_i16;
+    g.pcm_base = run.pcm_base;
+    if (k == 0 && run.defer_head) {
+      // the rank's first N - Hs stretched samples need the previous rank's tail: their outputs wait for stage 3
+      g.skip_head = 1;
+      g.out_lo = std::min(g.out_hi, pv_first_output_at(c.lo * kPvHs + kPvSeam, run.r, run.a->n));
+      run.head_hi = g.out_lo;
+    }
+    if (k == K - 1 && run.defer_tail) {
+      // ... and the outputs that interpolate into the first sample behind the rank's hops need the next rank's head
+      g.skip_tail = 1;
+      g.out_hi = std::max(g.out_lo, std::min(g.out_hi, pv_first_output_at(c.hi * kPvHs - 1, run.r, run.a->n)));
+      run.tail_lo = g.out_hi;
+    }
+    // the boundary between two chunks is finished in the left chunk's s: the right chunk copies it
+    if (k > 0) g.prev_final = args[(size_t)k - 1].s + (args[(size_t)k - 1].frames - args[(size_t)k - 1].first) * kPvHs;
+  }
+  for (int64_t k = 0; k + 1 < K; ++k) args[(size_t)k].next_head = args[(size_t)k + 1].halo;  // the right chunk's head: its workgroup 0's halo
+
+  // ---- the stages of one chunk ----
+  auto analysis = [&](int64_t k) {  // main stream
+    const PvChunk c = chunks[(size_t)k];
+    const PvArgs &g = args[(size_t)k];
+    PvPipe::Slot &sl = p.slot[k % p.NS];
+    if (run.plan) {
+      const int64_t g0 = c.lo - g.first;  // global frame of local row 0
+      PV_TRY(hipMemcpyAsync(sl.apos, run.plan->apos.data() + g0, (size_t)g.frames * 8, hipMemcpyHostToDevice, sm));
+      PV_TRY(hipMemcpyAsync(sl.hop, run.plan_hop->data() + g0, (size_t)g.frames * 4, hipMemcpyHostToDevice, sm));
+      PV_TRY(hipMemcpyAsync(sl.hratio, run.plan_hratio->data() + g0, (size_t)g.frames * 8, hipMemcpyHostToDevice, sm));
+      // (the resampler's rows live with the chunk's stretched signal: the slot has a new tenant by the time it runs)
+      PV_TRY(hipMemcpyAsync(const_cast<double *>(g.tf), run.plan->tf.data() + c.lo, (size_t)(c.hi - c.lo) * 8, hipMemcpyHostToDevice, sm));
+      PV_TRY(hipMemcpyAsync(const_cast<double *>(g.rf), run.plan->rf.data() + c.lo, (size_t)(c.hi - c.lo) * 8, hipMemcpyHostToDevice, sm));
+      PV_TRY(hipMemcpyAsync(const_cast<int64_t *>(g.i0), run.plan->i0.data() + c.lo, (size_t)(c.hi - c.lo + 1) * 8, hipMemcpyHostToDevice, sm));
+    } else if (k < p.NS || run.totals_only) {
+      PV_TRY(launch_pv_plan_const(sl.apos, sl.hop, sl.hratio, g.frames, c.lo - g.first, run.r, sm));
+    } else {
+      PV_TRY(hipStreamWaitEvent(sm, p.ev_plan[k % p.NS], 0));  // (the side stream wrote the rows beside the previous analysis)
+    }
+    PV_TRY(launch_pv_analysis(g, sm));
+    PV_TRY(hipEventRecord(p.ev_an[k % p.NS], sm));
+  };
+  auto synthesis = [&](int64_t k) {  // main stream
+    const PvArgs &g = args[(size_t)k];
+    PV_TRY(hipStreamWaitEvent(sm, p.ev_lock[k % p.NS], 0));
+    PV_TRY(launch_pv_synthesis(g, sm));
+    if (k == 0 && run.defer_head) {
+      PV_TRY(hipMemcpyAsync(p.head_raw, g.halo, kPvSeam * 4, hipMemcpyDeviceToDevice, sm));
+      // (the sample behind the seam left the synthesis finished: hop 15 of the chunk's first workgroup)
+      PV_TRY(hipMemcpyAsync(p.edge_head + kPvSeam, g.s + kPvSeam, 4, hipMemcpyDeviceToDevice, sm));
+    }
+    if (k == K - 1 && run.seams)  // the raw sums behind the rank's last hop (the fix-up normalises them in place)
+      PV_TRY(hipMemcpyAsync(p.tail_raw, g.s + (g.frames - g.first) * kPvHs, kPvSeam * 4, hipMemcpyDeviceToDevice, sm));
+    if (k == K - 1 && run.defer_tail)  // (the last sample of the rank's hops is finished too: the last workgroup's last hop)
+      PV_TRY(hipMemcpyAsync(p.edge_tail, g.s + (g.frames - g.first) * kPvHs - 1, 4, hipMemcpyDeviceToDevice, sm));
+    PV_TRY(hipEventRecord(p.ev_syn[k % p.NS], sm));
+  };
+
+  PV_TRY(hipEventRecord(p.ev_begin, sm));  // the input, and whatever used the arena before, are stream-ordered before this
+  PV_TRY(hipStreamWaitEvent(ss, p.ev_begin, 0));
+  PV_TRY(hipStreamWaitEvent(sf, p.ev_begin, 0));
+  if (run.totals_only) {
+    // stage 1 of a rank: transforms on the main stream, the maps (and the chunk's total map) beside the next chunk's
+    for (int64_t k = 0; k < K && e == hipSuccess; ++k) {
+      if (k >= p.NS) PV_TRY(hipStreamWaitEvent(sm, p.ev_lock[k % p.NS], 0));  // (the slot's maps are made)
+      analysis(k);
+      PV_TRY(hipStreamWaitEvent(ss, p.ev_an[k % p.NS], 0));
+      PV_TRY(launch_pv_maps(args[(size_t)k], ss));
+      PV_TRY(hipEventRecord(p.ev_lock[k % p.NS], ss));
+    }
+  } else {
+    // The main stream carries the two big kernels, one at a time:  A(0) A(1) S(0) A(2) S(1) A(3) S(2) ...  The side stream
+    // carries everything small, beside an ANALYSIS: while A(k + 1) runs — S(k - 1) is through —, the records, maps and offsets
+    // of chunk k, then the fix-up and resampling of chunk k - 2 (whose right neighbour's head S(k - 1) has just left).
+    // Nothing runs beside a synthesis: its workgroups take a whole CU's LDS and registers, four to a CU, exactly one round
+    // of them per chunk — a small kernel beside it displaces workgroups into a second round.
+    for (int64_t step = 0; step <= K && e == hipSuccess; ++step) {
+      if (step < K && !run.reuse_analysis) analysis(step);
+      const int64_t j = step - 1;
+      if (j < 0) continue;
+      // side stream: chunk j's recurrence ...
+      if (j >= 1) PV_TRY(hipStreamWaitEvent(ss, p.ev_syn[(j - 1) % p.NS], 0));  // (behind it on the main stream: A(j) is done too)
+      else if (!run.reuse_analysis) PV_TRY(hipStreamWaitEvent(ss, p.ev_an[j % p.NS], 0));
+      PvArgs gl = args[(size_t)j];
+      gl.tot_sums = nullptr;
+      gl.tot_org = nullptr;
+      if (!run.reuse_analysis) PV_TRY(launch_pv_maps(gl, ss));
+      PV_TRY(launch_pv_offsets(gl, ss));
+      // the last hop of s is beyond every frame, and s[s_len] backs the interpolation's m + 1
+      PV_TRY(hipMemsetAsync(gl.s + (gl.s_len - kPvHs), 0, (size_t)(kPvHs + 1) * 4, ss));
+      PV_TRY(hipEventRecord(p.ev_lock[j % p.NS], ss));
+      // (what would sit between the two big kernels on the main stream: the plan rows of the slot's next tenant — the
+      // transforms and maps of chunk j have read theirs)
+      if (j + p.NS < K && !run.plan) {
+        const PvChunk cn = chunks[(size_t)(j + p.NS)];
+        const PvArgs &gn = args[(size_t)(j + p.NS)];
+        PvPipe::Slot &sn = p.slot[j % p.NS];
+        PV_TRY(launch_pv_plan_const(sn.apos, sn.hop, sn.hratio, gn.frames, cn.lo - gn.first, run.r, ss));
+        PV_TRY(hipEventRecord(p.ev_plan[j % p.NS], ss));
+      }
+      // ... and, on a stream of its own (it must not hold the recurrence up, nor sit beside the synthesis the recurrence
+      // releases), chunk j - 2's fix-up and resampling: S(j - 1) is through
+      if (j >= 2) {
+        PV_TRY(hipStreamWaitEvent(sf, p.ev_syn[(j - 1) % p.NS], 0));
+        PV_TRY(launch_pv_finish(args[(size_t)j - 2], sf));
+        PV_TRY(hipEventRecord(p.ev_fin, sf));
+        PV_TRY(hipStreamWaitEvent(ss, p.ev_fin, 0));  // (S(j + 1) reuses a buffer this reads: the next chunk's recurrence releases it)
+      }
+      synthesis(j);
+    }
+    // the last two chunks' fix-up and resampling
+    PV_TRY(hipStreamWaitEvent(sf, p.ev_syn[(K - 1) % p.NS], 0));
+    if (K >= 2) PV_TRY(launch_pv_finish(args[(size_t)K - 2], sf));
+    PV_TRY(launch_pv_finish(args[(size_t)K - 1], sf));
+    PV_TRY(hipEventRecord(p.ev_fin, sf));
+    PV_TRY(hipStreamWaitEvent(sm, p.ev_fin, 0));  // everything joins the context's stream
+  }
+  if (e != hipSuccess) {
+    hipStreamSynchronize(ss);
+    hipStreamSynchronize(sf);
+    hipStreamSynchronize(sm);
+    return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(e));
+  }
+  return MX_OK;
+}
+
+}  // namespace
+
+void pv_release(mx_ctx *ctx) {
+  PvPipe *p = ctx->pv;
+  if (!p) return;
+  hipSetDevice(ctx->device);
+  if (p->ss) hipStreamSynchronize(p->ss);
+  if (p->sf) hipStreamSynchronize(p->sf);
+  hipStreamSynchronize(ctx->stream);
+  pv_shard_drop(*p);
+  for (hipEvent_t ev : {p->ev_begin, p->ev_fin})
+    if (ev) hipEventDestroy(ev);
+  for (int i = 0; i < kPvMaxSlots; ++i)
+    for (hipEvent_t ev : {p->ev_an[i], p->ev_lock[i], p->ev_syn[i], p->ev_plan[i]})
+      if (ev) hipEventDestroy(ev);
+  if (p->ss) hipStreamDestroy(p->ss);
+  if (p->sf) hipStreamDestroy(p->sf);
+  hipFree(p->base);
+  delete p;
+  ctx->pv = nullptr;
+}
+
+}  // namespace mx
+
 extern "C" {
+
+int mx_pv_set_chunk_frames(mx_ctx *ctx, int64_t frames) {
+  if (!ctx || frames < 0) return fail(MX_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> plk(ctx->pv_mu);
+  ctx->pv_chunk_frames = frames;  // (the arena is rebuilt by the next call that needs another size)
+  return MX_OK;
+}
+
+int64_t mx_pv_arena_bytes(mx_ctx *ctx) {
+  if (!ctx) return fail(MX_ERR_INVALID, "null context");
+  std::lock_guard<std::mutex> plk(ctx->pv_mu);
+  return ctx->pv ? (int64_t)ctx->pv->bytes : 0;
+}
 
 int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32, int16_t *d_pcm_i16) {
   if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
   if (!(semitones >= -48.0 && semitones <= 48.0)) return fail(MX_ERR_INVALID, "semitones out of range [-48, 48]");
   if (a->n == 0 || (!d_pcm_f32 && !d_pcm_i16)) return MX_OK;
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
-  ctx->pv_job_active = false;
-  PvArgs p;
-  const int rc = pv_prepare(ctx, a, semitones, 0, pv_frame_count(a->n, std::pow(2.0, semitones / 12.0)), false, p);
+  PvPipe *p = nullptr;
+  int rc = pv_pipe(ctx, &p);
   if (rc) return rc;
-  p.out_lo = 0;
-  p.out_hi = a->n;
-  p.pcm_f32 = d_pcm_f32;
-  p.pcm_i16 = d_pcm_i16;
-  hipError_t e = launch_pv(p, ctx->stream);
+  pv_shard_drop(*p);
+  PvRun run;
+  run.a = a;
+  run.r = std::pow(2.0, semitones / 12.0);
+  run.F_lo = 0;
+  run.F_hi = pv_frame_count(a->n, run.r);
+  run.out_lo = 0;
+  run.out_hi = a->n;
+  run.pcm_f32 = d_pcm_f32;
+  run.pcm_i16 = d_pcm_i16;
+  rc = pv_run(ctx, *p, run);
   const hipError_t es = hipStreamSynchronize(ctx->stream);
-  if (e == hipSuccess) e = es;
-  if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(e));
+  if (rc) return rc;
+  if (es != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(es));
   return MX_OK;
 }
 
@@ -233,18 +575,36 @@ int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_ma
     for (int64_t c : plan.apos)
       if (c < -(int64_t)MX_AUDIO_PAD / 2 || c > a->n + (int64_t)MX_AUDIO_PAD / 2)
         return fail(MX_ERR_INVALID, "a marker maps warped time outside the audio");
+    // hops and stretch factors of the plan (the constant-ratio plan computes them on the device)
+    const size_t F = plan.apos.size();
+    std::vector<uint32_t> hop(F, 0u);
+    std::vector<double> hratio(F, 0.0);
+    for (size_t j = 1; j < F; ++j) {
+      const int64_t h = plan.apos[j] - plan.apos[j - 1];
+      if (h >= 1 && h <= 0x7fffffffLL) {
+        hop[j] = (uint32_t)h;
+        hratio[j] = (double)kPvHs / (double)h;
+      }
+    }
     std::lock_guard<std::mutex> plk(ctx->pv_mu);
-    ctx->pv_job_active = false;
-    PvArgs p;
-    rc = pv_prepare(ctx, a, 0.0, 0, (int64_t)plan.apos.size(), false, p, &plan);
+    PvPipe *p = nullptr;
+    rc = pv_pipe(ctx, &p);
     if (rc) return rc;
-    p.sample_rate = sampleRate;
-    p.pcm_f32 = d_pcm_f32;
-    p.pcm_i16 = d_pcm_i16;
-    hipError_t e = launch_pv(p, ctx->stream);
-    const hipError_t es = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = es;
-    if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(e));
+    pv_shard_drop(*p);
+    PvRun run;
+    run.a = a;
+    run.plan = &plan;
+    run.plan_hop = &hop;
+    run.plan_hratio = &hratio;
+    run.sample_rate = sampleRate;
+    run.F_lo = 0;
+    run.F_hi = (int64_t)F;
+    run.pcm_f32 = d_pcm_f32;
+    run.pcm_i16 = d_pcm_i16;
+    rc = pv_run(ctx, *p, run);
+    const hipError_t es = hipStreamSynchronize(ctx->stream);  // (the plan's host arrays die with this frame)
+    if (rc) return rc;
+    if (es != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(es));
     return MX_OK;
   } catch (const std::bad_alloc &) {
     return fail(MX_ERR_NOMEM, "out of host memory");
@@ -277,11 +637,15 @@ int mx_pv_render(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_marker
   return rc;
 }
 
+
 // ---- one rank of a multi-GPU phase-vocoder run (the overlap-add seams) ------------------------
 // Every rank holds the whole input and takes a contiguous range of the frame axis (boundaries on multiples of 32
 // frames = the synthesis workgroups, so the float sums group exactly as in a single-GPU run).  Two small exchanges
 // happen outside this library (RCCL / gloo all-gathers in the caller): after stage 1 the per-rank phase totals
-// (2048 x {restart, phase}), after stage 2 the seams (2 x 3840 raw partial sums).
+// (2048 x {restart, phase}), after stage 2 the seams (2 x 3840 raw partial sums).  A rank walks its range through the
+// same bounded arena as a single GPU walks the whole signal; what that costs it: stage 1 cannot keep the spectra of
+// more than one chunk, so a rank whose range is longer than a chunk analyses its frames twice (stage 1 for the maps
+// alone, stage 2 again with the carry) — a range of one chunk is analysed once.
 int mx_pv_shard_frames(int64_t n, double semitones, int rank, int world, int64_t *frame_lo, int64_t *frame_hi,
                        int64_t *out_lo, int64_t *out_hi) {
   if (n <= 0 || world < 1 || rank < 0 || rank >= world || !(semitones >= -48.0 && semitones <= 48.0))
@@ -290,7 +654,9 @@ int mx_pv_shard_frames(int64_t n, double semitones, int rank, int world, int64_t
   const int64_t F = pv_frame_count(n, r);
   int64_t per = (F + world - 1) / world;
   per = (per + 31) / 32 * 32;
-  if (per * (world - 1) >= F) return fail(MX_ERR_INVALID, "signal too short for %d ranks (%lld frames)", world, (long long)F);
+  // (every rank gets at least one synthesis workgroup of its own: the seams either side of a rank must not overlap)
+  if (world > 1 && F - per * (world - 1) < 32)
+    return fail(MX_ERR_INVALID, "signal too short for %d ranks (%lld frames)", world, (long long)F);
   const int64_t lo = (int64_t)rank * per, hi = rank == world - 1 ? F : lo + per;
   if (frame_lo) *frame_lo = lo;
   if (frame_hi) *frame_hi = hi;
@@ -306,48 +672,114 @@ int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int ra
   int rc = mx_pv_shard_frames(a->n, semitones, rank, world, &lo, &hi, &olo, &ohi);
   if (rc) return rc;
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
-  ctx->pv_job_active = false;
-  rc = pv_prepare(ctx, a, semitones, lo, hi, true, ctx->pv_job);
+  PvPipe *p = nullptr;
+  rc = pv_pipe(ctx, &p);
   if (rc) return rc;
-  PvArgs &p = ctx->pv_job;
-  p.out_lo = olo;
-  p.out_hi = ohi;
-  ctx->pv_job_last = rank == world - 1;
-  hipError_t e = launch_pv_analyze(p, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(tot_sums_out, p.tot_sums, kPvM * 4, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(tot_org_out, p.tot_org, kPvM * 2, hipMemcpyDeviceToHost, ctx->stream);
-  const hipError_t es = hipStreamSynchronize(ctx->stream);
+  pv_shard_drop(*p);
+  const int64_t K = (int64_t)pv_chunks_of(lo, hi, p->C).size();
+  // every chunk's total map (12 KiB each), folded into the rank's behind the last analysis
+  uint32_t *d_sums = nullptr;
+  uint16_t *d_org = nullptr;
+  hipError_t e = hipMalloc(&d_sums, (size_t)K * kPvM * 4);
+  if (e == hipSuccess) e = hipMalloc(&d_org, (size_t)K * kPvM * 2);
+  if (e != hipSuccess) {
+    hipFree(d_sums);
+    return fail(MX_ERR_NOMEM, "phase-vocoder chunk maps: %s", hipGetErrorString(e));
+  }
+  PvRun run;
+  run.a = a;
+  run.r = std::pow(2.0, semitones / 12.0);
+  run.F_lo = lo;
+  run.F_hi = hi;
+  run.totals_only = true;
+  run.totmaps_sums = d_sums;
+  run.totmaps_org = d_org;
+  rc = pv_run(ctx, *p, run);
+  if (rc == MX_OK) {
+    const uint32_t *rs = d_sums;
+    const uint16_t *ro = d_org;
+    if (K > 1) {
+      e = launch_pv_compose_maps(d_sums, d_org, K, p->slot[0].tot_sums, p->slot[0].tot_org, p->ss);
+      rs = p->slot[0].tot_sums;
+      ro = p->slot[0].tot_org;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(tot_sums_out, rs, kPvM * 4, hipMemcpyDeviceToHost, p->ss);
+    if (e == hipSuccess) e = hipMemcpyAsync(tot_org_out, ro, kPvM * 2, hipMemcpyDeviceToHost, p->ss);
+  }
+  const hipError_t es = hipStreamSynchronize(p->ss);
+  hipFree(d_sums);
+  hipFree(d_org);
+  if (rc) return rc;
   if (e == hipSuccess) e = es;
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (analysis): %s", hipGetErrorString(e));
-  ctx->pv_job_active = true;
+  PvPipe::Shard &j = p->job;
+  j.active = true;
+  j.first = rank == 0;
+  j.last = rank == world - 1;
+  j.single = K == 1;
+  j.a = a;
+  j.semitones = semitones;
+  j.r = run.r;
+  j.F_lo = lo;
+  j.F_hi = hi;
+  j.out_lo = olo;
+  j.out_hi = ohi;
   return MX_OK;
 }
 
 int mx_pv_shard_synthesize(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out) {
   if (!ctx || !head_out || !tail_out) return fail(MX_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
-  if (!ctx->pv_job_active) return fail(MX_ERR_INVALID, "mx_pv_shard_analyze has not run on this context");
-  PvArgs &p = ctx->pv_job;
-  if (!p.global_first && !carry_in) return fail(MX_ERR_INVALID, "carry_in is required on every rank but the first");
+  PvPipe *p = ctx->pv;
+  if (!p || !p->job.active || p->job.synthesized) return fail(MX_ERR_INVALID, "mx_pv_shard_analyze has not run on this context");
+  PvPipe::Shard &j = p->job;
+  if (!j.first && !carry_in) return fail(MX_ERR_INVALID, "carry_in is required on every rank but the first");
   HIP_TRY(hipSetDevice(ctx->device));
+  // the rank's outputs wait on the device for stage 3 (both formats: the caller chooses there)
+  const int64_t cnt = j.out_hi - j.out_lo;
   hipError_t e = hipSuccess;
-  p.carry_in = nullptr;
-  if (carry_in) {
-    e = hipMemcpyAsync(ctx->pv_slot_carry, carry_in, kPvM * 4, hipMemcpyHostToDevice, ctx->stream);
-    p.carry_in = reinterpret_cast<const uint32_t *>(ctx->pv_slot_carry);
+  if (cnt > 0) {
+    e = hipMalloc(&j.d_f, (size_t)cnt * 4);
+    if (e == hipSuccess) e = hipMalloc(&j.d_i, (size_t)cnt * 2);
+    if (e != hipSuccess) {
+      pv_shard_drop(*p);
+      return fail(MX_ERR_NOMEM, "device PCM buffers: %s", hipGetErrorString(e));
+    }
   }
-  if (e == hipSuccess) e = launch_pv_synthesize(p, ctx->stream);
-  // the seams, raw: this rank's sums into the N - Hs samples before its first complete hop (halo of workgroup 0;
-  // all zero on the first rank, whose first hops are complete) and after its last hop
-  if (e == hipSuccess) {
-    if (p.global_first) memset(head_out, 0, kPvSeam * 4);
-    else e = hipMemcpyAsync(head_out, p.halo, kPvSeam * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (carry_in && !j.first) e = hipMemcpyAsync(p->carry_in, carry_in, kPvM * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (carry): %s", hipGetErrorString(e));
+  PvRun run;
+  run.a = j.a;
+  run.r = j.r;
+  run.F_lo = j.F_lo;
+  run.F_hi = j.F_hi;
+  run.carry_in = j.first ? nullptr : p->carry_in;
+  run.reuse_analysis = j.single;
+  run.defer_head = !j.first;
+  run.defer_tail = !j.last;
+  run.seams = true;
+  run.pcm_f32 = j.d_f;
+  run.pcm_i16 = j.d_i;
+  run.pcm_base = j.out_lo;
+  run.out_lo = run.head_hi = j.out_lo;
+  run.out_hi = run.tail_lo = j.out_hi;
+  int rc = pv_run(ctx, *p, run);
+  // the seams, raw: this rank's sums into the N - Hs samples before its first complete hop (all zero on the first rank,
+  // whose first hops are complete) and after its last hop
+  if (rc == MX_OK) {
+    if (j.first) memset(head_out, 0, kPvSeam * 4);
+    else e = hipMemcpyAsync(head_out, p->head_raw, kPvSeam * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tail_out, p->tail_raw, kPvSeam * 4, hipMemcpyDeviceToHost, ctx->stream);
   }
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(tail_out, p.s + (p.frames - p.first) * kPvHs, kPvSeam * 4, hipMemcpyDeviceToHost, ctx->stream);
   const hipError_t es = hipStreamSynchronize(ctx->stream);
-  if (e == hipSuccess) e = es;
-  if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (synthesis): %s", hipGetErrorString(e));
+  if (rc == MX_OK && e == hipSuccess) e = es;
+  if (rc || e != hipSuccess) {
+    pv_shard_drop(*p);
+    return rc ? rc : fail(MX_ERR_DEVICE, "phase vocoder (synthesis): %s", hipGetErrorString(e));
+  }
+  j.synthesized = true;
+  j.head_hi = run.head_hi;
+  j.tail_lo = run.tail_lo;
   return MX_OK;
 }
 
@@ -355,36 +787,44 @@ int mx_pv_shard_finish(mx_ctx *ctx, const float *prev_tail, const float *next_he
                        int16_t *pcm_i16_out) {
   if (!ctx) return fail(MX_ERR_INVALID, "null context");
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
-  if (!ctx->pv_job_active) return fail(MX_ERR_INVALID, "mx_pv_shard_analyze has not run on this context");
-  PvArgs &p = ctx->pv_job;
-  if ((!p.global_first && !prev_tail) || (!ctx->pv_job_last && !next_head))
-    return fail(MX_ERR_INVALID, "a neighbour's seam is missing");
+  PvPipe *p = ctx->pv;
+  if (!p || !p->job.active || !p->job.synthesized) return fail(MX_ERR_INVALID, "mx_pv_shard_synthesize has not run on this context");
+  PvPipe::Shard &j = p->job;
+  if ((!j.first && !prev_tail) || (!j.last && !next_head)) return fail(MX_ERR_INVALID, "a neighbour's seam is missing");
   HIP_TRY(hipSetDevice(ctx->device));
-  const int64_t cnt = p.out_hi - p.out_lo;
-  float *d_f = nullptr;
-  int16_t *d_i = nullptr;
+  const hipStream_t sm = ctx->stream;
+  const int64_t cnt = j.out_hi - j.out_lo;
   hipError_t e = hipSuccess;
-  if (pcm_f32_out && cnt) e = hipMalloc(&d_f, (size_t)cnt * 4);
-  if (e == hipSuccess && pcm_i16_out && cnt) e = hipMalloc(&d_i, (size_t)cnt * 2);
-  p.prev_tail = p.next_head = nullptr;
-  if (e == hipSuccess && !p.global_first) {
-    e = hipMemcpyAsync(ctx->pv_slot_prev_tail, prev_tail, kPvSeam * 4, hipMemcpyHostToDevice, ctx->stream);
-    p.prev_tail = reinterpret_cast<const float *>(ctx->pv_slot_prev_tail);
+  PvArgs g{};
+  g.ratio = j.r;
+  g.pcm_f32 = j.d_f;
+  g.pcm_i16 = j.d_i;
+  g.pcm_base = j.out_lo;
+  if (!j.first) {
+    // the rank's first N - Hs stretched samples: its head + the previous rank's tail, then their outputs
+    PV_TRY(hipMemcpyAsync(p->prev_tail, prev_tail, kPvSeam * 4, hipMemcpyHostToDevice, sm));
+    PV_TRY(launch_pv_edge_sum(p->edge_head, p->head_raw, p->prev_tail, kPvSeam, sm));
+    g.s = p->edge_head;
+    g.s_origin = j.F_lo * kPvHs;
+    g.out_lo = j.out_lo;
+    g.out_hi = j.head_hi;
+    PV_TRY(launch_pv_resample(g, sm));
   }
-  if (e == hipSuccess && !ctx->pv_job_last) {
-    e = hipMemcpyAsync(ctx->pv_slot_next_head, next_head, kPvSeam * 4, hipMemcpyHostToDevice, ctx->stream);
-    p.next_head = reinterpret_cast<const float *>(ctx->pv_slot_next_head);
+  if (!j.last) {
+    // the outputs that interpolate between the rank's last stretched sample and the first one behind it
+    PV_TRY(hipMemcpyAsync(p->next_head, next_head, kPvSeam * 4, hipMemcpyHostToDevice, sm));
+    PV_TRY(launch_pv_edge_sum(p->edge_tail + 1, p->tail_raw, p->next_head, 4, sm));
+    g.s = p->edge_tail;
+    g.s_origin = j.F_hi * kPvHs - 1;
+    g.out_lo = j.tail_lo;
+    g.out_hi = j.out_hi;
+    PV_TRY(launch_pv_resample(g, sm));
   }
-  p.pcm_f32 = d_f;
-  p.pcm_i16 = d_i;
-  if (e == hipSuccess) e = launch_pv_finish(p, ctx->stream);
-  if (e == hipSuccess && d_f) e = hipMemcpyAsync(pcm_f32_out, d_f, (size_t)cnt * 4, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess && d_i) e = hipMemcpyAsync(pcm_i16_out, d_i, (size_t)cnt * 2, hipMemcpyDeviceToHost, ctx->stream);
-  const hipError_t es = hipStreamSynchronize(ctx->stream);
+  if (pcm_f32_out && cnt) PV_TRY(hipMemcpyAsync(pcm_f32_out, j.d_f, (size_t)cnt * 4, hipMemcpyDeviceToHost, sm));
+  if (pcm_i16_out && cnt) PV_TRY(hipMemcpyAsync(pcm_i16_out, j.d_i, (size_t)cnt * 2, hipMemcpyDeviceToHost, sm));
+  const hipError_t es = hipStreamSynchronize(sm);
   if (e == hipSuccess) e = es;
-  hipFree(d_f);
-  hipFree(d_i);
-  ctx->pv_job_active = false;
+  pv_shard_drop(*p);
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (finish): %s", hipGetErrorString(e));
   return MX_OK;
 }

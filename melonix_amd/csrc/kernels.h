@@ -78,8 +78,8 @@ struct PvArgs {
   uint32_t *pkmap;     // [frames][N/64] bit k: bin k is a spectral peak of the frame
   uint32_t *pkcount;   // [frames] number of peaks (= records) of the frame
   float *fthr;         // [frames] the frame's activity threshold (squared magnitude): what the next frame's records compare with
-  uint2 *recs;         // [frames][N/2] the frame's records (only the first pkcount are written or read)
-  uint32_t *cvals;     // [frames][N/2] out of the second sweep: C_f of the frame's peaks in record order (0 = restarted)
+  uint2 *recs;         // [frames][N/2] the frame's records (only the first pkcount are written or read); the second sweep
+                       // REPLACES rec.y by C_f of the peak (0 = restarted): delta has no reader after it
   uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2] a chunk's composed map: delta (or restart value) ...
   uint16_t *chunk_org;   // ... and source bin at the chunk's start (0xFFFF: restart); then the chunk-start offsets
   uint32_t *group_sums;  // [ceil(chunks/32)][N/2] the same for groups of 32 chunks (the composition is two-level)
@@ -88,29 +88,45 @@ struct PvArgs {
   float *halo;        // pv_halo_floats(frames): partial sums right of each synthesis-workgroup boundary
   float *s;           // stretched signal, s_len = frames*Hs + N, index 0 = stretched time -N/2
   int64_t s_len;
-  float *pcm_f32;     // n, may be null
-  int16_t *pcm_i16;   // n, may be null
+  float *pcm_f32;     // output sample i of the whole signal is pcm[i - pcm_base]; may be null
+  int16_t *pcm_i16;   // likewise
+  int64_t pcm_base;
   int frames_per_block;
   // multi-GPU (one rank's part of the frame axis; all zero / null for a whole-signal run)
   int64_t first;             // local frames [first, frames) are this rank's; first = 1: row 0 is the frame before them
   int global_first;          // this rank holds the signal's frame 0
-  const uint32_t *carry_in;  // [N/2] synthesis phase at the end of the previous rank's last frame (null: zero)
+  const uint32_t *carry_in;  // [N/2] synthesis phase at the end of the previous rank's / chunk's last frame (null: zero)
+  uint32_t *carry_out;       // [N/2] out: the same row at the end of THIS range's last frame (null: not wanted)
   uint32_t *tot_sums;        // [N/2] out: this rank's total map over its frames (null: not wanted): delta / value ...
   uint16_t *tot_org;         // ... and source bin at the rank's start (0xFFFF: restart)
   const float *prev_tail;    // [N-Hs] the previous rank's tail seam (raw sums), null on the first rank
   const float *next_head;    // [N-Hs] the next rank's head seam, null on the last rank
+  const float *prev_final;   // [N-Hs] the previous chunk's FINISHED samples across boundary 0 (one GPU walking the signal chunk by
+                             // chunk: the previous chunk's fix-up already added the two sides and normalised); overrides prev_tail
+  int skip_head, skip_tail;  // pv_fixup leaves boundary 0 / the last boundary alone (a rank's edges wait for its neighbours' seams)
   int64_t out_lo, out_hi;    // output samples [out_lo, out_hi) of the whole signal are resampled here
   int64_t s_origin;          // stretched sample index (incl. the N/2 offset) of s[0]
   // marker-driven plan (null for a constant ratio): per frame warped time, ratio and first output sample
+  // (indexed like the frames this range synthesises: entry 0 is local frame `first`)
   const double *tf, *rf;
-  const int64_t *i0;         // frames + 1 entries
+  const int64_t *i0;         // one entry more than frames
+  int64_t frame_base;        // index in the whole signal of local frame `first`
   int sample_rate;
 };
 hipError_t launch_pv(const PvArgs &a, hipStream_t s);
 hipError_t launch_pv_analyze(const PvArgs &a, hipStream_t s);
 hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s);
+// the same stages in the pieces the chunked pipeline puts on streams of their own (pv_kernels.hip: launch_pv_analyze =
+// analysis + maps, launch_pv_synthesize = offsets + synthesis)
+hipError_t launch_pv_analysis(const PvArgs &a, hipStream_t s);
+hipError_t launch_pv_maps(const PvArgs &a, hipStream_t s);
+hipError_t launch_pv_offsets(const PvArgs &a, hipStream_t s);
+hipError_t launch_pv_synthesis(const PvArgs &a, hipStream_t s);
 hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s);
 int64_t pv_halo_floats(int64_t frames);
+hipError_t launch_pv_compose_maps(uint32_t *sums, uint16_t *org, int64_t n, uint32_t *out_sums, uint16_t *out_org, hipStream_t s);
+hipError_t launch_pv_resample(const PvArgs &a, hipStream_t s);
+hipError_t launch_pv_edge_sum(float *dst, const float *x, const float *y, int n, hipStream_t s);
 // constant-ratio analysis plan written on the device: rows of apos / hop / hratio for global frames fbase, fbase+1, ...
 hipError_t launch_pv_plan_const(int64_t *apos, uint32_t *hop, double *hratio, int64_t rows, int64_t fbase, double r,
                                 hipStream_t s);

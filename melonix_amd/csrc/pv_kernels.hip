@@ -378,7 +378,12 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
 // The records of every analysis workgroup's first frame f (a multiple of the run length): the frame's peaks from its map,
 // its spectrum and the previous frame's at the peaks from their rows, the previous frame's map and threshold — everything
 // pv_analysis left in memory.  One workgroup per such frame.
+// (pv_heads, pv_lock_walk and pv_lock_chunks are chains of dependent memory and LDS round trips, a few instructions between
+// them: in the chunked pipeline they run beside a transform kernel whose waves would win most issue cycles by age — they raise
+// their wave priority, MX_LATENCY_BOUND_KERNEL.  They are a few hundred waves: the transform does not notice.)
+#define MX_LATENCY_BOUND_KERNEL() __builtin_amdgcn_s_setprio(3)
 __global__ __launch_bounds__(PV::T) void pv_heads(const PvArgs a) {
+  MX_LATENCY_BOUND_KERNEL();
   using P = PV;
   constexpr int W = P::M / 32;
   __shared__ uint32_t pkq[W + 2];  // the previous frame's map, a zero word either side
@@ -419,6 +424,7 @@ __host__ __device__ inline int64_t pv_chunks(const PvArgs &a) { return (a.frames
 
 template <bool APPLY>
 __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
+  MX_LATENCY_BOUND_KERNEL();
   constexpr int W = kPvM / 32;
   __shared__ uint32_t SUM[2][kPvM];
   __shared__ uint16_t ORG[APPLY ? 1 : 2][APPLY ? 2 : kPvM];
@@ -465,8 +471,7 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
       if (r >= r1) break;  // (block-uniform)
       const int cnt = (int)cc[j];
       uint2 rec = rc[j];
-      const uint2 *rrow = a.recs + (size_t)r * kPvM;
-      uint32_t *crow = APPLY ? a.cvals + (size_t)r * kPvM : nullptr;
+      uint2 *rrow = a.recs + (size_t)r * kPvM;
       const int cp = cw == 0 ? 2 : cw - 1, cx = cw == 2 ? 0 : cw + 1;
       if (t < W) CM[cx][t] = 0u;  // (last read during the previous row, before the barrier that ended it)
       for (int i = t; i < cnt; i += kLockT) {
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
           if constexpr (!APPLY) ORG[cur][p] = org;
           atomicOr(&CM[cw][p >> 5], 1u << (p & 31));
         }
-        if constexpr (APPLY) crow[i] = val;  // (0 where the peak restarts)
+        if constexpr (APPLY) rrow[i].y = val;  // (0 where the peak restarts; the delta it replaces has no reader left)
       }
       __syncthreads();  // row r's state is complete; nobody reads row r-1's any more
       cur ^= 1;
@@ -528,7 +533,8 @@ constexpr int kPvGroup = 32;
 template <bool MAP>
 __global__ __launch_bounds__(kChunkT) void pv_lock_chunks(uint32_t *sums, uint16_t *org, int64_t n, int per_group,
                                                           const uint32_t *init, int init_per_group, uint32_t *out_sums,
-                                                          uint16_t *out_org) {
+                                                          uint16_t *out_org, uint32_t *final_out) {
+  MX_LATENCY_BOUND_KERNEL();
   __shared__ uint32_t D[2][kPvM];
   __shared__ uint16_t O[MAP ? 2 : 1][MAP ? kPvM : 2];
   const int t = threadIdx.x;
@@ -590,6 +596,9 @@ __global__ __launch_bounds__(kChunkT) void pv_lock_chunks(uint32_t *sums, uint16
       out_sums[(int64_t)blockIdx.x * kPvM + t + kChunkT * j] = sd[j];
       out_org[(int64_t)blockIdx.x * kPvM + t + kChunkT * j] = so[j];
     }
+  } else if (final_out) {  // (single-workgroup pass) the offsets behind the last map: what the next range starts from
+#pragma unroll
+    for (int j = 0; j < kChunkV; ++j) final_out[t + kChunkT * j] = sd[j];
   }
 }
 
@@ -645,12 +654,12 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   auto fill_cd = [&](int64_t fr, int cnt, int tt, uint32_t r_i, uint32_t cv, uint32_t r_m, uint32_t r_n) {
     const int lg = lanes_per_peak(cnt), G = 1 << lg, sub = tt & (G - 1);
     const uint2 *rrow = a.recs + (size_t)fr * P::M;
-    const uint32_t *crow = a.cvals + (size_t)fr * P::M;
     bool first = true;
     for (int i = tt >> lg; i < cnt; i += P::T >> lg) {
       if (!first) {
-        r_i = rrow[i].x;
-        cv = crow[i];
+        const uint2 rc = rrow[i];
+        r_i = rc.x;
+        cv = rc.y;
         r_m = i > 0 ? rrow[i - 1].x : 0u;
         r_n = i + 1 < cnt ? rrow[i + 1].x : 0u;
       }
@@ -673,8 +682,9 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     r_i = cv = r_m = r_n = 0u;
     if (i < cnt) {
       const uint2 *rrow = a.recs + (size_t)fr * P::M;
-      r_i = rrow[i].x;
-      cv = a.cvals[(size_t)fr * P::M + i];
+      const uint2 rc = rrow[i];
+      r_i = rc.x;
+      cv = rc.y;
       if (i > 0) r_m = rrow[i - 1].x;
       if (i + 1 < cnt) r_n = rrow[i + 1].x;
     }
@@ -907,8 +917,13 @@ __global__ __launch_bounds__(256) void pv_fixup(const PvArgs a) {
   const int64_t b = (int64_t)(blockIdx.x / kPerB);
   const int i = ((int)(blockIdx.x % kPerB) * 256 + threadIdx.x) * 4;
   if (i >= kPvHalo) return;
+  if ((b == 0 && a.skip_head) || (b == nb && a.skip_tail)) return;
   if (b == 0) {
     if (a.global_first) return;  // the first hops of the signal were complete when they left the accumulator
+    if (a.prev_final) {  // the same samples as the previous chunk's last boundary: finished there
+      *reinterpret_cast<f32x4 *>(a.s + i) = *reinterpret_cast<const f32x4 *>(a.prev_final + i);
+      return;
+    }
     f32x4 v = *reinterpret_cast<const f32x4 *>(a.halo + i);
     if (a.prev_tail) v += *reinterpret_cast<const f32x4 *>(a.prev_tail + i);
     *reinterpret_cast<f32x4 *>(a.s + i) = v * kPvNorm;
@@ -922,15 +937,25 @@ __global__ __launch_bounds__(256) void pv_fixup(const PvArgs a) {
 }
 
 // Four consecutive output samples per thread: the two outputs leave as 16- and 8-byte stores (a wavefront's 4- and 2-byte
-// stores were 256 and 128 bytes per instruction).
+// stores were 256 and 128 bytes per instruction).  The groups of four are cut where the f32 output's addresses are 16-byte
+// aligned (the int16 output's where there is no f32 output) — whatever sample the range starts at: a chunk of a long
+// signal, a rank's slice and the whole signal all store wide; the ragged ends and an output whose alignment differs from
+// the other's go sample by sample.  Values do not depend on the grouping.
+__host__ __device__ inline int64_t pv_resample_start(const PvArgs &a) {
+  const unsigned shift = a.pcm_f32 ? (unsigned)(((uintptr_t)a.pcm_f32 >> 2) & 3u) : (unsigned)(((uintptr_t)a.pcm_i16 >> 1) & 3u);
+  const int64_t e_lo = a.out_lo - a.pcm_base;  // element of pcm that receives output sample out_lo
+  return e_lo - (int64_t)((uint64_t)(e_lo + shift) & 3u);
+}
 __global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
-  const int64_t j0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;  // output samples out_lo + j0 .. + 3 of the whole signal
-  const int64_t left = a.out_hi - a.out_lo - j0;
-  if (left <= 0) return;
+  const int64_t e0 = pv_resample_start(a) + ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t e_lo = a.out_lo - a.pcm_base, e_hi = a.out_hi - a.pcm_base;
+  if (e0 >= e_hi) return;
   float v[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int64_t i = a.out_lo + j0 + (q < left ? q : 0);
+    int64_t e = e0 + q;
+    e = e < e_lo ? e_lo : (e < e_hi ? e : e_hi - 1);  // (clamped copies are computed, not stored)
+    const int64_t i = e + a.pcm_base;
     const double pos = (double)i * a.ratio + (double)(kPvN / 2);
     const double fl = floor(pos);
     const int64_t m = (int64_t)fl - a.s_origin;  // s[0] is stretched sample s_origin of the whole signal
@@ -943,37 +968,48 @@ __global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
     const float c = v[q] < -1.f ? -1.f : (1.f < v[q] ? 1.f : v[q]);  // the reference's cast is UB beyond +-1 (app.cpp:1211)
     w[q] = (int16_t)((double)c * 32767.);
   }
-  // (a caller's output pointers need not be aligned for the wide stores: then sample by sample)
-  const bool wide = (((uintptr_t)a.pcm_f32 & 15u) | ((uintptr_t)a.pcm_i16 & 7u)) == 0u;
-  if (left >= 4 && wide) {
-    using f32x4 = float __attribute__((ext_vector_type(4)));
-    using i16x4 = short __attribute__((ext_vector_type(4)));
-    if (a.pcm_f32) *reinterpret_cast<f32x4 *>(a.pcm_f32 + j0) = f32x4{v[0], v[1], v[2], v[3]};
-    if (a.pcm_i16) *reinterpret_cast<i16x4 *>(a.pcm_i16 + j0) = i16x4{w[0], w[1], w[2], w[3]};
-  } else {
-    for (int q = 0; q < (left < 4 ? (int)left : 4); ++q) {
-      if (a.pcm_f32) a.pcm_f32[j0 + q] = v[q];
-      if (a.pcm_i16) a.pcm_i16[j0 + q] = w[q];
+  const bool whole = e0 >= e_lo && e0 + 4 <= e_hi;
+  using f32x4 = float __attribute__((ext_vector_type(4)));
+  using i16x4 = short __attribute__((ext_vector_type(4)));
+  if (a.pcm_f32) {
+    float *o = a.pcm_f32 + e0;
+    if (whole && ((uintptr_t)o & 15u) == 0u) {
+      *reinterpret_cast<f32x4 *>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (e0 + q >= e_lo && e0 + q < e_hi) o[q] = v[q];
+    }
+  }
+  if (a.pcm_i16) {
+    int16_t *o = a.pcm_i16 + e0;
+    if (whole && ((uintptr_t)o & 7u) == 0u) {
+      *reinterpret_cast<i16x4 *>(o) = i16x4{w[0], w[1], w[2], w[3]};
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (e0 + q >= e_lo && e0 + q < e_hi) o[q] = w[q];
     }
   }
 }
 
 // Marker-driven variant: the ratio is constant over a frame's hop, so frame f owns the output samples
-// [i0_f, i0_{f+1}) and reads the stretched signal at u = f*Hs + (i/sr - t_f) * r_f * sr.
+// [i0_f, i0_{f+1}) and reads the stretched signal at u = f*Hs + (i/sr - t_f) * r_f * sr.  (One workgroup per frame of the
+// range; the plan rows are indexed from the range's first frame, frame_base in the whole signal.)
 __global__ __launch_bounds__(256) void pv_resample_frames(const PvArgs a) {
-  const int64_t f = blockIdx.x;
-  const int64_t lo = a.i0[f], hi = a.i0[f + 1];
-  const double tf = a.tf[f], rs = a.rf[f] * (double)a.sample_rate, sr = (double)a.sample_rate;
+  const int64_t j = blockIdx.x, f = a.frame_base + j;
+  const int64_t lo = a.i0[j], hi = a.i0[j + 1];
+  const double tf = a.tf[j], rs = a.rf[j] * (double)a.sample_rate, sr = (double)a.sample_rate;
   for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
     const double pos = (double)(f * kPvHs) + ((double)i / sr - tf) * rs + (double)(kPvN / 2);
     const double fl = floor(pos);
     const int64_t m = (int64_t)fl - a.s_origin;
     const float tt = (float)(pos - fl);
     const float v = (1.0f - tt) * a.s[m] + tt * a.s[m + 1];
-    if (a.pcm_f32) a.pcm_f32[i] = v;
+    if (a.pcm_f32) a.pcm_f32[i - a.pcm_base] = v;
     if (a.pcm_i16) {
       const float c = v < -1.f ? -1.f : (1.f < v ? 1.f : v);
-      a.pcm_i16[i] = (int16_t)((double)c * 32767.);
+      a.pcm_i16[i - a.pcm_base] = (int16_t)((double)c * 32767.);
     }
   }
 }
@@ -1020,41 +1056,66 @@ namespace {
 void launch_group_maps(const PvArgs &a, int64_t nchunks, hipStream_t s) {
   const unsigned G = (unsigned)((nchunks + kPvGroup - 1) / kPvGroup);
   hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(G), dim3(kChunkT), 0, s, a.chunk_sums, a.chunk_org, nchunks, kPvGroup,
-                     (const uint32_t *)nullptr, 0, a.group_sums, a.group_org);
+                     (const uint32_t *)nullptr, 0, a.group_sums, a.group_org, (uint32_t *)nullptr);
 }
 }  // namespace
 
-hipError_t launch_pv_analyze(const PvArgs &a0, hipStream_t s) {
+// The stages as the chunked pipeline launches them (capi_pv.cpp: each on a stream of its own) ...
+//   launch_pv_analysis   the transforms: rows, peak maps, counts, thresholds, every frame's records but a workgroup's first
+//   launch_pv_maps       those first records, the chunk maps of the recurrence, their group maps (and the range's total map)
+//   launch_pv_offsets    from carry_in: the offsets every group / chunk starts from, then every peak's offset (in the records)
+//   launch_pv_synthesis  rows + offsets -> the stretched signal
+// ... and as one rank of a multi-GPU run sees them (stage 1 = analysis + maps, stage 2 = offsets + synthesis).
+hipError_t launch_pv_analysis(const PvArgs &a0, hipStream_t s) {
   PvArgs a = a0;
   if (a.frames - a.first <= 0) return hipSuccess;
-  a.frames_per_block = 16;  // (8 / 12 / 16 / 24 frames per workgroup: 4.80 / 4.78 / 4.80 / 4.81 ms per 60 min — flat since the warm-up frame went)
+  // (8 / 12 / 16 / 24 frames per workgroup: 4.80 / 4.78 / 4.80 / 4.81 ms per 60 min in one launch — flat since the warm-up frame went)
+  if (a.frames_per_block <= 0) a.frames_per_block = 16;
+  const unsigned fb = (unsigned)((a.frames + a.frames_per_block - 1) / a.frames_per_block);
+  hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_pv_maps(const PvArgs &a0, hipStream_t s) {
+  PvArgs a = a0;
+  if (a.frames - a.first <= 0) return hipSuccess;
+  if (a.frames_per_block <= 0) a.frames_per_block = 16;  // (as launch_pv_analysis cut the frames)
   const unsigned fb = (unsigned)((a.frames + a.frames_per_block - 1) / a.frames_per_block);
   const int64_t nchunks = pv_chunks(a);
-  hipLaunchKernelGGL(pv_analysis, dim3(fb), dim3(PV::T), 0, s, a);
   hipLaunchKernelGGL(pv_heads, dim3(fb), dim3(PV::T), 0, s, a);
   hipLaunchKernelGGL(pv_lock_walk<false>, dim3((unsigned)nchunks), dim3(kLockT), 0, s, a);
-  if (a.tot_sums) {  // this rank's total map: the composition of its group maps
-    launch_group_maps(a, nchunks, s);
+  launch_group_maps(a, nchunks, s);
+  if (a.tot_sums) {  // this range's total map: the composition of its group maps
     const int64_t G = (nchunks + kPvGroup - 1) / kPvGroup;
     hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(1), dim3(kChunkT), 0, s, a.group_sums, a.group_org, G, (int)G,
-                       (const uint32_t *)nullptr, 0, a.tot_sums, a.tot_org);
+                       (const uint32_t *)nullptr, 0, a.tot_sums, a.tot_org, (uint32_t *)nullptr);
   }
   return hipGetLastError();
 }
-hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s) {
+hipError_t launch_pv_offsets(const PvArgs &a, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
   const int64_t nchunks = pv_chunks(a);
   const int64_t G = (nchunks + kPvGroup - 1) / kPvGroup;
-  launch_group_maps(a, nchunks, s);
   // the offsets every group starts from (they replace the group maps' delta rows) ...
   hipLaunchKernelGGL(pv_lock_chunks<false>, dim3(1), dim3(kChunkT), 0, s, a.group_sums, a.group_org, G, (int)G, a.carry_in, 0,
-                     (uint32_t *)nullptr, (uint16_t *)nullptr);
+                     (uint32_t *)nullptr, (uint16_t *)nullptr, a.carry_out);
   // ... and, from those, the offsets every chunk starts from
   hipLaunchKernelGGL(pv_lock_chunks<false>, dim3((unsigned)G), dim3(kChunkT), 0, s, a.chunk_sums, a.chunk_org, nchunks, kPvGroup,
-                     (const uint32_t *)a.group_sums, 1, (uint32_t *)nullptr, (uint16_t *)nullptr);
+                     (const uint32_t *)a.group_sums, 1, (uint32_t *)nullptr, (uint16_t *)nullptr, (uint32_t *)nullptr);
   hipLaunchKernelGGL(pv_lock_walk<true>, dim3((unsigned)nchunks), dim3(kLockT), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_pv_synthesis(const PvArgs &a, hipStream_t s) {
+  if (a.frames - a.first <= 0) return hipSuccess;
   hipLaunchKernelGGL(pv_synthesis, dim3((unsigned)pv_blocks(a.frames - a.first)), dim3(PV::T), 0, s, a);
   return hipGetLastError();
+}
+hipError_t launch_pv_analyze(const PvArgs &a, hipStream_t s) {
+  const hipError_t e = launch_pv_analysis(a, s);
+  return e == hipSuccess ? launch_pv_maps(a, s) : e;
+}
+hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s) {
+  const hipError_t e = launch_pv_offsets(a, s);
+  return e == hipSuccess ? launch_pv_synthesis(a, s) : e;
 }
 hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
@@ -1065,7 +1126,38 @@ hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s) {
   if (a.i0)  // marker-driven: one workgroup per frame
     hipLaunchKernelGGL(pv_resample_frames, dim3((unsigned)(a.frames - a.first)), dim3(256), 0, s, a);
   else if (a.out_hi > a.out_lo)
-    hipLaunchKernelGGL(pv_resample, dim3((unsigned)((a.out_hi - a.out_lo + 1023) / 1024)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pv_resample, dim3((unsigned)((a.out_hi - a.pcm_base - pv_resample_start(a) + 1023) / 1024)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+// The composition, in order, of n maps (sums / org [n][N/2]) -> out_sums / out_org [N/2]: a rank that walks its frames chunk
+// by chunk keeps every chunk's total map (12 KiB) and folds them into the rank's here.
+hipError_t launch_pv_compose_maps(uint32_t *sums, uint16_t *org, int64_t n, uint32_t *out_sums, uint16_t *out_org, hipStream_t s) {
+  if (n <= 0 || n > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(1), dim3(kChunkT), 0, s, sums, org, n, (int)n, (const uint32_t *)nullptr, 0,
+                     out_sums, out_org, (uint32_t *)nullptr);
+  return hipGetLastError();
+}
+
+namespace {
+// dst[i] = (a[i] + b[i]) * 1/sum w^2 — the two sides of an overlap-add seam, exactly as pv_fixup adds and normalises them
+__global__ __launch_bounds__(256) void pv_edge_sum(float *dst, const float *x, const float *y, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  if (y) v += y[i];
+  dst[i] = v * kPvNorm;
+}
+}  // namespace
+hipError_t launch_pv_edge_sum(float *dst, const float *x, const float *y, int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pv_edge_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, x, y, n);
+  return hipGetLastError();
+}
+
+// the constant-ratio resampler alone, over [out_lo, out_hi) from whatever a.s / a.s_origin point at (a rank's deferred edges)
+hipError_t launch_pv_resample(const PvArgs &a, hipStream_t s) {
+  if (a.out_hi <= a.out_lo) return hipSuccess;
+  hipLaunchKernelGGL(pv_resample, dim3((unsigned)((a.out_hi - a.pcm_base - pv_resample_start(a) + 1023) / 1024)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_pv(const PvArgs &a, hipStream_t s) {

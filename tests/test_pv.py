@@ -197,6 +197,136 @@ def test_gpu_sharded_equals_whole(gpu_ctx, world):
     a.free()
 
 
+def _chunk_signals():
+    rng = np.random.default_rng(5)
+    n = 3 * SR + 1234
+    sweep = (accum_sweep(n) + _tone(3000.0, n / SR + 0.01, 0.05)[:n]).astype(np.float32)
+    imp = np.zeros(n, dtype=np.float32)
+    imp[1000::7919] = 0.7  # every bin of the frames around an impulse is a peak: the records' worst case
+    rich = (0.3 * sweep + 0.02 * rng.uniform(-1, 1, n)).astype(np.float32)
+    return {"sweep": sweep, "impulses": imp, "noisy": rich}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sig", ["sweep", "impulses", "noisy"])
+def test_gpu_chunked_equals_whole(gpu_ctx, sig):
+    """The bounded arena: the signal walked in chunks of 32 .. 1024 frames (boundaries on synthesis workgroups, the frame
+    before a chunk analysed again, the phase row and the overlap-add seam carried across) gives the samples of one
+    chunk over the whole signal bit for bit, f32 and int16, at three ratios."""
+    w = _chunk_signals()[sig]
+    a = gpu_ctx.upload(w)
+    try:
+        for st in (3.0, -5.0, 12.0):
+            gpu_ctx.pv_set_chunk_frames(1 << 20)
+            whole_f, whole_i = gpu_ctx.pv_pitch_shift(a, st)
+            frames = int(np.ceil(len(w) * 2.0 ** (st / 12.0) / 256)) + 1
+            for C in (32, 96, 160, 1024):
+                assert frames > 2 * C or C == 1024
+                gpu_ctx.pv_set_chunk_frames(C)
+                f, i = gpu_ctx.pv_pitch_shift(a, st)
+                assert np.array_equal(f.view(np.uint32), whole_f.view(np.uint32)), (sig, st, C)
+                assert np.array_equal(i, whole_i), (sig, st, C)
+                only16 = gpu_ctx.pv_pitch_shift(a, st, want_f32=False)[1]
+                assert np.array_equal(only16, whole_i)
+    finally:
+        gpu_ctx.pv_set_chunk_frames(0)
+        gpu_ctx.release_scratch()
+        a.free()
+
+
+@pytest.mark.gpu
+def test_gpu_arena_is_bounded(gpu_ctx):
+    """The arena is a function of the chunk length alone: 2.36 GB at the default, the same before and after a signal
+    ten times longer; and it is one allocation the context gives back."""
+    import melonix_amd as mx
+    w = accum_sweep(SR)
+    a = gpu_ctx.upload(w)
+    gpu_ctx.release_scratch()
+    assert gpu_ctx.pv_arena_bytes() == 0
+    gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
+    b0 = gpu_ctx.pv_arena_bytes()
+    assert 2.0e9 < b0 <= 2.5e9
+    a.free()
+    a = gpu_ctx.upload(accum_sweep(10 * SR))
+    gpu_ctx.pv_pitch_shift(a, 24.0, want_i16=False)
+    assert gpu_ctx.pv_arena_bytes() == b0
+    gpu_ctx.pv_set_chunk_frames(64)
+    gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
+    assert gpu_ctx.pv_arena_bytes() < 64e6  # (the chunk maps of the recurrence: 2 x 18 MB whatever the chunk)
+    gpu_ctx.pv_set_chunk_frames(0)
+    gpu_ctx.release_scratch()
+    assert gpu_ctx.pv_arena_bytes() == 0
+    a.free()
+    assert mx  # (imported for the error type below)
+    with pytest.raises(mx.MxError):
+        gpu_ctx.pv_set_chunk_frames(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,C", [(2, 64), (3, 32), (2, 1 << 20)])
+def test_gpu_sharded_chunked_equals_whole(gpu_ctx, world, C):
+    """Ranks whose ranges are longer than a chunk (stage 1 keeps the maps only, stage 2 analyses again; the rank's edges
+    wait for the neighbours' seams) and ranks of one chunk (analysed once): the concatenated slices are the single-call
+    result bit for bit."""
+    import melonix_amd as mx
+    from melonix_amd import shard as sh
+    w = (accum_sweep(3 * SR) + _tone(3000.0, 3.0, 0.05)).astype(np.float32)
+    n = len(w)
+    a = gpu_ctx.upload(w)
+    ctxs, auds = [], []
+    try:
+        for st in (3.0, -7.0):
+            gpu_ctx.pv_set_chunk_frames(1 << 20)
+            whole_f, whole_i = gpu_ctx.pv_pitch_shift(a, st)
+            ctxs = [mx.Context(0) for _ in range(world)]
+            for c in ctxs:
+                c.pv_set_chunk_frames(C)
+            auds = [c.upload(w) for c in ctxs]
+            tots = [c.pv_shard_analyze(x, st, r, world) for r, (c, x) in enumerate(zip(ctxs, auds))]
+            all_sums = np.stack([t[0] for t in tots])
+            all_org = np.stack([t[1] for t in tots])
+            seams = [c.pv_shard_synthesize(sh.pv_fold_carry(all_sums, all_org, r) if r else None) for r, c in enumerate(ctxs)]
+            parts_f, parts_i = [], []
+            for r, c in enumerate(ctxs):
+                _, _, lo, hi = mx.pv_shard_frames(n, st, r, world)
+                f, i = c.pv_shard_finish(hi - lo, seams[r - 1][1] if r else None, seams[r + 1][0] if r < world - 1 else None)
+                parts_f.append(f)
+                parts_i.append(i)
+            assert np.array_equal(np.concatenate(parts_f).view(np.uint32), whole_f.view(np.uint32)), (st, world, C)
+            assert np.array_equal(np.concatenate(parts_i), whole_i)
+            for c, x in zip(ctxs, auds):
+                x.free()
+                c.close()
+            ctxs, auds = [], []
+    finally:
+        for c in ctxs:
+            c.close()
+        gpu_ctx.pv_set_chunk_frames(0)
+        gpu_ctx.release_scratch()
+        a.free()
+
+
+@pytest.mark.gpu
+def test_gpu_marker_render_chunked_equals_whole(gpu_ctx):
+    """The marker-driven variant through the chunked pipeline (the plan's rows travel chunk by chunk)."""
+    w = accum_sweep(3 * SR)
+    n = len(w)
+    mk = [(1000, 0, 0.0, 2.0), (n // 3, 0, -0.2, -3.0), (2 * n // 3, 0, 0.3, 5.0), (n - 1, 0, 0, 0)]
+    a = gpu_ctx.upload(w)
+    try:
+        gpu_ctx.pv_set_chunk_frames(1 << 20)
+        whole_f, whole_i = gpu_ctx.pv_render(a, SR, mk)
+        for C in (32, 128):
+            gpu_ctx.pv_set_chunk_frames(C)
+            f, i = gpu_ctx.pv_render(a, SR, mk)
+            assert np.array_equal(f.view(np.uint32), whole_f.view(np.uint32)), C
+            assert np.array_equal(i, whole_i)
+    finally:
+        gpu_ctx.pv_set_chunk_frames(0)
+        gpu_ctx.release_scratch()
+        a.free()
+
+
 def test_pv_fold_carry():
     """Rank maps applied in order to a zero row: value[org] + sums, or sums where the bin restarted (0xFFFF)."""
     from melonix_amd import shard as sh

@@ -1,12 +1,16 @@
 #!/bin/bash
-# tools/run_gpu_batch.sh — what one gpurun call runs (rewritten per experiment; this is the round's closing check):
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/run_gpu_batch.sh'
 set -u
-timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -3
-python bench.py > gpurun_out/bench_check.json 2> gpurun_out/bench_check.err
-python - <<'PY'
-import json
-d = json.load(open("gpurun_out/bench_check.json"))
-print({k: d[k] for k in ("value", "ms_per_step", "outputs_ok")}, d["roofline"]["frac"], d["phase_vocoder_supplementary"]["call_ms"])
-PY
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+export TMPDIR=/tmp
+mkdir -p gpurun_out/tl
+timeout 600 python -m pytest tests/test_pv.py -m gpu -q -x 2>&1 | tail -3
+for C in 32768 65536; do for R in 4 6 8 12; do
+  MELONIX_PV_ANALYSIS_RUN=$R MELONIX_PV_CHUNK_FRAMES=$C timeout 300 python tools/pv_ab.py 60 3 sweep 2>&1 | tail -1 | sed "s/^/C=$C run=$R /"
+done; done
+MELONIX_PV_ANALYSIS_RUN=8 timeout 300 python tools/pv_ab.py 60 3 rich 2>&1 | tail -1
+C=32768
+  MELONIX_PV_ANALYSIS_RUN=8 MELONIX_PV_CHUNK_FRAMES=$C timeout 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl/c$C -o pv -- python tools/pv_ab.py 60 3 sweep > gpurun_out/tl/c$C.log 2>&1
+  f=$(find gpurun_out/tl/c$C -name "*kernel_trace.csv" | head -1)
+  python tools/pv_timeline.py $f 60 > gpurun_out/tl/timeline_c$C.txt 2>&1
+  tail -1 gpurun_out/tl/c$C.log
+  cat gpurun_out/tl/timeline_c$C.txt
+find gpurun_out/tl -name "*.db" -delete; find gpurun_out/tl -name "*kernel_trace.csv" -delete
