@@ -76,7 +76,7 @@ struct PvPipe {
   uint32_t *carry_in = nullptr;
   float *prev_tail = nullptr, *next_head = nullptr, *head_raw = nullptr, *tail_raw = nullptr, *edge_head = nullptr, *edge_tail = nullptr;
   hipStream_t ss = nullptr, sf = nullptr;  // the side streams: the recurrence; fix-up + resampling
-  int min_scan = kPvMinScan;
+  int min_scan = kPvMinScan, scan_group = 0;
   hipEvent_t ev_begin = nullptr, ev_fin = nullptr, ev_an[kPvMaxSlots] = {}, ev_lock[kPvMaxSlots] = {}, ev_syn[kPvMaxSlots] = {},
              ev_plan[kPvMaxSlots] = {};
   // the staged job between mx_pv_shard_analyze and _finish
@@ -105,7 +105,7 @@ size_t pv_layout(PvPipe &p, int64_t C, char *base) {
   p.hann = reinterpret_cast<float *>(take(kPvN * 4));
   p.hann_scaled = reinterpret_cast<float *>(take(kPvN * 4));
   p.wsplit = reinterpret_cast<float2 *>(take(kPvM * 8));
-  const size_t nmaps = (size_t)kPvMaxScanChunks + 1, ngroups = (nmaps + 31) / 32;
+  const size_t nmaps = (size_t)kPvMaxScanChunks + 1, ngroups = (nmaps + 7) / 8;  // (groups of at least 8 maps)
   for (int si = 0; si < p.NS; ++si) {
     PvPipe::Slot &sl = p.slot[si];
     sl.apos = reinterpret_cast<int64_t *>(take((size_t)rows * 8));
@@ -170,6 +170,7 @@ int pv_pipe(mx_ctx *ctx, PvPipe **out) {
   if (!p) return fail(MX_ERR_NOMEM, "out of host memory");
   p->C = C;
   if (const char *e = getenv("MELONIX_PV_SLOTS")) p->NS = std::max(2, std::min(kPvMaxSlots, atoi(e)));
+  if (const char *e = getenv("MELONIX_PV_SCAN_GROUP")) p->scan_group = atoi(e) <= 0 ? 0 : std::max(8, std::min(64, atoi(e)));
   if (const char *e = getenv("MELONIX_PV_MIN_SCAN")) p->min_scan = std::max(16, std::min(4096, atoi(e)));
   if (const char *e = getenv("MELONIX_PV_ANALYSIS_RUN")) p->analysis_run = std::max(0, std::min(64, atoi(e)));
   p->bytes = pv_layout(*p, C, nullptr);
@@ -312,7 +313,10 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     g.s_len = (Fl - first) * kPvHs + kPvN;
     g.s_origin = c.lo * kPvHs;
     g.sample_rate = run.sample_rate;
-    g.frames_per_block = p.analysis_run;
+    // frames per analysis workgroup: 16 in one launch over the whole signal (flat from 8 to 24 there); a chunk is four
+    // rounds of workgroups at most, and what its launch loses is its ragged end — 8 (16: +0.8 ms per hour, 4: +0.2)
+    g.frames_per_block = p.analysis_run > 0 ? p.analysis_run : (K > 1 ? 8 : 16);
+    g.scan_group = p.scan_group;
     if (run.plan) {
       g.tf = o.tf;
       g.rf = o.rf;
@@ -350,7 +354,7 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
   for (int64_t k = 0; k + 1 < K; ++k) args[(size_t)k].next_head = args[(size_t)k + 1].halo;  // the right chunk's head: its workgroup 0's halo
 
   // ---- the stages of one chunk ----
-  auto analysis = [&](int64_t k) {  // main stream
+  auto analysis = [&](int64_t k, hipStream_t sm) {  // (sm: the stream the transforms go on)
     const PvChunk c = chunks[(size_t)k];
     const PvArgs &g = args[(size_t)k];
     PvPipe::Slot &sl = p.slot[k % p.NS];
@@ -369,7 +373,9 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
       PV_TRY(hipStreamWaitEvent(sm, p.ev_plan[k % p.NS], 0));  // (the side stream wrote the rows beside the previous analysis)
     }
     PV_TRY(launch_pv_analysis(g, sm));
-    PV_TRY(hipEventRecord(p.ev_an[k % p.NS], sm));
+    // (the side stream waits for S(k - 1), behind this launch on the stream, where there is one: one marker fewer between the
+    // two big kernels)
+    if (k == 0 || run.totals_only) PV_TRY(hipEventRecord(p.ev_an[k % p.NS], sm));
   };
   auto synthesis = [&](int64_t k) {  // main stream
     const PvArgs &g = args[(size_t)k];
@@ -394,7 +400,7 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     // stage 1 of a rank: transforms on the main stream, the maps (and the chunk's total map) beside the next chunk's
     for (int64_t k = 0; k < K && e == hipSuccess; ++k) {
       if (k >= p.NS) PV_TRY(hipStreamWaitEvent(sm, p.ev_lock[k % p.NS], 0));  // (the slot's maps are made)
-      analysis(k);
+      analysis(k, sm);
       PV_TRY(hipStreamWaitEvent(ss, p.ev_an[k % p.NS], 0));
       PV_TRY(launch_pv_maps(args[(size_t)k], ss));
       PV_TRY(hipEventRecord(p.ev_lock[k % p.NS], ss));
@@ -406,7 +412,7 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     // Nothing runs beside a synthesis: its workgroups take a whole CU's LDS and registers, four to a CU, exactly one round
     // of them per chunk — a small kernel beside it displaces workgroups into a second round.
     for (int64_t step = 0; step <= K && e == hipSuccess; ++step) {
-      if (step < K && !run.reuse_analysis) analysis(step);
+      if (step < K && !run.reuse_analysis) analysis(step, sm);
       const int64_t j = step - 1;
       if (j < 0) continue;
       // side stream: chunk j's recurrence ...

@@ -355,6 +355,23 @@ def test_shards_of_circular_window_kernels_equal_unsharded(N, hop, world, hours)
     assert "shard8_check ok" in r.stdout
 
 
+def test_pv_eight_hours_on_one_gpu_bounded_arena():
+    """BASELINE configs[3]'s signal through the phase vocoder on ONE GPU (tests/tools/pv8h_check.py): rounds 1-4 needed
+    ~260 GB of work buffers for it (41 KiB per frame, one allocation) and failed with MX_ERR_NOMEM; the chunked pipeline
+    walks it through 2.36 GB.  Properties of the output (int16 = clamped f32, level kept, deterministic, the output's pitch
+    track = the sweep's times 2^(3/12) by this build's own STFT) and the multi-GPU path on the same signal: two ranks played
+    on this device, each a range of ~100 chunks, equal the single call bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "tools", "pv8h_check.py"), "8", "2"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "pv8h_check ok" in r.stdout
+
+
 def test_pv_more_than_2M_frames(gpu_ctx, hour):
     """+24 semitones over the hour is 2.7 M analysis frames: the boundary fix-up kernel used to put one block row per
     32 frames on gridDim.y (capped at 65 535, i.e. 2.1 M frames) and the call failed after all the work was done."""
