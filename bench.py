@@ -277,7 +277,29 @@ def cpu_baseline(N: int, hop: int):
     f1 = max(16, min(frames, int(frames / max(cores, 1)), 20000))
     dt_1 = timed(f1, 1, api)
     dt_b = timed(min(f1, 4000), 1, False)
+    # The resynthesis leg of the metric: the reference's export loop (app.cpp:1201-1212 — process() per grain, then the int16
+    # cast) over the WHOLE hour at +3 st, as the oracle restates it.  One thread: the loop is serial in `cursor`.  The grain scan
+    # (App::preproc, once per file) is timed apart and left out, as the GPU step leaves its own grain scan out.
+    resynth = None
+    try:
+        n_all = len(probe_audio)
+        mk = [(1, 0, 0, 3.0), (n_all - 1, 0, 0, 3.0)]
+        t0 = time.perf_counter()
+        O.grains(probe_audio)
+        t_gr = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _, pcm = O.export_run(probe_audio, SR, mk)
+        t_ex = time.perf_counter() - t0 - t_gr  # (export_run scans the grains itself first)
+        t0 = time.perf_counter()
+        O.pcm_to_i16(pcm)
+        t_16 = time.perf_counter() - t0
+        resynth = {"samples": int(len(pcm)), "seconds": t_ex + t_16, "export_loop_s": t_ex, "int16_s": t_16, "grain_scan_s": t_gr,
+                   "samples_per_s": len(pcm) / (t_ex + t_16)}
+        del pcm
+    except Exception as exc:  # the STFT figure stands on its own
+        resynth = {"error": str(exc)}
     return {
+        "resynth": resynth,
         "value": frames / dt_all, "unit": "frames/s", "cores": cores, "kind": "port",
         "sample": f"first {frames} frames (N={N}, hop={hop}) of the workload sweep, oracle mxo_stft_hop (spec.cpp:44-66 "
                   f"per frame, double c2c DFT by {'the ' + provider + ' library (the FFTW3 API the reference calls)' if all_api else 'the built-in FFT'}"
@@ -314,10 +336,17 @@ def main() -> None:
                     help="torch.distributed backend of the pitch-track exchange (nccl = RCCL; gloo: test use)")
     ap.add_argument("--single-device", action="store_true",
                     help="(testing the multi-rank logic on a one-GPU box) every rank runs on GPU 0")
+    ap.add_argument("--allow-shared-device", action="store_true",
+                    help="(testing the per-rank device masking on a one-GPU box) ranks may turn out to share a physical device")
     ap.add_argument("--no-noise-secondary", action="store_true", help="skip the noise-input secondary")
     ap.add_argument("--no-pcm-gather", action="store_true", help="(multi-rank) skip the PCM all-gather secondary")
     ap.add_argument("--pcm-gather-reps", type=int, default=3)
     ap.add_argument("--no-limiter-probe", action="store_true", help="skip the power / clock sample behind roofline.limiter")
+    ap.add_argument("--n1-value", type=float, default=0.0,
+                    help="the N = 1 `value` of the same workload (a BENCH_*.json's): the line then carries efficiency_vs_n1")
+    ap.add_argument("--init-timeout", type=float, default=180.0,
+                    help="seconds the process-group start-up and the first collective may take before the rank prints a "
+                         "one-line JSON error and exits 5 instead of hanging")
     args = ap.parse_args()
 
     import torch
@@ -333,10 +362,13 @@ def main() -> None:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU implementation", file=sys.stderr)
         sys.exit(3)
-    if args.single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # The device this rank drives: LOCAL_RANK where the rank sees every GPU of the node (torch.distributed.run's default), 0
+    # where the launcher masks the devices per rank (HIP_/ROCR_VISIBLE_DEVICES: each rank then sees ONE device, its own, as
+    # ordinal 0) — or with --single-device.  The distinct-PCI check further down is the safety net for both layouts.
+    visible = torch.cuda.device_count()
+    dev_ord = 0 if (args.single_device or local_rank >= visible) else local_rank
+    torch.cuda.set_device(dev_ord)
+    dev = torch.device("cuda", dev_ord)
     dist = None
     # under torch.distributed.run (RANK set) the RCCL path is exercised even with one rank
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
@@ -344,10 +376,40 @@ def main() -> None:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        # A start-up that cannot complete (a rank that died, a fabric that does not come up) must not hang the job: a
+        # watchdog thread ends this process with a one-line JSON error if the group is not up and through its first collective
+        # in time (os._exit: a thread stuck inside RCCL cannot be unwound).
+        import datetime
+        import threading
+
+        def _give_up():
+            print(json.dumps({"error": f"process group start-up / first collective did not finish in {args.init_timeout:g} s",
+                              "rank": rank, "local_rank": local_rank, "device": dev_ord, "world_size": world,
+                              "backend": args.dist_backend, "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}),
+                  flush=True)
+            os._exit(5)
+
+        watchdog = threading.Timer(args.init_timeout, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            tmo = datetime.timedelta(seconds=max(args.init_timeout, 30.0))
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+            else:
+                dist.init_process_group("gloo", timeout=tmo)
+            first = torch.ones(1, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(first)  # the first collective builds the communicator
+            if args.dist_backend == "nccl":
+                torch.cuda.synchronize()
+            if int(first.item()) != world:
+                raise RuntimeError(f"first all-reduce returned {first.item()} for {world} ranks")
+        except Exception as exc:
+            print(json.dumps({"error": f"process group start-up failed: {exc}", "rank": rank, "local_rank": local_rank,
+                              "device": dev_ord, "world_size": world, "backend": args.dist_backend}), flush=True)
+            os._exit(5)
+        finally:
+            watchdog.cancel()
 
     import melonix_amd as mx
 
@@ -366,7 +428,7 @@ def main() -> None:
     pad = mx.MX_AUDIO_PAD
 
     audio_t = gen_shard(torch, dev, rank, world, n, pad)
-    ctx = mx.Context(local_rank)
+    ctx = mx.Context(dev_ord)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.frames_per_block:
         ctx.set_frames_per_block(args.frames_per_block)
@@ -561,8 +623,10 @@ def main() -> None:
             dt = time.perf_counter() - t0
             fpv = int(np.ceil(n * 2.0 ** (3 / 12) / 256)) + 1
             pv = {"pitch_shift_semitones": 3, "frames": fpv, "call_ms": dt * 1e3, "frames_per_s": fpv / dt,
+                  "arena_bytes": ctx.pv_arena_bytes(),
                   "output_rms": float(out16.float().pow(2).mean().sqrt().item() / 32767.0),
-                  "note": "build-defined (no reference counterpart); N=4096, synthesis hop 256, identity phase locking"}
+                  "note": "build-defined (no reference counterpart); N=4096, synthesis hop 256, identity phase locking; the signal "
+                          "walked in chunks of 32768 frames through a work arena of arena_bytes whatever its length"}
             del out16
         except Exception as exc:  # never let a supplementary figure take the headline line down
             pv = {"error": str(exc)}
@@ -572,7 +636,7 @@ def main() -> None:
     limiter = None
     if not args.no_limiter_probe:
         reps = int(min(2000, max(50, np.ceil(1.2 / max(elapsed / args.steps, 1e-5)))))
-        with PowerSampler(local_rank) as ps:
+        with PowerSampler(dev_ord) as ps:
             works = []
             for k in range(reps):
                 step(k, works, rs=rs)
@@ -594,14 +658,24 @@ def main() -> None:
     # stream), timed call -> wait() -> synchronize per repetition; equal-sized exchange padded to the largest shard.
     pcm_gather = None
     if use_dist and rs is not None and not args.no_pcm_gather:
+        # (collectives inside: every rank enters the timed part or none does — the rank-local setup is agreed on first)
+        sizes = [None] * world
+        dist.all_gather_object(sizes, int(rs["total"]))
+        m = int(max(sizes))
+        m += (-m) % 8  # whole 16-byte units
+        send = recv = None
+        setup_err = None
         try:
-            sizes = [None] * world
-            dist.all_gather_object(sizes, int(rs["total"]))
-            m = int(max(sizes))
-            m += (-m) % 8  # whole 16-byte units
             send = torch.zeros(m, dtype=torch.int16, device=dev)
             send[: rs["total"]] = rs["pcm"]
             recv = torch.empty(world * m, dtype=torch.int16, device=dev)
+        except Exception as exc:
+            setup_err = str(exc)
+        flag = torch.tensor([0 if setup_err else 1], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not bool(flag.item()):
+            pcm_gather = {"error": setup_err or "the buffers could not be allocated on another rank"}
+        else:
             ts = []
             for rep in range(args.pcm_gather_reps + 1):
                 barrier()
@@ -627,9 +701,7 @@ def main() -> None:
                           "gathered_ok": bool(okt.item()), "reps": args.pcm_gather_reps,
                           "note": "best of reps after one untimed repetition, MAX over ranks; every rank ends up with the "
                                   "whole stream (shard.gather_pcm's exchange); not part of the timed step"}
-            del send, recv
-        except Exception as exc:
-            pcm_gather = {"error": str(exc)}
+        del send, recv
 
     # labelled secondary (SURVEY 8d's optional variant): the same step on sweep + 1e-3 * U(-1,1) from PCG32 — a kernel at
     # the package power limit takes longer on data that toggles more wires; the grain table and the schedule are rebuilt
@@ -671,8 +743,8 @@ def main() -> None:
     # (one hot / throttled device, a shared device, a slow host) with the ranks' own clocks and power next to their times
     ranks = None
     if use_dist:
-        pr = torch.cuda.get_device_properties(local_rank)
-        me = {"rank": rank, "local_rank": local_rank,
+        pr = torch.cuda.get_device_properties(dev_ord)
+        me = {"rank": rank, "local_rank": local_rank, "device_ordinal": dev_ord, "visible_devices": visible,
               "pci": f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}",
               "device": pr.name, "kernel_ms": my_kern_ms, "resynth_ms": my_res_ms,
               "watts": limiter["watts"] if limiter else None, "sclk_mhz": limiter["sclk_mhz"] if limiter else None,
@@ -680,10 +752,12 @@ def main() -> None:
         ranks = [None] * world
         dist.all_gather_object(ranks, me)
         distinct = len({(r["host"], r["pci"]) for r in ranks}) == world
-        if not args.single_device and not distinct:
+        if not args.single_device and not args.allow_shared_device and not distinct:
             if rank == 0:
                 print(f"bench.py: {world} ranks but only {len({(r['host'], r['pci']) for r in ranks})} distinct devices: "
                       f"{[(r['rank'], r['pci']) for r in ranks]}", file=sys.stderr)
+                print(json.dumps({"error": "ranks share a device", "ranks": [(r["rank"], r["pci"]) for r in ranks]}), flush=True)
+            dist.destroy_process_group()  # (every rank takes this branch: `ranks` is the same list everywhere)
             sys.exit(4)
 
     if rank == 0:
@@ -746,6 +820,10 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                # (not measured in this run: PMC passes serialise the kernels and take minutes)
+                "traffic_source": ("profiles/pmc_latest.json (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                   "tools/profile_gpu.sh; quoted only while its kernel_source_sha1 equals the shipped kernel sources)")
+                                  if traffic is not None else None,
                 "kernel": f"stft_kernel<{N}>",
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_frame": balg,
@@ -756,6 +834,10 @@ def main() -> None:
             # labelled secondary: BASELINE configs[1] alone (what round 1 quoted as `value`)
             "stft_pitch_only": {"frames_per_s": world * F / (kern_ms * 1e-3), "kernel_ms": kern_ms},
             "pitch_track_sha1": local_track_sha1,
+            # which build ran: the digits mx_version() carries = sha1 over the library's sources and flags (melonix_amd/build.py);
+            # the loader refuses a library whose digits differ from the tree's
+            "library_version": mx._capi.lib().mx_version().decode(),
+            "library_src_sha": mx._capi.library_src_sha(mx._capi.lib().mx_version().decode()),
             "outputs_ok": ok,
             "outputs_check": {"pitch_max_abs_bin_error_vs_sweep": pitch_err, "pcm_rms_full_scale": pcm_rms,
                               "note": "every pitch bin in band and within 2.5 bins of the sweep's instantaneous frequency at the "
@@ -766,6 +848,10 @@ def main() -> None:
             line["resynth_setup"] = {"grain_scan_s": rs["grain_scan_s"], "grain_scan_warm_s": rs["grain_scan_warm_s"],
                                      "schedule_host_s": rs["schedule_host_s"],
                                      "note": "once per (audio, markers), before the timed region"}
+        if args.n1_value > 0:
+            # (weak: N GPUs do N times the work; strong: the same work — either way N ideal GPUs give N times the N = 1 value)
+            line["efficiency_vs_n1"] = {"value": line["value"] / (world * args.n1_value), "n1_value": args.n1_value, "n_gpus": world,
+                                        "formula": "value / (n_gpus * n1_value)"}
         if cond is not None:
             line["value_conditioned"] = cond
         if exchange is not None:
@@ -781,9 +867,23 @@ def main() -> None:
         if e2e is not None:
             line["end_to_end_supplementary"] = e2e
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(N, hop)
-            # the CPU figure is the STFT+pitch path (the reference's FFTW loop); compare like with like
-            line["gpu_over_cpu_stft_pitch"] = line["stft_pitch_only"]["frames_per_s"] / line["cpu_baseline"]["value"]
+            cb = cpu_baseline(N, hop)
+            line["cpu_baseline"] = cb
+            # `value` is the STFT+pitch path (the reference's FFTW loop) on all cores; compare like with like
+            line["gpu_over_cpu_stft_pitch"] = line["stft_pitch_only"]["frames_per_s"] / cb["value"]
+            # ... and the CPU's time for the step the GPU's `value` times: the hour's frames through the STFT on all cores + the
+            # hour's export loop on one (it is serial in the cursor) — extrapolated from the bounded STFT sample, measured for
+            # the export loop
+            rsy = cb.pop("resynth", None)
+            if rsy and "error" not in rsy and rs is not None:
+                cb["resynth_samples_per_s"] = rsy["samples_per_s"]
+                cb["resynth"] = rsy
+                cb["step_seconds"] = F / cb["value"] + rsy["seconds"]
+                cb["step_seconds_note"] = (f"{F} frames / value (STFT + pitch, {cb['cores']} threads) + {rsy['samples']} PCM samples of the "
+                                           "+3 st export loop and int16 cast on 1 thread (app.cpp:1201-1212, serial in the cursor)")
+                line["gpu_over_cpu_step"] = cb["step_seconds"] / (elapsed / args.steps)
+            elif rsy:
+                cb["resynth"] = rsy
         print(json.dumps(line), flush=True)
 
     audio.free()

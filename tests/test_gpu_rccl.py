@@ -157,3 +157,66 @@ def test_eight_ranks_on_one_device_carry_rank_records_and_the_pcm_gather():
     if log:
         with open(log, "a") as f:
             f.write(json.dumps({"world8_one_device_weak_5min": line}) + "\n")
+
+
+def _bench_ranks_by_hand(args, world, mask_devices, timeout=600):
+    """`world` bench.py processes started by hand with the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
+    each with its own HIP_VISIBLE_DEVICES when `mask_devices` — the layout of a launcher that hands every rank ONE device."""
+    port = str(_free_port())
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port})
+        if mask_devices:
+            env["HIP_VISIBLE_DEVICES"] = "0"  # (the box has one GPU: every rank's "own" device is that one)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + args, cwd=ROOT, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p_ in procs:
+        try:
+            outs.append(p_.communicate(timeout=timeout) + (p_.returncode,))
+        except subprocess.TimeoutExpired:
+            p_.kill()
+            outs.append(p_.communicate() + (-9,))
+    return outs
+
+
+def test_ranks_with_one_visible_device_each():
+    """A launcher that masks the devices per rank (HIP_VISIBLE_DEVICES) leaves every rank with ONE device, ordinal 0, whatever its
+    LOCAL_RANK: round 4's bench.py called set_device(LOCAL_RANK) and rank 1 died at start-up.  Two ranks here, LOCAL_RANK 0 and
+    1, each seeing only device 0: both run, rank 1 on ordinal 0; the gathered track is checked as in every multi-rank run."""
+    minutes = 2 * 8192 * 1758 / (60.0 * 48000.0)
+    args = ["--steps", "3", "--warmup", "1", "--conditioning", "0", "--strong-total-minutes", repr(minutes), "--no-cpu-baseline",
+            "--no-supplementary", "--no-noise-secondary", "--no-limiter-probe", "--no-resynth", "--dist-backend", "gloo",
+            "--allow-shared-device", "--n1-value", "1e8"]
+    outs = _bench_ranks_by_hand(args, 2, True)
+    assert all(rc == 0 for _, _, rc in outs), [(o[-1500:], e[-3000:], rc) for o, e, rc in outs]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    line = json.loads(lines[0])
+    assert line["outputs_ok"] and line["n_gpus"] == 2 and line["exchange"]["gathered_equals_local"] is True
+    rk = line["ranks"]
+    assert [r["local_rank"] for r in rk] == [0, 1] and [r["device_ordinal"] for r in rk] == [0, 0]
+    assert all(r["visible_devices"] == 1 for r in rk)
+    eff = line["efficiency_vs_n1"]
+    assert eff["n_gpus"] == 2 and abs(eff["value"] - line["value"] / 2e8) < 1e-12
+    assert line["library_src_sha"] and line["library_version"].endswith("src:" + line["library_src_sha"])
+
+
+def test_start_up_that_cannot_complete_ends_with_a_json_error():
+    """Rank 0 of a two-rank job whose rank 1 never shows up: instead of hanging in the rendezvous (the one failure of an 8-GPU
+    launch that cannot be debugged from outside) the process prints a one-line JSON error and exits 5 within the time-out."""
+    import time
+    port = str(_free_port())
+    env = dict(os.environ)
+    env.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port})
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--init-timeout", "8",
+                        "--minutes", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 5, (r.returncode, r.stdout[-1000:], r.stderr[-2000:])
+    assert time.time() - t0 < 120
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    err = json.loads(lines[0])
+    assert "error" in err and err["rank"] == 0 and err["world_size"] == 2
