@@ -115,9 +115,11 @@ struct Spec::Impl {
   melonix::LruTable<Range, Row, pair_hash> rows{static_cast<std::size_t>(MaxRanges)};
   // key -> "somebody asked for the magnitudes" (getSpec); false = only texels are wanted so far (requestTexRow)
   std::unordered_map<Range, bool, pair_hash> pending;
-  // the batch the worker is computing right now (key -> magnitudes wanted): a column that is asked for again while its
-  // batch is on the device is neither queued nor computed a second time
+  // the batch the worker is computing right now (key -> magnitudes wanted) and the colour scale its texel rows are made
+  // with: a column that is asked for again while its batch is on the device is neither queued nor computed a second time —
+  // as long as what is on its way is what is asked for (magnitudes; texels of THIS scale)
   std::unordered_map<Range, bool, pair_hash> inflight;
+  float inflightK = 0.f;
   std::atomic<bool> alive{true};
   std::atomic<float> texScale{0.f};  // 0 = no SpecCache attached: magnitudes only
   std::atomic<int> failures{0};
@@ -128,7 +130,10 @@ struct Spec::Impl {
   std::size_t devBudget = std::size_t(1) << 30;
   std::size_t devBudgetConfigured = devBudget;  // what MELONIX_SPEC_DEVICE_MB (or the default) asked for
   int devBudgetWarned = 0;
-  int keptSinceShrink = 0;  // batches kept since the budget was last cut: after kRegrowAfter of them it doubles back
+  // after a NOMEM cut the budget doubles back towards its configured value: after kRegrowAfter batches KEPT under the cut
+  // budget, or — while the cut budget admits no screen-sized batch at all — after kRegrowAfter batches that went by unkept
+  static constexpr int kRegrowAfter = 8;
+  int keptSinceShrink = 0, skippedSinceShrink = 0;
   // what the worker has done so far (tests, MELONIX_TIMING)
   std::atomic<std::uint64_t> nLaunchedColumns{0}, nFetchedRows{0}, nRecolouredRows{0};
 
@@ -237,27 +242,26 @@ struct Spec::Impl {
         devBatches.push_back(dev);
         devBytes += keepBytes;
         // a shortage is usually transient (the arena is released again): the budget a failure halved grows back
-        // towards its configured value once keeping works again
-        constexpr int kRegrowAfter = 8;
+        // towards its configured value once keeping has worked kRegrowAfter times
         if (devBudget < devBudgetConfigured && ++keptSinceShrink >= kRegrowAfter) {
           devBudget = std::min(devBudgetConfigured, std::max<std::size_t>(devBudget * 2, keepBytes));
-          keptSinceShrink = 0;
+          keptSinceShrink = skippedSinceShrink = 0;
         }
       } else if (rc == MX_ERR_NOMEM) {
         // still no room: the columns get computed through the staging-only path below, and the row cache asks for
         // half as much until keeping has worked kRegrowAfter times again
         devBudget /= 2;
-        keptSinceShrink = 0;
+        keptSinceShrink = skippedSinceShrink = 0;
         if (devBudgetWarned++ == 0)
           fprintf(stderr, "melonix_amd Spec worker: no device memory for the row cache (%s); budget now %zu MiB\n",
                   mx_last_error(), devBudget >> 20);
       }
     } else if (devBudget < devBudgetConfigured && keepBytes <= devBudgetConfigured) {
-      // the halved budget no longer admits a screen-sized batch: probe the configured one again every so often instead
-      // of recomputing every screen for the life of the Spec
-      if (++keptSinceShrink >= 8) {
+      // the halved budget no longer admits a screen-sized batch: probe a doubled one after kRegrowAfter such batches (a
+      // count of their own: nothing was kept) instead of recomputing every screen for the life of the Spec
+      if (++skippedSinceShrink >= kRegrowAfter) {
         devBudget = std::min(devBudgetConfigured, std::max<std::size_t>(devBudget * 2, keepBytes));
-        keptSinceShrink = 0;
+        keptSinceShrink = skippedSinceShrink = 0;
       }
     }
     if (rc == MX_ERR_NOMEM) {  // over the budget, or the keep call could not allocate: rows leave through staging only
@@ -367,6 +371,7 @@ struct Spec::Impl {
           }
         }
         inflight.swap(pending);
+        inflightK = k;
         pending.clear();
       }
       struct Landed {  // the batch is no longer in flight when this scope is left, whichever way
@@ -458,7 +463,13 @@ auto Spec::getSpec(int start, int end) const -> std::vector<float> {
     }
     if (!row->computed()) {
       auto it = impl->pending.find(key);
-      if (it != impl->pending.end()) it->second = true;  // still queued: now the magnitudes are wanted too
+      if (it != impl->pending.end()) {
+        it->second = true;  // still queued: now the magnitudes are wanted too
+      } else if (auto fl = impl->inflight.find(key); fl != impl->inflight.end() && !fl->second) {
+        // on the device for its texels alone: the magnitudes are queued behind it (a copy from the device row once the
+        // batch has landed) instead of waiting for the poll after that
+        impl->pending[key] = true;
+      }
       return {};
     }
     // only the texel row of this column was brought back so far (SpecCache was its only consumer): the worker copies
@@ -501,7 +512,10 @@ int Spec::requestTexView(int start, int end, float k, TexView &view) const {
       if (row->mag) return 2;  // the caller colours the getSpec row itself, as the reference does
       // texels of another scale and no magnitudes on the host: the worker re-colours the device row with k (or
       // computes the column again if that was released)
-      if (impl->pending.find(key) == impl->pending.end() && impl->inflight.find(key) == impl->inflight.end()) {
+      // (unless texels of this very scale, or the magnitudes — answer 2 —, are already on their way)
+      const auto fl = impl->inflight.find(key);
+      const bool coming = fl != impl->inflight.end() && (fl->second || impl->inflightK == k);
+      if (impl->pending.find(key) == impl->pending.end() && !coming) {
         impl->pending[key] = false;
         impl->wake.notify_one();
       }
