@@ -29,7 +29,7 @@ namespace {
 constexpr int kPvN = 4096, kPvM = kPvN / 2, kPvHs = 256, kPvSeam = kPvN - kPvHs;
 constexpr int64_t kPvDefaultChunk = 32768;  // frames: two slots of 32.3 KiB per frame + the ring = 2.36 GB
 constexpr int64_t kPvMaxChunk = 1 << 22;
-constexpr int kPvMaxSlots = 4;
+constexpr int kPvSlots = 2;  // (three or four buy nothing: profiles/timeline_r05_pv_pipeline.log)
 constexpr int kPvOutRing = 4;  // chunk k's synthesis writes while chunk k - 2's fix-up reads k - 2, k - 1 (head) and k - 3 (boundary)
 constexpr int kPvMinScan = 64;              // frames per scan chunk of the phase recurrence, at least
 constexpr int64_t kPvMaxScanChunks = 1536;  // one round of row-walking workgroups, six per CU
@@ -63,9 +63,8 @@ struct PvPipe {
     float *fthr;
     uint32_t *chunk_sums, *group_sums, *tot_sums;
     uint16_t *chunk_org, *group_org, *tot_org;
-  } slot[kPvMaxSlots];
-  int NS = 2;  // slots in use
-  int analysis_run = 0;  // frames per analysis workgroup (0: the kernels' default)
+  } slot[kPvSlots];
+  static constexpr int NS = kPvSlots;
   struct Out {  // what the synthesis of a chunk leaves and the fix-up / resampler read (+ the resampler's plan rows)
     float *halo, *s;
     double *tf, *rf;
@@ -76,9 +75,8 @@ struct PvPipe {
   uint32_t *carry_in = nullptr;
   float *prev_tail = nullptr, *next_head = nullptr, *head_raw = nullptr, *tail_raw = nullptr, *edge_head = nullptr, *edge_tail = nullptr;
   hipStream_t ss = nullptr, sf = nullptr;  // the side streams: the recurrence; fix-up + resampling
-  int min_scan = kPvMinScan, scan_group = 0;
-  hipEvent_t ev_begin = nullptr, ev_fin = nullptr, ev_an[kPvMaxSlots] = {}, ev_lock[kPvMaxSlots] = {}, ev_syn[kPvMaxSlots] = {},
-             ev_plan[kPvMaxSlots] = {};
+  hipEvent_t ev_begin = nullptr, ev_fin = nullptr, ev_an[kPvSlots] = {}, ev_lock[kPvSlots] = {}, ev_syn[kPvSlots] = {},
+             ev_plan[kPvSlots] = {};
   // the staged job between mx_pv_shard_analyze and _finish
   struct Shard {
     bool active = false, first = false, last = false, single = false;
@@ -105,7 +103,7 @@ size_t pv_layout(PvPipe &p, int64_t C, char *base) {
   p.hann = reinterpret_cast<float *>(take(kPvN * 4));
   p.hann_scaled = reinterpret_cast<float *>(take(kPvN * 4));
   p.wsplit = reinterpret_cast<float2 *>(take(kPvM * 8));
-  const size_t nmaps = (size_t)kPvMaxScanChunks + 1, ngroups = (nmaps + 7) / 8;  // (groups of at least 8 maps)
+  const size_t nmaps = (size_t)kPvMaxScanChunks + 1, ngroups = (nmaps + 31) / 32;
   for (int si = 0; si < p.NS; ++si) {
     PvPipe::Slot &sl = p.slot[si];
     sl.apos = reinterpret_cast<int64_t *>(take((size_t)rows * 8));
@@ -169,10 +167,6 @@ int pv_pipe(mx_ctx *ctx, PvPipe **out) {
   std::unique_ptr<PvPipe> p(new (std::nothrow) PvPipe());
   if (!p) return fail(MX_ERR_NOMEM, "out of host memory");
   p->C = C;
-  if (const char *e = getenv("MELONIX_PV_SLOTS")) p->NS = std::max(2, std::min(kPvMaxSlots, atoi(e)));
-  if (const char *e = getenv("MELONIX_PV_SCAN_GROUP")) p->scan_group = atoi(e) <= 0 ? 0 : std::max(8, std::min(64, atoi(e)));
-  if (const char *e = getenv("MELONIX_PV_MIN_SCAN")) p->min_scan = std::max(16, std::min(4096, atoi(e)));
-  if (const char *e = getenv("MELONIX_PV_ANALYSIS_RUN")) p->analysis_run = std::max(0, std::min(64, atoi(e)));
   p->bytes = pv_layout(*p, C, nullptr);
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < p->bytes)
@@ -187,15 +181,13 @@ int pv_pipe(mx_ctx *ctx, PvPipe **out) {
   PvPipe &q = *ctx->pv;
   hipError_t e = hipSuccess;
   {
-    int lo_p = 0, hi_p = 0;
-    const bool prio = !getenv("MELONIX_PV_SIDE_PRIO") || atoi(getenv("MELONIX_PV_SIDE_PRIO")) != 0;
-    e = hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-    // (the side stream's kernels are a few waves each and wait on each other: ahead of the big kernel in the dispatcher)
-    if (e == hipSuccess) e = prio ? hipStreamCreateWithPriority(&q.ss, hipStreamNonBlocking, hi_p) : hipStreamCreateWithFlags(&q.ss, hipStreamNonBlocking);
+    // (what gets the side stream's small kernels through beside a transform is their WAVE priority — s_setprio in the
+    // kernels: 0.5 ms per hour; the queue's priority measured nothing either way and is left at the default)
+    e = hipStreamCreateWithFlags(&q.ss, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&q.sf, hipStreamNonBlocking);
   }
   std::vector<hipEvent_t *> evs = {&q.ev_begin, &q.ev_fin};
-  for (int i = 0; i < kPvMaxSlots; ++i) {
+  for (int i = 0; i < kPvSlots; ++i) {
     evs.push_back(&q.ev_an[i]);
     evs.push_back(&q.ev_lock[i]);
     evs.push_back(&q.ev_syn[i]);
@@ -307,7 +299,7 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     g.chunk_org = sl.chunk_org;
     g.group_sums = sl.group_sums;
     g.group_org = sl.group_org;
-    g.scan_chunk = (int)std::max<int64_t>(p.min_scan, (Fl - first + kPvMaxScanChunks - 1) / kPvMaxScanChunks);
+    g.scan_chunk = (int)std::max<int64_t>(kPvMinScan, (Fl - first + kPvMaxScanChunks - 1) / kPvMaxScanChunks);
     g.halo = o.halo;
     g.s = o.s;
     g.s_len = (Fl - first) * kPvHs + kPvN;
@@ -315,8 +307,7 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     g.sample_rate = run.sample_rate;
     // frames per analysis workgroup: 16 in one launch over the whole signal (flat from 8 to 24 there); a chunk is four
     // rounds of workgroups at most, and what its launch loses is its ragged end — 8 (16: +0.8 ms per hour, 4: +0.2)
-    g.frames_per_block = p.analysis_run > 0 ? p.analysis_run : (K > 1 ? 8 : 16);
-    g.scan_group = p.scan_group;
+    g.frames_per_block = K > 1 ? 8 : 16;
     if (run.plan) {
       g.tf = o.tf;
       g.rf = o.rf;
@@ -473,7 +464,7 @@ void pv_release(mx_ctx *ctx) {
   pv_shard_drop(*p);
   for (hipEvent_t ev : {p->ev_begin, p->ev_fin})
     if (ev) hipEventDestroy(ev);
-  for (int i = 0; i < kPvMaxSlots; ++i)
+  for (int i = 0; i < kPvSlots; ++i)
     for (hipEvent_t ev : {p->ev_an[i], p->ev_lock[i], p->ev_syn[i], p->ev_plan[i]})
       if (ev) hipEventDestroy(ev);
   if (p->ss) hipStreamDestroy(p->ss);

@@ -85,7 +85,6 @@ struct PvArgs {
   uint32_t *group_sums;  // [ceil(chunks/32)][N/2] the same for groups of 32 chunks (the composition is two-level)
   uint16_t *group_org;
   int scan_chunk;
-  int scan_group;      // chunk maps per group of the two-level composition (0: 32)
   float *halo;        // pv_halo_floats(frames): partial sums right of each synthesis-workgroup boundary
   float *s;           // stretched signal, s_len = frames*Hs + N, index 0 = stretched time -N/2
   int64_t s_len;

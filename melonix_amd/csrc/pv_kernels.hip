@@ -529,8 +529,7 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
 // irrelevant for the rank that holds frame 0, which restarts every bin; MAP = true: this rank's total map, what the
 // other ranks need to know of it), then the groups again in parallel from their start offsets (MAP = false).
 constexpr int kChunkT = 1024, kChunkV = kPvM / kChunkT;
-constexpr int kPvGroupDefault = 32;
-__host__ inline int pv_group(const PvArgs &a) { return a.scan_group > 0 ? a.scan_group : kPvGroupDefault; }
+constexpr int kPvGroup = 32;
 template <bool MAP>
 __global__ __launch_bounds__(kChunkT) void pv_lock_chunks(uint32_t *sums, uint16_t *org, int64_t n, int per_group,
                                                           const uint32_t *init, int init_per_group, uint32_t *out_sums,
@@ -1055,7 +1054,6 @@ hipError_t launch_pv_plan_const(int64_t *apos, uint32_t *hop, double *hratio, in
 namespace {
 // the group maps of the chunk maps (chunk_sums / chunk_org stay as they are)
 void launch_group_maps(const PvArgs &a, int64_t nchunks, hipStream_t s) {
-  const int kPvGroup = pv_group(a);
   const unsigned G = (unsigned)((nchunks + kPvGroup - 1) / kPvGroup);
   hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(G), dim3(kChunkT), 0, s, a.chunk_sums, a.chunk_org, nchunks, kPvGroup,
                      (const uint32_t *)nullptr, 0, a.group_sums, a.group_org, (uint32_t *)nullptr);
@@ -1087,8 +1085,7 @@ hipError_t launch_pv_maps(const PvArgs &a0, hipStream_t s) {
   hipLaunchKernelGGL(pv_lock_walk<false>, dim3((unsigned)nchunks), dim3(kLockT), 0, s, a);
   launch_group_maps(a, nchunks, s);
   if (a.tot_sums) {  // this range's total map: the composition of its group maps
-    const int kPvGroup = pv_group(a);
-    const int64_t G = (nchunks + kPvGroup - 1) / kPvGroup;
+      const int64_t G = (nchunks + kPvGroup - 1) / kPvGroup;
     hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(1), dim3(kChunkT), 0, s, a.group_sums, a.group_org, G, (int)G,
                        (const uint32_t *)nullptr, 0, a.tot_sums, a.tot_org, (uint32_t *)nullptr);
   }
@@ -1097,7 +1094,6 @@ hipError_t launch_pv_maps(const PvArgs &a0, hipStream_t s) {
 hipError_t launch_pv_offsets(const PvArgs &a, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
   const int64_t nchunks = pv_chunks(a);
-  const int kPvGroup = pv_group(a);
   const int64_t G = (nchunks + kPvGroup - 1) / kPvGroup;
   // the offsets every group starts from (they replace the group maps' delta rows) ...
   hipLaunchKernelGGL(pv_lock_chunks<false>, dim3(1), dim3(kChunkT), 0, s, a.group_sums, a.group_org, G, (int)G, a.carry_in, 0,

@@ -1,16 +1,11 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_guard.py -q -x 2>&1 | tail -25
-timeout 900 python -m pytest tests/test_gpu_rccl.py -q -x -k "visible_device or start_up" 2>&1 | tail -15
-python bench.py > gpurun_out/bench_check.json 2> gpurun_out/bench_check.err; echo "bench rc $?"
-python - <<'PY'
-import json
-d = json.load(open("gpurun_out/bench_check.json"))
-print({k: d[k] for k in ("value", "ms_per_step", "outputs_ok", "library_src_sha")}, d["roofline"]["frac"], d["roofline"]["traffic_source"])
-print(d["phase_vocoder_supplementary"])
-cb = d["cpu_baseline"]
-print({k: cb.get(k) for k in ("value", "cores", "resynth_samples_per_s", "step_seconds")}, cb.get("resynth"), d.get("gpu_over_cpu_step"), d.get("gpu_over_cpu_stft_pitch"))
-PY
-tail -3 gpurun_out/bench_check.err
+for rep in 1 2; do
+timeout 300 python tools/pv_ab.py 60 3 sweep 2>&1 | tail -1 | cut -c1-130
+for V in lock64 noprio lock64noprio; do
+  MX_AB_LIB=melonix_amd/lib/variants/$V.so timeout 300 python tools/pv_ab.py 60 3 sweep 2>&1 | tail -1 | cut -c1-150
+  MX_AB_LIB=melonix_amd/lib/variants/$V.so MELONIX_PV_SIDE_PRIO=0 timeout 300 python tools/pv_ab.py 60 3 sweep 2>&1 | tail -1 | cut -c1-150 | sed "s/^/streamprio0 /"
+done
+MELONIX_PV_SIDE_PRIO=0 timeout 300 python tools/pv_ab.py 60 3 sweep 2>&1 | tail -1 | cut -c1-130 | sed "s/^/streamprio0 /"
+done
