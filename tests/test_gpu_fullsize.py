@@ -355,6 +355,27 @@ def test_shards_of_circular_window_kernels_equal_unsharded(N, hop, world, hours)
     assert "shard8_check ok" in r.stdout
 
 
+def test_pv_hour_is_bit_for_bit_what_the_single_launch_gave():
+    """The hour of the bench workload at +3 st through the chunked pipeline (25 chunks of 32 768 frames, 2.4 GB of arena): the
+    output's sha1s are the ones round 4's single launch over a 33 GB arena produced (`profiles/variants_r04_pv_steps.log`,
+    verdict r04 item 1's done-criterion), f32 and int16 — and the same again with chunks a quarter as long."""
+    import os
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pv_ab.py")
+    for chunk in ("", "8192"):
+        env = dict(os.environ)
+        env.pop("MX_AB_LIB", None)
+        if chunk:
+            env["MELONIX_PV_CHUNK_FRAMES"] = chunk
+        else:
+            env.pop("MELONIX_PV_CHUNK_FRAMES", None)
+        r = subprocess.run([sys.executable, tool, "60", "3", "sweep"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert "sha1 f32 7d5500cef5117a15 i16 89ee573a94112bd2" in r.stdout, r.stdout[-500:]
+
+
 def test_pv_eight_hours_on_one_gpu_bounded_arena():
     """BASELINE configs[3]'s signal through the phase vocoder on ONE GPU (tests/tools/pv8h_check.py): rounds 1-4 needed
     ~260 GB of work buffers for it (41 KiB per frame, one allocation) and failed with MX_ERR_NOMEM; the chunked pipeline
