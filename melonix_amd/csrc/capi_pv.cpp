@@ -30,6 +30,7 @@ constexpr int kPvN = 4096, kPvM = kPvN / 2, kPvHs = 256, kPvSeam = kPvN - kPvHs;
 constexpr int64_t kPvDefaultChunk = 32768;  // frames: two slots of 32.3 KiB per frame + the ring = 2.36 GB
 constexpr int64_t kPvMaxChunk = 1 << 22;
 constexpr int kPvSlots = 2;  // (three or four buy nothing: profiles/timeline_r05_pv_pipeline.log)
+constexpr int kPvPlanRing = 4;  // chunk k + 3's plan rows are written while chunk k - 1's are long read
 constexpr int kPvOutRing = 4;  // chunk k's synthesis writes while chunk k - 2's fix-up reads k - 2, k - 1 (head) and k - 3 (boundary)
 constexpr int kPvMinScan = 64;              // frames per scan chunk of the phase recurrence, at least
 constexpr int64_t kPvMaxScanChunks = 1536;  // one round of row-walking workgroups, six per CU
@@ -53,10 +54,12 @@ struct PvPipe {
   // constants: the two windows, the split twiddles of the inverse transform
   float *hann = nullptr, *hann_scaled = nullptr;
   float2 *wsplit = nullptr;
-  struct Slot {  // what the analysis of a chunk leaves and its synthesis reads
+  struct Plan {  // a chunk's analysis plan (positions, hops, stretch factors): written three chunks ahead, a ring of its own
     int64_t *apos;
     uint32_t *hop;
     double *hratio;
+  } plan[kPvPlanRing];
+  struct Slot {  // what the analysis of a chunk leaves and its synthesis reads
     float2 *xrows;
     uint2 *recs;
     uint32_t *pkmap, *pkcount;
@@ -75,8 +78,7 @@ struct PvPipe {
   uint32_t *carry_in = nullptr;
   float *prev_tail = nullptr, *next_head = nullptr, *head_raw = nullptr, *tail_raw = nullptr, *edge_head = nullptr, *edge_tail = nullptr;
   hipStream_t ss = nullptr, sf = nullptr;  // the side streams: the recurrence; fix-up + resampling
-  hipEvent_t ev_begin = nullptr, ev_fin = nullptr, ev_an[kPvSlots] = {}, ev_lock[kPvSlots] = {}, ev_syn[kPvSlots] = {},
-             ev_plan[kPvSlots] = {};
+  hipEvent_t ev_begin = nullptr, ev_fin = nullptr, ev_an[kPvSlots] = {}, ev_lock[kPvSlots] = {}, ev_syn[kPvSlots] = {};
   // the staged job between mx_pv_shard_analyze and _finish
   struct Shard {
     bool active = false, first = false, last = false, single = false;
@@ -104,11 +106,13 @@ size_t pv_layout(PvPipe &p, int64_t C, char *base) {
   p.hann_scaled = reinterpret_cast<float *>(take(kPvN * 4));
   p.wsplit = reinterpret_cast<float2 *>(take(kPvM * 8));
   const size_t nmaps = (size_t)kPvMaxScanChunks + 1, ngroups = (nmaps + 31) / 32;
+  for (auto &pl : p.plan) {
+    pl.apos = reinterpret_cast<int64_t *>(take((size_t)rows * 8));
+    pl.hop = reinterpret_cast<uint32_t *>(take((size_t)rows * 4));
+    pl.hratio = reinterpret_cast<double *>(take((size_t)rows * 8));
+  }
   for (int si = 0; si < p.NS; ++si) {
     PvPipe::Slot &sl = p.slot[si];
-    sl.apos = reinterpret_cast<int64_t *>(take((size_t)rows * 8));
-    sl.hop = reinterpret_cast<uint32_t *>(take((size_t)rows * 4));
-    sl.hratio = reinterpret_cast<double *>(take((size_t)rows * 8));
     sl.xrows = reinterpret_cast<float2 *>(take((size_t)rows * kPvM * 8));
     // (room for a peak in every bin — silence, an impulse —: only a frame's first pkcount records are ever touched)
     sl.recs = reinterpret_cast<uint2 *>(take((size_t)rows * kPvM * 8));
@@ -191,7 +195,6 @@ int pv_pipe(mx_ctx *ctx, PvPipe **out) {
     evs.push_back(&q.ev_an[i]);
     evs.push_back(&q.ev_lock[i]);
     evs.push_back(&q.ev_syn[i]);
-    evs.push_back(&q.ev_plan[i]);
   }
   for (hipEvent_t *ev : evs)
     if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
@@ -287,9 +290,9 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     g.hann = p.hann;
     g.hann_scaled = p.hann_scaled;
     g.wsplit = p.wsplit;
-    g.apos = sl.apos;
-    g.hop = sl.hop;
-    g.hratio = sl.hratio;
+    g.apos = p.plan[k % kPvPlanRing].apos;
+    g.hop = p.plan[k % kPvPlanRing].hop;
+    g.hratio = p.plan[k % kPvPlanRing].hratio;
     g.xrows = sl.xrows;
     g.recs = sl.recs;
     g.pkmap = sl.pkmap;
@@ -345,24 +348,34 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
   for (int64_t k = 0; k + 1 < K; ++k) args[(size_t)k].next_head = args[(size_t)k + 1].halo;  // the right chunk's head: its workgroup 0's halo
 
   // ---- the stages of one chunk ----
+  // the constant-ratio plan rows of chunk k, on stream st (binary64 division and floor on the device: launch_pv_plan_const)
+  auto plan_rows = [&](int64_t k, hipStream_t st) {
+    const PvArgs &g = args[(size_t)k];
+    const PvPipe::Plan &pl = p.plan[k % kPvPlanRing];
+    PV_TRY(launch_pv_plan_const(pl.apos, pl.hop, pl.hratio, g.frames, chunks[(size_t)k].lo - g.first, run.r, st));
+  };
+  // (the pipeline writes them three chunks ahead on the fix-up stream; only the rows of a run's first chunks, a marker plan's
+  // and those of a rank's maps-only pass are made in front of their analysis)
+  const bool plan_ahead = !run.plan && !run.totals_only;
   auto analysis = [&](int64_t k, hipStream_t sm) {  // (sm: the stream the transforms go on)
     const PvChunk c = chunks[(size_t)k];
     const PvArgs &g = args[(size_t)k];
-    PvPipe::Slot &sl = p.slot[k % p.NS];
+    const PvPipe::Plan &pl = p.plan[k % kPvPlanRing];
     if (run.plan) {
       const int64_t g0 = c.lo - g.first;  // global frame of local row 0
-      PV_TRY(hipMemcpyAsync(sl.apos, run.plan->apos.data() + g0, (size_t)g.frames * 8, hipMemcpyHostToDevice, sm));
-      PV_TRY(hipMemcpyAsync(sl.hop, run.plan_hop->data() + g0, (size_t)g.frames * 4, hipMemcpyHostToDevice, sm));
-      PV_TRY(hipMemcpyAsync(sl.hratio, run.plan_hratio->data() + g0, (size_t)g.frames * 8, hipMemcpyHostToDevice, sm));
+      PV_TRY(hipMemcpyAsync(pl.apos, run.plan->apos.data() + g0, (size_t)g.frames * 8, hipMemcpyHostToDevice, sm));
+      PV_TRY(hipMemcpyAsync(pl.hop, run.plan_hop->data() + g0, (size_t)g.frames * 4, hipMemcpyHostToDevice, sm));
+      PV_TRY(hipMemcpyAsync(pl.hratio, run.plan_hratio->data() + g0, (size_t)g.frames * 8, hipMemcpyHostToDevice, sm));
       // (the resampler's rows live with the chunk's stretched signal: the slot has a new tenant by the time it runs)
       PV_TRY(hipMemcpyAsync(const_cast<double *>(g.tf), run.plan->tf.data() + c.lo, (size_t)(c.hi - c.lo) * 8, hipMemcpyHostToDevice, sm));
       PV_TRY(hipMemcpyAsync(const_cast<double *>(g.rf), run.plan->rf.data() + c.lo, (size_t)(c.hi - c.lo) * 8, hipMemcpyHostToDevice, sm));
       PV_TRY(hipMemcpyAsync(const_cast<int64_t *>(g.i0), run.plan->i0.data() + c.lo, (size_t)(c.hi - c.lo + 1) * 8, hipMemcpyHostToDevice, sm));
-    } else if (k < p.NS || run.totals_only) {
-      PV_TRY(launch_pv_plan_const(sl.apos, sl.hop, sl.hratio, g.frames, c.lo - g.first, run.r, sm));
-    } else {
-      PV_TRY(hipStreamWaitEvent(sm, p.ev_plan[k % p.NS], 0));  // (the side stream wrote the rows beside the previous analysis)
+    } else if (!plan_ahead) {
+      plan_rows(k, sm);
     }
+    // (plan_ahead: the rows were written on the fix-up stream at chunk k - 3's step, in front of its ev_fin; the side stream
+    // waited for that event before chunk k - 2's recurrence, whose ev_lock S(k - 2) waited for — and S(k - 2) is in front of
+    // this launch on this stream: no wait of its own between the two big kernels)
     PV_TRY(launch_pv_analysis(g, sm));
     // (the side stream waits for S(k - 1), behind this launch on the stream, where there is one: one marker fewer between the
     // two big kernels)
@@ -402,6 +415,8 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     // of chunk k, then the fix-up and resampling of chunk k - 2 (whose right neighbour's head S(k - 1) has just left).
     // Nothing runs beside a synthesis: its workgroups take a whole CU's LDS and registers, four to a CU, exactly one round
     // of them per chunk — a small kernel beside it displaces workgroups into a second round.
+    if (plan_ahead && !run.reuse_analysis)
+      for (int64_t k = 0; k < std::min<int64_t>(K, 3); ++k) plan_rows(k, sm);
     for (int64_t step = 0; step <= K && e == hipSuccess; ++step) {
       if (step < K && !run.reuse_analysis) analysis(step, sm);
       const int64_t j = step - 1;
@@ -417,23 +432,15 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
       // the last hop of s is beyond every frame, and s[s_len] backs the interpolation's m + 1
       PV_TRY(hipMemsetAsync(gl.s + (gl.s_len - kPvHs), 0, (size_t)(kPvHs + 1) * 4, ss));
       PV_TRY(hipEventRecord(p.ev_lock[j % p.NS], ss));
-      // (what would sit between the two big kernels on the main stream: the plan rows of the slot's next tenant — the
-      // transforms and maps of chunk j have read theirs)
-      if (j + p.NS < K && !run.plan) {
-        const PvChunk cn = chunks[(size_t)(j + p.NS)];
-        const PvArgs &gn = args[(size_t)(j + p.NS)];
-        PvPipe::Slot &sn = p.slot[j % p.NS];
-        PV_TRY(launch_pv_plan_const(sn.apos, sn.hop, sn.hratio, gn.frames, cn.lo - gn.first, run.r, ss));
-        PV_TRY(hipEventRecord(p.ev_plan[j % p.NS], ss));
-      }
       // ... and, on a stream of its own (it must not hold the recurrence up, nor sit beside the synthesis the recurrence
-      // releases), chunk j - 2's fix-up and resampling: S(j - 1) is through
-      if (j >= 2) {
-        PV_TRY(hipStreamWaitEvent(sf, p.ev_syn[(j - 1) % p.NS], 0));
-        PV_TRY(launch_pv_finish(args[(size_t)j - 2], sf));
-        PV_TRY(hipEventRecord(p.ev_fin, sf));
-        PV_TRY(hipStreamWaitEvent(ss, p.ev_fin, 0));  // (S(j + 1) reuses a buffer this reads: the next chunk's recurrence releases it)
-      }
+      // releases): the plan rows of chunk j + 3 (their ring slot's last reader was chunk j - 1's maps, in front of S(j - 1)) and
+      // chunk j - 2's fix-up and resampling, S(j - 1) being through
+      if (j >= 1) PV_TRY(hipStreamWaitEvent(sf, p.ev_syn[(j - 1) % p.NS], 0));
+      if (plan_ahead && j + 3 < K) plan_rows(j + 3, sf);
+      if (j >= 2) PV_TRY(launch_pv_finish(args[(size_t)j - 2], sf));
+      PV_TRY(hipEventRecord(p.ev_fin, sf));
+      // (S(j + 1) reuses a buffer the fix-up reads, A(j + 3) reads the plan rows: the next chunk's recurrence waits for both)
+      PV_TRY(hipStreamWaitEvent(ss, p.ev_fin, 0));
       synthesis(j);
     }
     // the last two chunks' fix-up and resampling
@@ -465,7 +472,7 @@ void pv_release(mx_ctx *ctx) {
   for (hipEvent_t ev : {p->ev_begin, p->ev_fin})
     if (ev) hipEventDestroy(ev);
   for (int i = 0; i < kPvSlots; ++i)
-    for (hipEvent_t ev : {p->ev_an[i], p->ev_lock[i], p->ev_syn[i], p->ev_plan[i]})
+    for (hipEvent_t ev : {p->ev_an[i], p->ev_lock[i], p->ev_syn[i]})
       if (ev) hipEventDestroy(ev);
   if (p->ss) hipStreamDestroy(p->ss);
   if (p->sf) hipStreamDestroy(p->sf);
