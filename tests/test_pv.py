@@ -261,12 +261,21 @@ def test_gpu_arena_is_bounded(gpu_ctx):
         gpu_ctx.pv_set_chunk_frames(-1)
     # an arena the device cannot give (4 M frames per chunk: 295 GB) is refused before anything is allocated — MX_ERR_NOMEM,
     # with the sizes in the message — and the context goes on working at the default afterwards
+    # (chunks of 4 M frames want 302 GB; with 64 GB held elsewhere no MI355X has that)
+    import ctypes as C
+    from conftest import loaded_hip
+    hip = loaded_hip()
+    ballast = C.c_void_p()
+    assert hip.hipMalloc(C.byref(ballast), C.c_size_t(64 << 30)) == 0
     a = gpu_ctx.upload(w)
     gpu_ctx.pv_set_chunk_frames(1 << 22)
-    with pytest.raises(mx.MxError) as err:
-        gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
-    assert err.value.code == -3 and "MiB" in str(err.value)
-    assert gpu_ctx.pv_arena_bytes() == 0
+    try:
+        with pytest.raises(mx.MxError) as err:
+            gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
+        assert err.value.code == -3 and "MiB" in str(err.value)
+        assert gpu_ctx.pv_arena_bytes() == 0
+    finally:
+        hip.hipFree(ballast)
     gpu_ctx.pv_set_chunk_frames(0)
     y, _ = gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
     assert len(y) == len(w) and gpu_ctx.pv_arena_bytes() == b0
