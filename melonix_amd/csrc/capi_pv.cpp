@@ -498,7 +498,22 @@ int64_t mx_pv_arena_bytes(mx_ctx *ctx) {
   return ctx->pv ? (int64_t)ctx->pv->bytes : 0;
 }
 
-int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32, int16_t *d_pcm_i16) {
+}  // extern "C"
+
+namespace {
+// (host containers are used on the way — chunk lists, argument blocks —: nothing they throw may cross the C boundary)
+template <class F>
+int pv_guarded(F &&body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return fail(MX_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception &e) {
+    return fail(MX_ERR_INVALID, "phase vocoder: %s", e.what());
+  }
+}
+
+int pv_pitch_shift_dev_impl(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32, int16_t *d_pcm_i16) {
   if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
   if (!(semitones >= -48.0 && semitones <= 48.0)) return fail(MX_ERR_INVALID, "semitones out of range [-48, 48]");
   if (a->n == 0 || (!d_pcm_f32 && !d_pcm_i16)) return MX_OK;
@@ -521,6 +536,13 @@ int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, floa
   if (rc) return rc;
   if (es != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(es));
   return MX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32, int16_t *d_pcm_i16) {
+  return pv_guarded([&] { return pv_pitch_shift_dev_impl(ctx, a, semitones, d_pcm_f32, d_pcm_i16); });
 }
 
 // Marker-driven variant: the vocoder steered by the editor's markers as App::exportWav is (warped time, pitch bend).
@@ -669,7 +691,7 @@ int mx_pv_shard_frames(int64_t n, double semitones, int rank, int world, int64_t
   return MX_OK;
 }
 
-int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world, uint32_t *tot_sums_out,
+static int pv_shard_analyze_impl(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world, uint32_t *tot_sums_out,
                         uint16_t *tot_org_out) {
   if (!ctx || !a || !tot_sums_out || !tot_org_out) return fail(MX_ERR_INVALID, "bad argument");
   int64_t lo, hi, olo, ohi;
@@ -731,7 +753,7 @@ int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int ra
   return MX_OK;
 }
 
-int mx_pv_shard_synthesize(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out) {
+static int pv_shard_synthesize_impl(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out) {
   if (!ctx || !head_out || !tail_out) return fail(MX_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
   PvPipe *p = ctx->pv;
@@ -787,7 +809,7 @@ int mx_pv_shard_synthesize(mx_ctx *ctx, const uint32_t *carry_in, float *head_ou
   return MX_OK;
 }
 
-int mx_pv_shard_finish(mx_ctx *ctx, const float *prev_tail, const float *next_head, float *pcm_f32_out,
+static int pv_shard_finish_impl(mx_ctx *ctx, const float *prev_tail, const float *next_head, float *pcm_f32_out,
                        int16_t *pcm_i16_out) {
   if (!ctx) return fail(MX_ERR_INVALID, "null context");
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
@@ -831,6 +853,18 @@ int mx_pv_shard_finish(mx_ctx *ctx, const float *prev_tail, const float *next_he
   pv_shard_drop(*p);
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (finish): %s", hipGetErrorString(e));
   return MX_OK;
+}
+
+int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world, uint32_t *tot_sums_out,
+                        uint16_t *tot_org_out) {
+  return pv_guarded([&] { return pv_shard_analyze_impl(ctx, a, semitones, rank, world, tot_sums_out, tot_org_out); });
+}
+int mx_pv_shard_synthesize(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out) {
+  return pv_guarded([&] { return pv_shard_synthesize_impl(ctx, carry_in, head_out, tail_out); });
+}
+int mx_pv_shard_finish(mx_ctx *ctx, const float *prev_tail, const float *next_head, float *pcm_f32_out,
+                       int16_t *pcm_i16_out) {
+  return pv_guarded([&] { return pv_shard_finish_impl(ctx, prev_tail, next_head, pcm_f32_out, pcm_i16_out); });
 }
 
 int mx_pv_pitch_shift(mx_ctx *ctx, const mx_audio *a, double semitones, float *pcm_f32_out, int16_t *pcm_i16_out) {
