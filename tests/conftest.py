@@ -60,12 +60,20 @@ def loaded_hip():
     """ctypes handle of the HIP runtime THIS process already runs on — the one libmelonix_amd.so resolved.  (torch, if
     an earlier test imported it, carries its own copy; opening a second runtime by name would see no device.)"""
     import ctypes as C
-    path = "libamdhip64.so"
+    path, seen = "libamdhip64.so", []
     with open("/proc/self/maps") as maps:
         for line in maps:
-            if "libamdhip64" in line:
-                path = line.split()[-1]
-                break
+            if "libamdhip64" in line and line.split()[-1] not in seen:
+                seen.append(line.split()[-1])
+    # (a process that has also imported torch maps TWO runtimes: the wheel's private copy sees no device once the system
+    # runtime — the one libmelonix_amd.so is linked against — has claimed them)
+    for cand in seen:
+        if "/torch/" not in cand:
+            path = cand
+            break
+    else:
+        if seen:
+            path = seen[0]
     return C.CDLL(path)
 
 
