@@ -1,7 +1,13 @@
 #!/bin/bash
+# tools/run_gpu_batch.sh — what one gpurun call runs (rewritten per experiment; this is the round's closing check):
+#   /usr/local/graft/bin/gpurun --timeout 2700 -- 'bash tools/run_gpu_batch.sh'
 set -u
-for rep in 1 2; do
-timeout 300 python tools/pv_ab.py 60 3 sweep 2>&1 | tail -1 | cut -c1-110
-for M in 256 128 128:2 64 64:4 32 32:8 16:16; do
-  MELONIX_PV_SIDE_CUS=$M timeout 300 python tools/pv_ab.py 60 3 sweep 2>&1 | tail -1 | cut -c1-110 | sed "s/^/cus=$M /"
-done; done
+mkdir -p gpurun_out
+timeout 2100 python -m pytest tests -m gpu -q 2>&1 | tail -5
+python bench.py > gpurun_out/bench_check.json 2> gpurun_out/bench_check.err
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/bench_check.json"))
+print({k: d[k] for k in ("value", "ms_per_step", "outputs_ok", "library_src_sha")}, d["roofline"]["frac"], d["phase_vocoder_supplementary"]["call_ms"], d.get("gpu_over_cpu_step"))
+PY
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
