@@ -765,15 +765,18 @@ def main() -> None:
         achieved = balg * F / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (profiles/pmc_latest.json, written by tools/profile_gpu.sh): only
         # quoted while the profiled kernel IS the shipped one — same size, and the same kernel sources by hash
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        traffic = traffic_file = None
+        # (one file per size — profiles/pmc_latest_<N>x<hop>.json —, the default size also under its old name)
+        for pmc in (os.path.join(ROOT, "profiles", f"pmc_latest_{N}x{hop}.json"), os.path.join(ROOT, "profiles", "pmc_latest.json")):
+            if traffic is not None or not os.path.exists(pmc):
+                continue
             try:
                 with open(pmc) as f:
                     j = json.load(f)
                 if (j.get("fft") == N and j.get("hop") == hop and j.get("frames") == F
                         and j.get("kernel_source_sha1") == kernel_source_hash()):
                     traffic = j.get("hbm_bytes_per_launch")
+                    traffic_file = os.path.relpath(pmc, ROOT)
             except Exception:
                 traffic = None
         kernels = [{"name": f"stft_kernel<Plan<{N},{'16' if N == 4096 else '32'}>, hop {hop}> (magnitudes + pitch pick)",
@@ -821,7 +824,7 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 # (not measured in this run: PMC passes serialise the kernels and take minutes)
-                "traffic_source": ("profiles/pmc_latest.json (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                "traffic_source": (f"{traffic_file} (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                    "tools/profile_gpu.sh; quoted only while its kernel_source_sha1 equals the shipped kernel sources)")
                                   if traffic is not None else None,
                 "kernel": f"stft_kernel<{N}>",
