@@ -341,6 +341,7 @@ def main() -> None:
     ap.add_argument("--no-noise-secondary", action="store_true", help="skip the noise-input secondary")
     ap.add_argument("--no-pcm-gather", action="store_true", help="(multi-rank) skip the PCM all-gather secondary")
     ap.add_argument("--pcm-gather-reps", type=int, default=3)
+    ap.add_argument("--no-pv-shard", action="store_true", help="(multi-rank) skip the sharded phase-vocoder secondary")
     ap.add_argument("--no-limiter-probe", action="store_true", help="skip the power / clock sample behind roofline.limiter")
     ap.add_argument("--n1-value", type=float, default=0.0,
                     help="the N = 1 `value` of the same workload (a BENCH_*.json's): the line then carries efficiency_vs_n1")
@@ -623,10 +624,13 @@ def main() -> None:
             dt = time.perf_counter() - t0
             fpv = int(np.ceil(n * 2.0 ** (3 / 12) / 256)) + 1
             pv = {"pitch_shift_semitones": 3, "frames": fpv, "call_ms": dt * 1e3, "frames_per_s": fpv / dt,
-                  "arena_bytes": ctx.pv_arena_bytes(),
+                  "arena_bytes": ctx.pv_arena_bytes(), "arena_budget_bytes": ctx.pv_arena_budget(), "chunks": ctx.pv_last_chunks(),
+                  "arena_policy": "default: budget = a quarter of the free device memory at the context's first call; a call that "
+                                  "fits is one resident chunk, else the longest chunks the budget holds",
                   "output_rms": float(out16.float().pow(2).mean().sqrt().item() / 32767.0),
-                  "note": "build-defined (no reference counterpart); N=4096, synthesis hop 256, identity phase locking; the signal "
-                          "walked in chunks of 32768 frames through a work arena of arena_bytes whatever its length"}
+                  "note": "build-defined (no reference counterpart); N=4096, synthesis hop 256, identity phase locking; second call timed "
+                          "(the first builds the arena)"}
+            ctx.release_scratch()  # (the arena goes back before the other secondaries allocate)
             del out16
         except Exception as exc:  # never let a supplementary figure take the headline line down
             pv = {"error": str(exc)}
@@ -702,6 +706,124 @@ def main() -> None:
                           "note": "best of reps after one untimed repetition, MAX over ranks; every rank ends up with the "
                                   "whole stream (shard.gather_pcm's exchange); not part of the timed step"}
         del send, recv
+
+    # labelled secondary, multi-rank runs (north_star's "single RCCL all-gather ... to stitch the overlap-add seams"):
+    # the build-defined phase vocoder at +3 st SHARDED over the ranks — every rank holds the whole world x minutes signal and
+    # takes its range of frames; three stages on the device with two small all-gathers between them (12 KiB of phase maps and
+    # 30 KiB of overlap-add seams per rank: shard.pv_pitch_shift_rank_dev).  (a) correctness on a common 2-minute signal: the
+    # ranks' int16 slices all-gathered and concatenated = the single call's output, by sha1; (b) the workload itself: per-rank
+    # stage and all-gather times, against the same rank's single call over ITS OWN share of the audio (what N = 1 does).
+    # Every collective is entered by all ranks or by none (agree-then-enter, like the secondaries above).
+    pv_shard = None
+    if use_dist and rs is not None and not args.no_pv_shard:
+        from melonix_amd import shard as _shp
+
+        def agree(ok_here: bool) -> bool:
+            fl = torch.tensor([1 if ok_here else 0], device=dev)
+            dist.all_reduce(fl, op=dist.ReduceOp.MIN)
+            return bool(fl.item())
+
+        def run_sharded(whole_audio, want_timings):
+            tm = {} if want_timings else None
+            lo, hi, _, i16 = _shp.pv_pitch_shift_rank_dev(ctx, whole_audio, 3.0, dist, rank, world, want_f32=False, want_i16=True,
+                                                          timings=tm, agree=agree)
+            return lo, hi, i16, tm
+
+        try:
+            # (a) the common signal
+            n2 = 2 * 60 * SR
+            common_t, err = None, None
+            try:
+                common_t = gen_shard(torch, dev, 0, 1, n2, pad)
+                common = ctx.wrap_device(common_t.data_ptr(), n2, keepalive=common_t)
+                single16 = torch.empty(n2, dtype=torch.int16, device=dev)
+                ctx.pv_pitch_shift_dev(common, 3.0, None, single16.data_ptr())
+                torch.cuda.synchronize()
+            except Exception as exc:
+                err = str(exc)
+            if not agree(err is None):
+                raise RuntimeError(err or "the set-up failed on another rank")
+            lo2, hi2, part16, _ = run_sharded(common, False)
+            cnts = [None] * world
+            dist.all_gather_object(cnts, (int(lo2), int(hi2)))
+            m2 = max(h - l for l, h in cnts)
+            m2 += (-m2) % 8
+            send = torch.zeros(m2, dtype=torch.int16, device=dev)
+            send[: hi2 - lo2] = part16
+            recv = torch.empty(world * m2, dtype=torch.int16, device=dev)
+            dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))
+            cat16 = torch.cat([recv[r * m2: r * m2 + (cnts[r][1] - cnts[r][0])] for r in range(world)])
+            sha_cat = hashlib.sha1(cat16.cpu().numpy().tobytes()).hexdigest()
+            sha_single = hashlib.sha1(single16.cpu().numpy().tobytes()).hexdigest()
+            contiguous = cnts[0][0] == 0 and cnts[-1][1] == n2 and all(cnts[r][1] == cnts[r + 1][0] for r in range(world - 1))
+            common_ok = agree(sha_cat == sha_single and contiguous)
+            del send, recv, cat16, single16, part16, common_t
+            common.free()
+            # (b) the workload: world x minutes of audio whole on every rank, the rank's own share through the single call first
+            err, whole_t, whole = None, None, None
+            local_ms = None
+            try:
+                out16 = torch.empty(n, dtype=torch.int16, device=dev)
+                ctx.pv_pitch_shift_dev(audio, 3.0, None, out16.data_ptr())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.pv_pitch_shift_dev(audio, 3.0, None, out16.data_ptr())
+                torch.cuda.synchronize()
+                local_ms = (time.perf_counter() - t0) * 1e3
+                local_chunks = ctx.pv_last_chunks()
+                del out16
+                whole_t = gen_shard(torch, dev, 0, 1, world * n, pad)
+                whole = ctx.wrap_device(whole_t.data_ptr(), world * n, keepalive=whole_t)
+            except Exception as exc:
+                err = str(exc)
+            if not agree(err is None):
+                raise RuntimeError(err or "the set-up failed on another rank")
+            run_sharded(whole, False)  # (arenas of the ranks' ranges built, RCCL's small-message path warm)
+            barrier()
+            t0 = time.perf_counter()
+            lo_w, hi_w, mine16, tm = run_sharded(whole, True)
+            wall_ms = (time.perf_counter() - t0) * 1e3
+            # the rank's slice against the single call over the WHOLE signal on the same device (chunked where it does not fit)
+            slice_ok = None
+            try:
+                all16 = torch.empty(world * n, dtype=torch.int16, device=dev)
+                ctx.pv_pitch_shift_dev(whole, 3.0, None, all16.data_ptr())
+                torch.cuda.synchronize()
+                slice_ok = bool(torch.equal(all16[lo_w:hi_w], mine16))
+                del all16
+            except Exception:
+                slice_ok = None  # (not enough memory beside the bench's own buffers: not a failure of the sharded path)
+            flo, fhi, _, _ = mx.pv_shard_frames(world * n, 3.0, rank, world)
+            me_pv = {"rank": rank, "frames": int(fhi - flo), "samples": int(hi_w - lo_w), "chunks": tm["chunks"], "arena_bytes": tm["arena_bytes"],
+                     "stage1_ms": tm["stage1_s"] * 1e3, "gather_maps_ms": tm["gather_maps_s"] * 1e3, "stage2_ms": tm["stage2_s"] * 1e3,
+                     "gather_seams_ms": tm["gather_seams_s"] * 1e3, "stage3_ms": tm["stage3_s"] * 1e3, "wall_ms": wall_ms,
+                     "single_call_over_own_share_ms": local_ms, "single_call_chunks": local_chunks,
+                     "slice_equals_single_call_over_the_whole_signal": slice_ok}
+            per = [None] * world
+            dist.all_gather_object(per, me_pv)
+            slow = max(p["wall_ms"] for p in per)
+            fr_total = sum(p["frames"] for p in per)
+            pv_shard = {"pitch_shift_semitones": 3, "world_size": world, "backend": dist.get_backend(),
+                        "common_signal": {"seconds": 120, "sha1_concatenated_int16": sha_cat, "sha1_single_call_int16": sha_single,
+                                          "equal_on_every_rank": common_ok, "ranges": cnts},
+                        "frames_total": fr_total, "wall_ms_max_over_ranks": slow, "frames_per_s": fr_total / (slow * 1e-3),
+                        "efficiency_vs_single_call_over_own_share": min(p["single_call_over_own_share_ms"] for p in per) / slow,
+                        "slices_equal_single_call": (all(p["slice_equals_single_call_over_the_whole_signal"] is True for p in per)
+                                                     if all(p["slice_equals_single_call_over_the_whole_signal"] is not None for p in per) else None),
+                        "exchanged_bytes_per_rank": _shp.PV_MAP_BYTES + _shp.PV_SEAM_BYTES, "ranks": per,
+                        "note": "every rank holds the whole signal; stage 1 = analysis + phase maps of its range, all-gather of the maps, "
+                                "stage 2 = carry folded on the device, offsets, synthesis, resampling into the rank's int16 slice, all-gather "
+                                "of the overlap-add seams, stage 3 = the slice's edges; host clock around the blocking calls, second pass; "
+                                "efficiency = the fastest rank's single call over one rank's share of the audio / the slowest rank's wall time"}
+            del whole_t, mine16
+            whole.free()
+            ctx.release_scratch()
+        except Exception as exc:  # (raised on every rank or on none: see `agree`)
+            pv_shard = {"error": str(exc)}
+            try:
+                ctx.release_scratch()
+            except Exception:
+                pass
 
     # labelled secondary (SURVEY 8d's optional variant): the same step on sweep + 1e-3 * U(-1,1) from PCG32 — a kernel at
     # the package power limit takes longer on data that toggles more wires; the grain table and the schedule are rebuilt
@@ -863,6 +985,8 @@ def main() -> None:
             line["ranks"] = ranks
         if pcm_gather is not None:
             line["pcm_gather_secondary"] = pcm_gather
+        if pv_shard is not None:
+            line["pv_shard_secondary"] = pv_shard
         if noise is not None:
             line["noise_input_secondary"] = noise
         if pv is not None:

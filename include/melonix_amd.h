@@ -271,19 +271,33 @@ int mx_export_wav(mx_ctx *ctx, const float *host_wav, int64_t n, int sampleRate,
 int mx_pv_pitch_shift(mx_ctx *ctx, const mx_audio *a, double semitones, float *pcm_f32_out,
                       int16_t *pcm_i16_out);
 /* Same, outputs stay in HBM (either may be NULL); blocks until done.
- * WORK ARENA: bounded, whatever the signal's length.  The vocoder walks the signal in chunks of 32768 frames (8.4 M
- * stretched samples) through two slots of spectra + peak records (32.3 KiB per frame of a chunk) and a ring of three
- * stretched-signal buffers: 2.36 GB in one allocation, made at the first call, kept by the context for the next one and
- * released by mx_ctx_release_scratch / mx_ctx_destroy; MX_ERR_NOMEM (checked against hipMemGetInfo before allocating) if
- * the device cannot give that much.  Chunks meet on multiples of 32 frames — the synthesis workgroups — and hand each
- * other the phase row and the overlap-add seam the way the ranks of a multi-GPU run do (below): the output is bit-identical
- * whatever the chunk length.  mx_pv_set_chunk_frames changes it (rounded up to a multiple of 32; 0 = the default; the
- * environment variable MELONIX_PV_CHUNK_FRAMES sets the default): a smaller arena for a small GPU share, or a test that
- * wants many chunk boundaries in a short signal.  mx_pv_arena_bytes: what the context holds right now (0 before the
- * first call).  While a call runs, a second internal stream carries the next chunk's analysis; both are joined before
- * the call returns. */
+ * WORK ARENA: one device allocation with a BUDGET, made at the first call, kept by the context for the next one (regrown
+ * only when a call needs another shape) and released by mx_ctx_release_scratch / mx_ctx_destroy.
+ *   budget   mx_pv_set_arena_budget(ctx, bytes); 0 (the default) = the environment variable MELONIX_PV_ARENA_MB if set,
+ *            else a quarter of what hipMemGetInfo reports free when the context first needs an arena (taken once, kept
+ *            until mx_ctx_release_scratch).  mx_pv_arena_budget: the budget in force.  An arena above a newly set budget
+ *            is given back at once.
+ *   resident a call whose frames fit the budget (34 KiB per frame: spectra 16 KiB, peak records 16 KiB, the stretched
+ *            signal, maps and plan rows; 27.5 GB for an hour at +3 semitones) is ONE chunk: analysis, phase recurrence
+ *            and synthesis each run once over the whole call, and a rank of a multi-GPU run (below) analyses its frames
+ *            once.
+ *   chunked  what does not fit (8 h on one GPU) is walked in chunks — the longest multiple of 32 frames of which two
+ *            slots of spectra + records and a ring of four stretched-signal buffers (70.6 KiB per frame of a chunk) fit
+ *            the budget.  Chunks meet on multiples of 32 frames — the synthesis workgroups — and hand each other the
+ *            phase row and the overlap-add seam the way the ranks of a multi-GPU run do: the output is bit-identical
+ *            whatever the chunk length, resident included.  While a chunked call runs, two internal streams carry the
+ *            phase recurrence and the fix-up / resampling beside the transforms; both are joined before the call returns.
+ *   MX_ERR_NOMEM (checked against hipMemGetInfo before allocating) if the device cannot give the arena, or if the
+ *            budget is below what the smallest chunks need (two slots of 32 frames: 4.8 MiB).
+ * mx_pv_set_chunk_frames(frames > 0) overrides the policy with two-slot chunks of exactly that length (rounded up to a
+ * multiple of 32; 0 = back to the budget; the environment variable MELONIX_PV_CHUNK_FRAMES likewise): a test that wants
+ * many chunk boundaries in a short signal.  mx_pv_arena_bytes: what the context holds right now (0 before the first
+ * call).  mx_pv_last_chunks: the number of chunks the last run over this arena took (1 = resident). */
 int mx_pv_set_chunk_frames(mx_ctx *ctx, int64_t frames);
+int mx_pv_set_arena_budget(mx_ctx *ctx, int64_t bytes);
+int64_t mx_pv_arena_budget(mx_ctx *ctx);
 int64_t mx_pv_arena_bytes(mx_ctx *ctx);
+int64_t mx_pv_last_chunks(mx_ctx *ctx);
 int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32,
                           int16_t *d_pcm_i16);
 
@@ -306,11 +320,16 @@ int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_ma
  * input and takes a contiguous range of frames (boundaries on multiples of 32 frames, so the sums group exactly
  * as in a single-GPU run and the concatenated outputs are bit-identical to mx_pv_pitch_shift's).  The caller does
  * the two small exchanges between the stages with its own collective (melonix_amd/shard.py: RCCL / gloo
- * all-gathers): the per-rank phase totals after stage 1, the seams after stage 2.  A rank walks its range through the
- * same bounded arena as a single GPU walks the whole signal; a rank whose range is longer than one chunk therefore
- * analyses its frames twice (stage 1 keeps the maps only, stage 2 analyses again with the carry), a range of one chunk
- * once.  Between stage 2 and stage 3 the rank's outputs wait on the device (6 bytes per output sample).  Every rank needs
- * at least 32 frames of its own.
+ * all-gathers): the per-rank phase totals after stage 1, the seams after stage 2.  A rank works inside the same budgeted
+ * arena as a single GPU (above): a range that fits the budget stays RESIDENT between the stages and is analysed once
+ * (stage 1 = analysis + maps, stage 2 = offsets + synthesis from the rows stage 1 left); only a range beyond the budget is
+ * walked in chunks, and then analysed twice (stage 1 keeps the maps only, stage 2 analyses again with the carry).  Every
+ * rank needs at least 32 frames of its own.
+ * Two forms.  Host pointers (mx_pv_shard_analyze / _synthesize / _finish): the exchanged rows travel through host memory
+ * and the rank's outputs wait in library-owned device buffers (6 bytes per output sample) until stage 3 downloads them.
+ * Device pointers (the _dev forms): everything a rank exchanges stays in HBM, laid out as the two all-gathers move it — each
+ * stage writes the rank's entry of the next all-gather's send buffer and reads the previous all-gather's receive buffer
+ * as it is — and the PCM goes straight into the caller's device buffers.
  *   mx_pv_shard_frames      the rank's frame range and the output samples [out_lo, out_hi) it will deliver
  *   mx_pv_shard_analyze     stage 1; tot_sums_out[2048] / tot_org_out[2048]: this rank's frames as one map of the
  *                           phase row: bin k ends at value[org[k]] + sums[k] (mod 2^32), or at sums[k] where
@@ -319,7 +338,15 @@ int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_ma
  *                           ranks applied in order to a zero row (NULL on rank 0);
  *                           head_out / tail_out[3840]: raw partial sums either side of the rank's frames
  *   mx_pv_shard_finish      stage 3; prev_tail = rank-1's tail_out (NULL on rank 0), next_head = rank+1's head_out
- *                           (NULL on the last rank); out_hi-out_lo samples each (host, either may be NULL) */
+ *                           (NULL on the last rank); out_hi-out_lo samples each (host, either may be NULL)
+ *   mx_pv_shard_analyze_dev     stage 1; d_map_out: 12 KiB on the device = 2048 uint32 sums then 2048 uint16 source bins
+ *   mx_pv_shard_synthesize_dev  stage 2; d_maps_all: [world] x 12 KiB, the all-gathered stage-1 entries (the maps of the
+ *                               ranks below are folded into the rank's carry on the device); d_pcm_f32 / d_pcm_i16:
+ *                               out_hi - out_lo samples each on the device (either may be NULL), complete but for the
+ *                               rank's edges; d_seams_out: 30 KiB = head then tail, 3840 floats each
+ *   mx_pv_shard_finish_dev      stage 3; d_seams_all: [world] x 30 KiB, the all-gathered stage-2 entries; fills the edges
+ *                               of the PCM buffers given to stage 2
+ * Every stage blocks until its device work is done. */
 int mx_pv_shard_frames(int64_t n, double semitones, int rank, int world, int64_t *frame_lo, int64_t *frame_hi,
                        int64_t *out_lo, int64_t *out_hi);
 int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world,
@@ -327,6 +354,10 @@ int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int ra
 int mx_pv_shard_synthesize(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out);
 int mx_pv_shard_finish(mx_ctx *ctx, const float *prev_tail, const float *next_head, float *pcm_f32_out,
                        int16_t *pcm_i16_out);
+int mx_pv_shard_analyze_dev(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world, void *d_map_out);
+int mx_pv_shard_synthesize_dev(mx_ctx *ctx, const void *d_maps_all, float *d_pcm_f32, int16_t *d_pcm_i16,
+                               void *d_seams_out);
+int mx_pv_shard_finish_dev(mx_ctx *ctx, const void *d_seams_all);
 
 /* ---- waveform min/max pyramid ---------------------------------------------------
  * Replaces App::calcPicks (app.cpp:347-378): level l = floor(n / 2^(l+1)) {min,max} pairs over blocks

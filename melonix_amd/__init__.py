@@ -260,8 +260,23 @@ class Context:
                                                C.c_void_p(d_f32 or 0), C.c_void_p(d_i16 or 0)))
 
     def pv_set_chunk_frames(self, frames: int):
-        """Frames per chunk of the phase vocoder's pipeline (rounded up to a multiple of 32; 0 = the default, 32768)."""
+        """Override of the phase vocoder's arena policy: two-slot chunks of exactly `frames` frames (rounded up to a multiple of
+        32); 0 = back to the budget (resident when the call fits, else the longest chunks it holds)."""
         _capi.check(_capi.lib().mx_pv_set_chunk_frames(self.handle, int(frames)))
+
+    def pv_set_arena_budget(self, nbytes: int):
+        """Bytes the phase vocoder's work arena may take; 0 = the default (MELONIX_PV_ARENA_MB, else a quarter of the free memory)."""
+        _capi.check(_capi.lib().mx_pv_set_arena_budget(self.handle, int(nbytes)))
+
+    def pv_arena_budget(self) -> int:
+        v = int(_capi.lib().mx_pv_arena_budget(self.handle))
+        if v < 0:
+            _capi.check(v)
+        return v
+
+    def pv_last_chunks(self) -> int:
+        """Chunks the last phase-vocoder run of this context took (1 = resident)."""
+        return int(_capi.lib().mx_pv_last_chunks(self.handle))
 
     def pv_arena_bytes(self) -> int:
         """Bytes of the phase vocoder's work arena this context holds (0 before the first call)."""
@@ -315,6 +330,18 @@ class Context:
         nh = None if next_head is None else np.ascontiguousarray(next_head, dtype=np.float32)
         _capi.check(_capi.lib().mx_pv_shard_finish(self.handle, _ptr(pt), _ptr(nh), _ptr(f32), _ptr(i16)))
         return f32, i16
+
+    # (the same stages with everything on the device: pointers are integers, e.g. torch tensors' data_ptr())
+    def pv_shard_analyze_dev(self, audio: Audio, semitones: float, rank: int, world: int, d_map_out: int):
+        _capi.check(_capi.lib().mx_pv_shard_analyze_dev(self.handle, audio.handle, float(semitones), rank, world,
+                                                        C.c_void_p(d_map_out)))
+
+    def pv_shard_synthesize_dev(self, d_maps_all: int, d_f32: int | None, d_i16: int | None, d_seams_out: int):
+        _capi.check(_capi.lib().mx_pv_shard_synthesize_dev(self.handle, C.c_void_p(d_maps_all), C.c_void_p(d_f32 or 0),
+                                                           C.c_void_p(d_i16 or 0), C.c_void_p(d_seams_out)))
+
+    def pv_shard_finish_dev(self, d_seams_all: int):
+        _capi.check(_capi.lib().mx_pv_shard_finish_dev(self.handle, C.c_void_p(d_seams_all)))
 
     def minmax_pyramid(self, audio: Audio):
         """App::calcPicks on the GPU -> list of (count_l, 2) float32 arrays {min,max}, one per level."""

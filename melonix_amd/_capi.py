@@ -101,7 +101,10 @@ SIGNATURES = {
     "mx_resynth_to_wav": (_i, [_vp, _vp, _vp, _i64, _i64, C.c_char_p, _i, _i]),
     "mx_export_wav": (_i, [_vp, _vp, _i64, _i, _vp, _i, C.c_char_p, _i]),
     "mx_pv_set_chunk_frames": (_i, [_vp, _i64]),
+    "mx_pv_set_arena_budget": (_i, [_vp, _i64]),
+    "mx_pv_arena_budget": (_i64, [_vp]),
     "mx_pv_arena_bytes": (_i64, [_vp]),
+    "mx_pv_last_chunks": (_i64, [_vp]),
     "mx_pv_pitch_shift": (_i, [_vp, _vp, _d, _vp, _vp]),
     "mx_pv_pitch_shift_dev": (_i, [_vp, _vp, _d, _vp, _vp]),
     "mx_pv_render_length": (_i64, [_i64, _i, _vp, _i]),
@@ -113,6 +116,9 @@ SIGNATURES = {
     "mx_pv_shard_analyze": (_i, [_vp, _vp, _d, _i, _i, _vp, _vp]),
     "mx_pv_shard_synthesize": (_i, [_vp, _vp, _vp, _vp]),
     "mx_pv_shard_finish": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mx_pv_shard_analyze_dev": (_i, [_vp, _vp, _d, _i, _i, _vp]),
+    "mx_pv_shard_synthesize_dev": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mx_pv_shard_finish_dev": (_i, [_vp, _vp]),
     "mx_minmax_pyramid": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "mx_minmax_pyramid_dev": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "mx_minmax_range": (None, [_vp, _i64, _vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f)]),

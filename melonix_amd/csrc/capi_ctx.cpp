@@ -8,15 +8,13 @@ using namespace mx;
 
 namespace mx {
 namespace {
-thread_local std::string g_err;
+thread_local char g_err[512] = "";  // (no std::string: recording an error must not allocate — mx_guard's handlers call fail)
 }
-int fail(int code, const char *fmt, ...) {
-  char buf[512];
+int fail(int code, const char *fmt, ...) noexcept {
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
-  g_err = buf;
   return code;
 }
 
@@ -180,7 +178,7 @@ void stage_trim(mx_ctx *ctx) {
 
 extern "C" {
 
-const char *mx_last_error(void) { return g_err.c_str(); }
+const char *mx_last_error(void) { return g_err; }
 // (MX_SRC_SHA: melonix_amd/build.py source_sha() — 12 hex digits of the sha1 over the library's sources and compile flags)
 #ifndef MX_SRC_SHA
 #define MX_SRC_SHA "unknown"
@@ -188,172 +186,205 @@ const char *mx_last_error(void) { return g_err.c_str(); }
 const char *mx_version(void) { return "melonix_amd 0.1.0 gfx950 src:" MX_SRC_SHA; }
 
 int mx_ctx_create(int device, mx_ctx **out) {
-  if (!out) return fail(MX_ERR_INVALID, "out is null");
-  *out = nullptr;
-  int ndev = 0;
-  hipError_t e = hipGetDeviceCount(&ndev);
-  if (e != hipSuccess || ndev <= 0)
-    return fail(MX_ERR_DEVICE, "no HIP device visible (%s); melonix_amd has no CPU path",
-                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
-  if (device < 0 || device >= ndev) return fail(MX_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(MX_ERR_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device,
-                prop.gcnArchName);
-  HIP_TRY(hipSetDevice(device));
-  mx_ctx *c = new (std::nothrow) mx_ctx();
-  if (!c) return fail(MX_ERR_NOMEM, "out of host memory");
-  c->device = device;
-  e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    delete c;
-    return fail(MX_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
-  }
-  c->stream = c->own_stream;
-  *out = c;
-  return MX_OK;
+  return mx_guard([&]() -> int {
+    if (!out) return fail(MX_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+      return fail(MX_ERR_DEVICE, "no HIP device visible (%s); melonix_amd has no CPU path",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(MX_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(MX_ERR_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device,
+                  prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    mx_ctx *c = new (std::nothrow) mx_ctx();
+    if (!c) return fail(MX_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      return fail(MX_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return MX_OK;
+  });
 }
 
 void mx_ctx_destroy(mx_ctx *ctx) {
-  if (!ctx) return;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  for (auto &kv : ctx->tables) {
-    hipFree(kv.second.tw2);
-    hipFree(kv.second.tw3);
-    hipFree(kv.second.ubase);
-    hipFree(kv.second.wext);
-  }
-  for (auto &kv : ctx->wtabs) hipFree(kv.second);
-  for (auto &st : ctx->stage) hipFree(st.p);
-  for (auto &st : ctx->chain) hipFree(st.p);
-  pv_release(ctx);
-  hipStreamDestroy(ctx->own_stream);
-  delete ctx;
+  mx_guard_void([&] {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->tables) {
+      hipFree(kv.second.tw2);
+      hipFree(kv.second.tw3);
+      hipFree(kv.second.ubase);
+      hipFree(kv.second.wext);
+    }
+    for (auto &kv : ctx->wtabs) hipFree(kv.second);
+    for (auto &st : ctx->stage) hipFree(st.p);
+    for (auto &st : ctx->chain) hipFree(st.p);
+    pv_release(ctx);
+    hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+  });
 }
 
 int mx_ctx_set_stream(mx_ctx *ctx, void *hip_stream) {
-  if (!ctx) return fail(MX_ERR_INVALID, "null context");
-  ctx->stream = (hipStream_t)hip_stream;  // NULL is the HIP null stream (torch's default stream)
-  return MX_OK;
+  return mx_guard([&]() -> int {
+    if (!ctx) return fail(MX_ERR_INVALID, "null context");
+    ctx->stream = (hipStream_t)hip_stream;  // NULL is the HIP null stream (torch's default stream)
+    return MX_OK;
+  });
 }
 
 int mx_ctx_use_own_stream(mx_ctx *ctx) {
-  if (!ctx) return fail(MX_ERR_INVALID, "null context");
-  ctx->stream = ctx->own_stream;
-  return MX_OK;
+  return mx_guard([&]() -> int {
+    if (!ctx) return fail(MX_ERR_INVALID, "null context");
+    ctx->stream = ctx->own_stream;
+    return MX_OK;
+  });
 }
 
 int mx_ctx_synchronize(mx_ctx *ctx) {
-  if (!ctx) return fail(MX_ERR_INVALID, "null context");
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return MX_OK;
+  return mx_guard([&]() -> int {
+    if (!ctx) return fail(MX_ERR_INVALID, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MX_OK;
+  });
 }
 
 int mx_ctx_release_scratch(mx_ctx *ctx) {
-  if (!ctx) return fail(MX_ERR_INVALID, "null context");
-  HIP_TRY(hipSetDevice(ctx->device));
-  {
-    std::lock_guard<std::mutex> lk(ctx->stage_mu);
-    for (auto &st : ctx->stage) {
-      hipFree(st.p);
-      st = {};
+  return mx_guard([&]() -> int {
+    if (!ctx) return fail(MX_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    {
+      std::lock_guard<std::mutex> lk(ctx->stage_mu);
+      for (auto &st : ctx->stage) {
+        hipFree(st.p);
+        st = {};
+      }
     }
-  }
-  {
-    std::lock_guard<std::mutex> lk(ctx->pv_mu);
-    pv_release(ctx);  // (a staged multi-GPU job lives in that arena: it ends here)
-  }
-  {
-    std::lock_guard<std::mutex> lk(ctx->zc_mu);
-    ctx->zc_scratch = ZcBitmaps{};
-    for (auto &st : ctx->chain) {
-      hipFree(st.p);
-      st = {};
+    {
+      std::lock_guard<std::mutex> lk(ctx->pv_mu);
+      pv_release(ctx);  // (a staged multi-GPU job lives in that arena: it ends here)
+      ctx->pv_budget_auto = 0;  // (the automatic budget is taken again from what is free at the next first use)
     }
-  }
-  return MX_OK;
+    {
+      std::lock_guard<std::mutex> lk(ctx->zc_mu);
+      ctx->zc_scratch = ZcBitmaps{};
+      for (auto &st : ctx->chain) {
+        hipFree(st.p);
+        st = {};
+      }
+    }
+    return MX_OK;
+  });
 }
 
 int mx_pinned_alloc(mx_ctx *ctx, size_t bytes, void **out) {
-  if (!ctx || !out) return fail(MX_ERR_INVALID, "null context / out");
-  *out = nullptr;
-  if (bytes == 0) return MX_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
-  if (e != hipSuccess) {
+  return mx_guard([&]() -> int {
+    if (!ctx || !out) return fail(MX_ERR_INVALID, "null context / out");
     *out = nullptr;
-    return fail(MX_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
-  }
-  return MX_OK;
+    if (bytes == 0) return MX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      *out = nullptr;
+      return fail(MX_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    return MX_OK;
+  });
 }
 
 void mx_pinned_free(mx_ctx *ctx, void *p) {
-  if (!p) return;
-  if (ctx) hipSetDevice(ctx->device);
-  hipHostFree(p);
+  mx_guard_void([&] {
+    if (!p) return;
+    if (ctx) hipSetDevice(ctx->device);
+    hipHostFree(p);
+  });
 }
 
 int mx_ctx_set_frames_per_block(mx_ctx *ctx, int g) {  // tuning knob (bench sweeps)
-  if (!ctx || g < 0) return fail(MX_ERR_INVALID, "bad argument");
-  ctx->frames_per_block = g;
-  return MX_OK;
+  return mx_guard([&]() -> int {
+    if (!ctx || g < 0) return fail(MX_ERR_INVALID, "bad argument");
+    ctx->frames_per_block = g;
+    return MX_OK;
+  });
 }
 
 // ---- audio ------------------------------------------------------------------
 int mx_audio_upload(mx_ctx *ctx, const float *host_wav, int64_t n, mx_audio **out) {
-  if (!ctx || !out || n < 0 || (n > 0 && !host_wav)) return fail(MX_ERR_INVALID, "bad argument");
-  if (n > 0x7fffffffLL - 2 * MX_AUDIO_PAD)
-    return fail(MX_ERR_INVALID, "audio longer than the reference's int sample indices allow");
-  HIP_TRY(hipSetDevice(ctx->device));
-  mx_audio *a = new (std::nothrow) mx_audio();
-  if (!a) return fail(MX_ERR_NOMEM, "out of host memory");
-  const size_t total = (size_t)n + 2 * (size_t)MX_AUDIO_PAD;
-  hipError_t e = hipMalloc(&a->d_padded, total * sizeof(float));
-  if (e == hipSuccess) e = hipMemsetAsync(a->d_padded, 0, total * sizeof(float), ctx->stream);
-  if (e == hipSuccess && n > 0)
-    e = hipMemcpyAsync(a->d_padded + MX_AUDIO_PAD, host_wav, (size_t)n * sizeof(float), hipMemcpyHostToDevice,
-                       ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) {
-    if (a->d_padded) hipFree(a->d_padded);
-    delete a;
-    return fail(MX_ERR_DEVICE, "audio upload: %s", hipGetErrorString(e));
-  }
-  a->n = n;
-  a->owned = true;
-  *out = a;
-  return MX_OK;
+  return mx_guard([&]() -> int {
+    if (!ctx || !out || n < 0 || (n > 0 && !host_wav)) return fail(MX_ERR_INVALID, "bad argument");
+    if (n > 0x7fffffffLL - 2 * MX_AUDIO_PAD)
+      return fail(MX_ERR_INVALID, "audio longer than the reference's int sample indices allow");
+    HIP_TRY(hipSetDevice(ctx->device));
+    mx_audio *a = new (std::nothrow) mx_audio();
+    if (!a) return fail(MX_ERR_NOMEM, "out of host memory");
+    const size_t total = (size_t)n + 2 * (size_t)MX_AUDIO_PAD;
+    hipError_t e = hipMalloc(&a->d_padded, total * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(a->d_padded, 0, total * sizeof(float), ctx->stream);
+    if (e == hipSuccess && n > 0)
+      e = hipMemcpyAsync(a->d_padded + MX_AUDIO_PAD, host_wav, (size_t)n * sizeof(float), hipMemcpyHostToDevice,
+                         ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      if (a->d_padded) hipFree(a->d_padded);
+      delete a;
+      return fail(MX_ERR_DEVICE, "audio upload: %s", hipGetErrorString(e));
+    }
+    a->n = n;
+    a->owned = true;
+    *out = a;
+    return MX_OK;
+  });
 }
 
 int mx_audio_wrap_device(mx_ctx *ctx, const float *d_padded, int64_t n, mx_audio **out) {
-  if (!ctx || !out || !d_padded || n < 0) return fail(MX_ERR_INVALID, "bad argument");
-  if (reinterpret_cast<uintptr_t>(d_padded) & 15)  // the kernels use 8- and 16-byte loads of the samples
-    return fail(MX_ERR_INVALID, "device audio buffer must be 16-byte aligned");
-  mx_audio *a = new (std::nothrow) mx_audio();
-  if (!a) return fail(MX_ERR_NOMEM, "out of host memory");
-  a->d_padded = const_cast<float *>(d_padded);
-  a->n = n;
-  a->owned = false;
-  *out = a;
-  return MX_OK;
+  return mx_guard([&]() -> int {
+    if (!ctx || !out || !d_padded || n < 0) return fail(MX_ERR_INVALID, "bad argument");
+    if (reinterpret_cast<uintptr_t>(d_padded) & 15)  // the kernels use 8- and 16-byte loads of the samples
+      return fail(MX_ERR_INVALID, "device audio buffer must be 16-byte aligned");
+    mx_audio *a = new (std::nothrow) mx_audio();
+    if (!a) return fail(MX_ERR_NOMEM, "out of host memory");
+    a->d_padded = const_cast<float *>(d_padded);
+    a->n = n;
+    a->owned = false;
+    *out = a;
+    return MX_OK;
+  });
 }
 
-int64_t mx_audio_length(const mx_audio *a) { return a ? a->n : -1; }
+int64_t mx_audio_length(const mx_audio *a) {
+  return mx_guard([&]() -> int64_t {
+    return a ? a->n : -1;
+  });
+}
 
 int mx_audio_free(mx_ctx *ctx, mx_audio *a) {
-  if (!a) return MX_OK;
-  if (a->owned) {
-    if (ctx) {
-      hipSetDevice(ctx->device);
-      hipStreamSynchronize(ctx->stream);
+  return mx_guard([&]() -> int {
+    if (!a) return MX_OK;
+    if (a->owned) {
+      if (ctx) {
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+      }
+      hipFree(a->d_padded);
     }
-    hipFree(a->d_padded);
-  }
-  delete a;
-  return MX_OK;
+    delete a;
+    return MX_OK;
+  });
 }
-void mx_free(void *p) { free(p); }
+void mx_free(void *p) {
+  mx_guard_void([&] {
+    free(p);
+  });
+}
 
 }  // extern "C"

@@ -22,8 +22,55 @@
 
 namespace mx {
 
-// records the message mx_last_error returns on this thread and hands `code` back
-int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// records the message mx_last_error returns on this thread and hands `code` back (a fixed thread-local buffer: recording an
+// error allocates nothing and cannot throw — it is what the handlers below call)
+int fail(int code, const char *fmt, ...) noexcept __attribute__((format(printf, 2, 3)));
+
+// NOTHING THROWN CROSSES extern "C" (SURVEY 8b "Errors": the reference's callers get empty results, never exceptions; an
+// exception that reached the C boundary would std::terminate the editor).  By construction: the body of EVERY entry point of
+// capi_*.cpp is a lambda run by one of these three — tests/test_abi.py checks that of the sources, tests/cpp/fault_sweep.cpp makes
+// operator new fail at the k-th call inside the library for every k and watches the statuses.
+//   mx_guard       entry points that return a status (int) or a count / size that is negative on error (int64_t)
+//   mx_guard_or    entry points that return a value (time maps: double, float, int): `fallback` + the error recorded
+//   mx_guard_void  entry points that return nothing (destructors, pure out-parameter helpers)
+template <class T, class F>
+T mx_guard_or(T fallback, F &&body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    fail(MX_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception &e) {
+    fail(MX_ERR_INVALID, "%s", e.what());
+  } catch (...) {
+    fail(MX_ERR_INVALID, "unknown exception");
+  }
+  return fallback;
+}
+template <class F>
+auto mx_guard(F &&body) noexcept -> decltype(body()) {
+  using R = decltype(body());
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return (R)fail(MX_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception &e) {
+    return (R)fail(MX_ERR_INVALID, "%s", e.what());
+  } catch (...) {
+    return (R)fail(MX_ERR_INVALID, "unknown exception");
+  }
+}
+template <class F>
+void mx_guard_void(F &&body) noexcept {
+  try {
+    body();
+  } catch (const std::bad_alloc &) {
+    fail(MX_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception &e) {
+    fail(MX_ERR_INVALID, "%s", e.what());
+  } catch (...) {
+    fail(MX_ERR_INVALID, "unknown exception");
+  }
+}
 
 #define HIP_TRY(expr)                                                                       \
   do {                                                                                      \
@@ -69,6 +116,9 @@ struct mx_ctx {
   std::mutex pv_mu;
   mx::PvPipe *pv = nullptr;
   int64_t pv_chunk_frames = 0;
+  // the arena's budget: set (mx_pv_set_arena_budget; 0 = not set) and the automatic one (a quarter of the free device memory when
+  // the context first needed an arena; forgotten by mx_ctx_release_scratch)
+  int64_t pv_budget_bytes = 0, pv_budget_auto = 0;
 };
 
 struct mx_audio {

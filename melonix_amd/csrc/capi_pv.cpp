@@ -2,9 +2,12 @@
 // One unit of the C-ABI implementation behind include/melonix_amd.h (see capi_internal.h).  There is no CPU compute path:
 // every transform entry point needs a live gfx950 device and fails with MX_ERR_DEVICE otherwise.
 //
-// The vocoder walks the signal CHUNK BY CHUNK through a work arena whose size does not depend on the signal's length
-// (round 5; rounds 1-4 laid the whole signal's spectra, records and offsets out at once: 41 KiB per frame, 33 GB for an
-// hour at +3 st, and an 8-hour signal did not fit the GPU).  What one chunk hands the next is what one rank of a
+// The vocoder works inside a work arena with a memory BUDGET (round 6: mx_pv_set_arena_budget / MELONIX_PV_ARENA_MB; the
+// default is a quarter of what the device has free at the context's first phase-vocoder call).  A call whose frames fit the
+// budget is ONE chunk: its spectra stay resident between analysis and synthesis (one slot, 34 KiB per frame: 27.5 GB for an
+// hour at +3 st) and a rank of a multi-GPU run analyses its frames once.  What does not fit is walked CHUNK BY CHUNK, two
+// slots alternating, with the longest chunk the budget holds (round 5: a fixed 32768 frames whatever was free; rounds 1-4 laid
+// the whole signal out at 41 KiB per frame and an 8-hour signal did not fit the GPU).  What one chunk hands the next is what one rank of a
 // multi-GPU run hands its neighbour (pv_kernels.hip, mx_pv_shard_*): the frame before the chunk is analysed again as its
 // row 0, the dense offset row behind the chunk's last frame is the next chunk's carry_in, and the N - Hs samples across
 // the boundary are the left chunk's raw tail plus the right chunk's raw head.  Chunks start on multiples of 32 frames
@@ -27,7 +30,6 @@ namespace mx {
 
 namespace {
 constexpr int kPvN = 4096, kPvM = kPvN / 2, kPvHs = 256, kPvSeam = kPvN - kPvHs;
-constexpr int64_t kPvDefaultChunk = 32768;  // frames: two slots of 32.3 KiB per frame + the ring = 2.36 GB
 constexpr int64_t kPvMaxChunk = 1 << 22;
 constexpr int kPvSlots = 2;  // (three or four buy nothing: profiles/timeline_r05_pv_pipeline.log)
 constexpr int kPvPlanRing = 4;  // chunk k + 3's plan rows are written while chunk k - 1's are long read
@@ -47,7 +49,18 @@ int64_t pv_first_output_at(int64_t q, double r, int64_t n) {
 }
 }  // namespace
 
+// What an arena is made for: chunks of C frames; `slots` sets of spectra + records (one: the call is a single chunk and
+// its rows stay resident; two: chunks alternate), and the rings of the pipeline (one entry each where there is one chunk).
+struct PvShape {
+  int64_t C = 0;
+  int slots = kPvSlots, outs = kPvOutRing, plans = kPvPlanRing;
+  bool operator==(const PvShape &o) const { return C == o.C && slots == o.slots && outs == o.outs && plans == o.plans; }
+};
+constexpr PvShape pv_chunked(int64_t C) { return PvShape{C, kPvSlots, kPvOutRing, kPvPlanRing}; }
+constexpr PvShape pv_resident(int64_t C) { return PvShape{C, 1, 1, 1}; }
+
 struct PvPipe {
+  PvShape shape;
   int64_t C = 0;  // frames per chunk (a multiple of 32); a slot has room for C + 32 frames and the row before them
   char *base = nullptr;
   size_t bytes = 0;
@@ -58,7 +71,7 @@ struct PvPipe {
     int64_t *apos;
     uint32_t *hop;
     double *hratio;
-  } plan[kPvPlanRing];
+  } plan[kPvPlanRing] = {};
   struct Slot {  // what the analysis of a chunk leaves and its synthesis reads
     float2 *xrows;
     uint2 *recs;
@@ -66,35 +79,41 @@ struct PvPipe {
     float *fthr;
     uint32_t *chunk_sums, *group_sums, *tot_sums;
     uint16_t *chunk_org, *group_org, *tot_org;
-  } slot[kPvSlots];
-  static constexpr int NS = kPvSlots;
+  } slot[kPvSlots] = {};
+  int NS = kPvSlots, NOUT = kPvOutRing, NPLAN = kPvPlanRing;  // the entries of `shape` (slot / out / plan of chunk k: k % N..)
   struct Out {  // what the synthesis of a chunk leaves and the fix-up / resampler read (+ the resampler's plan rows)
     float *halo, *s;
     double *tf, *rf;
     int64_t *i0;
-  } out[kPvOutRing];
+  } out[kPvOutRing] = {};
   uint32_t *carry[2];  // the dense offset row behind chunk k's last frame: carry[k & 1]
   // one rank of a multi-GPU run: what it gets from its neighbours and owes them
   uint32_t *carry_in = nullptr;
   float *prev_tail = nullptr, *next_head = nullptr, *head_raw = nullptr, *tail_raw = nullptr, *edge_head = nullptr, *edge_tail = nullptr;
   hipStream_t ss = nullptr, sf = nullptr;  // the side streams: the recurrence; fix-up + resampling
   hipEvent_t ev_begin = nullptr, ev_fin = nullptr, ev_an[kPvSlots] = {}, ev_lock[kPvSlots] = {}, ev_syn[kPvSlots] = {};
+  int64_t last_chunks = 0;  // chunks of the last run (mx_pv_last_chunks)
   // the staged job between mx_pv_shard_analyze and _finish
   struct Shard {
     bool active = false, first = false, last = false, single = false;
+    int rank = 0, world = 1;
     const mx_audio *a = nullptr;
     double semitones = 0., r = 1.;
     int64_t F_lo = 0, F_hi = 0, out_lo = 0, out_hi = 0;
     bool synthesized = false;
     int64_t head_hi = 0, tail_lo = 0;  // the outputs [out_lo, head_hi) and [tail_lo, out_hi) wait for the neighbours' seams
-    float *d_f = nullptr;  // the rank's outputs between stage 2 and stage 3 (device)
+    // the rank's outputs between stage 2 and stage 3 (device): the library's own buffers (host-pointer entry points, freed
+    // by pv_shard_drop) or the caller's (_dev entry points)
+    bool own_pcm = false;
+    float *d_f = nullptr;
     int16_t *d_i = nullptr;
   } job;
 };
 
 namespace {
 
-size_t pv_layout(PvPipe &p, int64_t C, char *base) {
+size_t pv_layout(PvPipe &p, const PvShape &sh, char *base) {
+  const int64_t C = sh.C;
   const int64_t rows = C + 32 + 1;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -105,13 +124,15 @@ size_t pv_layout(PvPipe &p, int64_t C, char *base) {
   p.hann = reinterpret_cast<float *>(take(kPvN * 4));
   p.hann_scaled = reinterpret_cast<float *>(take(kPvN * 4));
   p.wsplit = reinterpret_cast<float2 *>(take(kPvM * 8));
-  const size_t nmaps = (size_t)kPvMaxScanChunks + 1, ngroups = (nmaps + 31) / 32;
-  for (auto &pl : p.plan) {
+  // (a short chunk cuts its frame axis into fewer scan chunks than the cap: pv_run's scan_chunk is at least kPvMinScan frames)
+  const size_t nmaps = (size_t)std::min<int64_t>(kPvMaxScanChunks, (rows + kPvMinScan - 1) / kPvMinScan) + 1, ngroups = (nmaps + 31) / 32;
+  for (int i = 0; i < sh.plans; ++i) {
+    PvPipe::Plan &pl = p.plan[i];
     pl.apos = reinterpret_cast<int64_t *>(take((size_t)rows * 8));
     pl.hop = reinterpret_cast<uint32_t *>(take((size_t)rows * 4));
     pl.hratio = reinterpret_cast<double *>(take((size_t)rows * 8));
   }
-  for (int si = 0; si < p.NS; ++si) {
+  for (int si = 0; si < sh.slots; ++si) {
     PvPipe::Slot &sl = p.slot[si];
     sl.xrows = reinterpret_cast<float2 *>(take((size_t)rows * kPvM * 8));
     // (room for a peak in every bin — silence, an impulse —: only a frame's first pkcount records are ever touched)
@@ -126,7 +147,8 @@ size_t pv_layout(PvPipe &p, int64_t C, char *base) {
     sl.tot_sums = reinterpret_cast<uint32_t *>(take(kPvM * 4));
     sl.tot_org = reinterpret_cast<uint16_t *>(take(kPvM * 2));
   }
-  for (auto &o : p.out) {
+  for (int i = 0; i < sh.outs; ++i) {
+    PvPipe::Out &o = p.out[i];
     o.halo = reinterpret_cast<float *>(take((size_t)pv_halo_floats(C + 32) * 4));
     o.s = reinterpret_cast<float *>(take(((size_t)(C + 32) * kPvHs + kPvN + 8) * 4));
     o.tf = reinterpret_cast<double *>(take((size_t)rows * 8));
@@ -143,35 +165,104 @@ size_t pv_layout(PvPipe &p, int64_t C, char *base) {
   p.edge_tail = reinterpret_cast<float *>(take((kPvSeam + 8) * 4));
   return off;
 }
+size_t pv_shape_bytes(const PvShape &sh) {
+  PvPipe tmp;
+  return pv_layout(tmp, sh, nullptr);
+}
 
 void pv_shard_drop(PvPipe &p) {
-  hipFree(p.job.d_f);
-  hipFree(p.job.d_i);
+  if (p.job.own_pcm) {
+    hipFree(p.job.d_f);
+    hipFree(p.job.d_i);
+  }
   p.job = PvPipe::Shard{};
 }
 
-int64_t pv_chunk_setting(const mx_ctx *ctx) {
+// ---- the arena's policy -------------------------------------------------------------------------------------------------
+// The budget: mx_pv_set_arena_budget, else MELONIX_PV_ARENA_MB, else a quarter of what the device had free when the context
+// first needed an arena (taken once and kept until mx_ctx_release_scratch: a budget that followed the free memory call by call
+// would rebuild the arena call by call).
+int pv_budget(mx_ctx *ctx, size_t *out) {
+  if (ctx->pv_budget_bytes > 0) {
+    *out = (size_t)ctx->pv_budget_bytes;
+    return MX_OK;
+  }
+  if (const char *e = getenv("MELONIX_PV_ARENA_MB")) {
+    const long long mb = atoll(e);
+    if (mb > 0) {
+      *out = (size_t)mb << 20;
+      return MX_OK;
+    }
+  }
+  if (ctx->pv_budget_auto <= 0) {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (ctx->pv) free_b += ctx->pv->bytes;  // (what the context holds already counts as available to it)
+    ctx->pv_budget_auto = (int64_t)std::max<size_t>(free_b / 4, (size_t)64 << 20);
+  }
+  *out = (size_t)ctx->pv_budget_auto;
+  return MX_OK;
+}
+
+// The shape of the arena a call over `frames` frames wants.  An explicit chunk length (mx_pv_set_chunk_frames /
+// MELONIX_PV_CHUNK_FRAMES: tests that want many chunk boundaries in a short signal) is taken as it is, two slots; otherwise one
+// resident chunk if the budget holds the call's frames, else the longest chunks (multiples of 32 frames) two slots of which
+// fit the budget.
+int pv_shape_for(mx_ctx *ctx, int64_t frames, PvShape *out) {
   int64_t C = ctx->pv_chunk_frames;
   if (C <= 0)
     if (const char *e = getenv("MELONIX_PV_CHUNK_FRAMES")) C = atoll(e);
-  if (C <= 0) C = kPvDefaultChunk;
-  C = std::min<int64_t>(kPvMaxChunk, (C + 31) / 32 * 32);
-  return C;
-}
-
-// The pipe of the context, built (or rebuilt for another chunk length) on demand.  Caller holds ctx->pv_mu.
-int pv_pipe(mx_ctx *ctx, PvPipe **out) {
-  HIP_TRY(hipSetDevice(ctx->device));  // HIP's current device is per thread
-  const int64_t C = pv_chunk_setting(ctx);
-  if (ctx->pv && ctx->pv->C == C) {
-    *out = ctx->pv;
+  if (C > 0) {
+    *out = pv_chunked(std::min<int64_t>(kPvMaxChunk, (C + 31) / 32 * 32));
     return MX_OK;
   }
+  size_t budget = 0;
+  const int rc = pv_budget(ctx, &budget);
+  if (rc) return rc;
+  const int64_t Fr = std::max<int64_t>(32, (frames + 31) / 32 * 32);
+  if (pv_shape_bytes(pv_resident(Fr)) <= budget) {
+    *out = pv_resident(Fr);
+    return MX_OK;
+  }
+  // bytes are affine in C up to the 256-byte roundings: solve, then step down onto the budget
+  const size_t b0 = pv_shape_bytes(pv_chunked(32)), b1 = pv_shape_bytes(pv_chunked(32 + 32 * 1024));
+  if (b0 > budget)
+    return fail(MX_ERR_NOMEM, "phase-vocoder arena budget of %zu MiB is below the %zu MiB the smallest chunks need", budget >> 20, (b0 >> 20) + 1);
+  const double per32 = (double)(b1 - b0) / 1024.0;
+  C = 32 + 32 * (int64_t)((double)(budget - b0) / per32);
+  C = std::min<int64_t>(kPvMaxChunk, std::max<int64_t>(32, C));
+  while (C > 32 && pv_shape_bytes(pv_chunked(C)) > budget) C -= 32;
+  *out = pv_chunked(C);
+  return MX_OK;
+}
+
+// The pipe of the context for a call over `frames` frames, built (or rebuilt in another shape) on demand.  An arena that
+// holds the call in one chunk is kept whatever it was made for; so is a chunked one of the wanted chunk length.  Caller holds
+// ctx->pv_mu.
+int pv_pipe(mx_ctx *ctx, int64_t frames, PvPipe **out) {
+  HIP_TRY(hipSetDevice(ctx->device));  // HIP's current device is per thread
+  PvShape want;
+  int rc = pv_shape_for(ctx, frames, &want);
+  if (rc) return rc;
+  const bool pinned = want.slots == kPvSlots && (ctx->pv_chunk_frames > 0 || getenv("MELONIX_PV_CHUNK_FRAMES"));
+  if (ctx->pv) {
+    const PvShape &have = ctx->pv->shape;
+    const bool keep = pinned ? have == want : (have.C >= (frames + 31) / 32 * 32 || have == want);
+    if (keep) {
+      *out = ctx->pv;
+      return MX_OK;
+    }
+  }
+  const int64_t C = want.C;
   pv_release(ctx);
   std::unique_ptr<PvPipe> p(new (std::nothrow) PvPipe());
   if (!p) return fail(MX_ERR_NOMEM, "out of host memory");
+  p->shape = want;
   p->C = C;
-  p->bytes = pv_layout(*p, C, nullptr);
+  p->NS = want.slots;
+  p->NOUT = want.outs;
+  p->NPLAN = want.plans;
+  p->bytes = pv_layout(*p, want, nullptr);
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < p->bytes)
     return fail(MX_ERR_NOMEM, "phase-vocoder work arena: %zu MiB needed for chunks of %lld frames, %zu MiB free", p->bytes >> 20,
@@ -180,7 +271,7 @@ int pv_pipe(mx_ctx *ctx, PvPipe **out) {
   const hipError_t em = hipMalloc(&mem, p->bytes);
   if (em != hipSuccess) return fail(MX_ERR_NOMEM, "phase-vocoder work arena (%zu MiB): %s", p->bytes >> 20, hipGetErrorString(em));
   p->base = static_cast<char *>(mem);
-  pv_layout(*p, C, p->base);
+  pv_layout(*p, want, p->base);
   ctx->pv = p.release();
   PvPipe &q = *ctx->pv;
   hipError_t e = hipSuccess;
@@ -268,12 +359,15 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
   const hipStream_t sm = ctx->stream, ss = p.ss, sf = p.sf;
   const std::vector<PvChunk> chunks = pv_chunks_of(run.F_lo, run.F_hi, p.C);
   const int64_t K = (int64_t)chunks.size();
+  if (K > 1 && (p.NS < kPvSlots || p.NOUT < kPvOutRing || p.NPLAN < kPvPlanRing))
+    return fail(MX_ERR_INVALID, "phase vocoder: %lld chunks through an arena made for one", (long long)K);
+  p.last_chunks = K;
   hipError_t e = hipSuccess;
   std::vector<PvArgs> args((size_t)K);
   for (int64_t k = 0; k < K; ++k) {
     const PvChunk c = chunks[(size_t)k];
     PvPipe::Slot &sl = p.slot[k % p.NS];
-    PvPipe::Out &o = p.out[k % kPvOutRing];
+    PvPipe::Out &o = p.out[k % p.NOUT];
     const int64_t first = c.lo > 0 ? 1 : 0, Fl = c.hi - c.lo + first;
     PvArgs &g = args[(size_t)k];
     g = PvArgs{};
@@ -290,9 +384,9 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     g.hann = p.hann;
     g.hann_scaled = p.hann_scaled;
     g.wsplit = p.wsplit;
-    g.apos = p.plan[k % kPvPlanRing].apos;
-    g.hop = p.plan[k % kPvPlanRing].hop;
-    g.hratio = p.plan[k % kPvPlanRing].hratio;
+    g.apos = p.plan[k % p.NPLAN].apos;
+    g.hop = p.plan[k % p.NPLAN].hop;
+    g.hratio = p.plan[k % p.NPLAN].hratio;
     g.xrows = sl.xrows;
     g.recs = sl.recs;
     g.pkmap = sl.pkmap;
@@ -351,7 +445,7 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
   // the constant-ratio plan rows of chunk k, on stream st (binary64 division and floor on the device: launch_pv_plan_const)
   auto plan_rows = [&](int64_t k, hipStream_t st) {
     const PvArgs &g = args[(size_t)k];
-    const PvPipe::Plan &pl = p.plan[k % kPvPlanRing];
+    const PvPipe::Plan &pl = p.plan[k % p.NPLAN];
     PV_TRY(launch_pv_plan_const(pl.apos, pl.hop, pl.hratio, g.frames, chunks[(size_t)k].lo - g.first, run.r, st));
   };
   // (the pipeline writes them three chunks ahead on the fix-up stream; only the rows of a run's first chunks, a marker plan's
@@ -360,13 +454,16 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
   auto analysis = [&](int64_t k, hipStream_t sm) {  // (sm: the stream the transforms go on)
     const PvChunk c = chunks[(size_t)k];
     const PvArgs &g = args[(size_t)k];
-    const PvPipe::Plan &pl = p.plan[k % kPvPlanRing];
+    const PvPipe::Plan &pl = p.plan[k % p.NPLAN];
     if (run.plan) {
       const int64_t g0 = c.lo - g.first;  // global frame of local row 0
       PV_TRY(hipMemcpyAsync(pl.apos, run.plan->apos.data() + g0, (size_t)g.frames * 8, hipMemcpyHostToDevice, sm));
       PV_TRY(hipMemcpyAsync(pl.hop, run.plan_hop->data() + g0, (size_t)g.frames * 4, hipMemcpyHostToDevice, sm));
       PV_TRY(hipMemcpyAsync(pl.hratio, run.plan_hratio->data() + g0, (size_t)g.frames * 8, hipMemcpyHostToDevice, sm));
-      // (the resampler's rows live with the chunk's stretched signal: the slot has a new tenant by the time it runs)
+      // (the resampler's rows live with the chunk's stretched signal: the slot has a new tenant by the time it runs.  Its
+      // last reader was the resampling of chunk k - 4 on the fix-up stream, queued at step k - 1 with an ev_fin behind it:
+      // the event's latest record is that one when this is called)
+      if (k >= p.NOUT) PV_TRY(hipStreamWaitEvent(sm, p.ev_fin, 0));
       PV_TRY(hipMemcpyAsync(const_cast<double *>(g.tf), run.plan->tf.data() + c.lo, (size_t)(c.hi - c.lo) * 8, hipMemcpyHostToDevice, sm));
       PV_TRY(hipMemcpyAsync(const_cast<double *>(g.rf), run.plan->rf.data() + c.lo, (size_t)(c.hi - c.lo) * 8, hipMemcpyHostToDevice, sm));
       PV_TRY(hipMemcpyAsync(const_cast<int64_t *>(g.i0), run.plan->i0.data() + c.lo, (size_t)(c.hi - c.lo + 1) * 8, hipMemcpyHostToDevice, sm));
@@ -486,47 +583,69 @@ void pv_release(mx_ctx *ctx) {
 extern "C" {
 
 int mx_pv_set_chunk_frames(mx_ctx *ctx, int64_t frames) {
-  if (!ctx || frames < 0) return fail(MX_ERR_INVALID, "bad argument");
-  std::lock_guard<std::mutex> plk(ctx->pv_mu);
-  ctx->pv_chunk_frames = frames;  // (the arena is rebuilt by the next call that needs another size)
-  return MX_OK;
+  return mx_guard([&]() -> int {
+    if (!ctx || frames < 0) return fail(MX_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> plk(ctx->pv_mu);
+    ctx->pv_chunk_frames = frames;  // (the arena is rebuilt by the next call that needs another size)
+    return MX_OK;
+  });
 }
 
 int64_t mx_pv_arena_bytes(mx_ctx *ctx) {
-  if (!ctx) return fail(MX_ERR_INVALID, "null context");
-  std::lock_guard<std::mutex> plk(ctx->pv_mu);
-  return ctx->pv ? (int64_t)ctx->pv->bytes : 0;
+  return mx_guard([&]() -> int64_t {
+    if (!ctx) return fail(MX_ERR_INVALID, "null context");
+    std::lock_guard<std::mutex> plk(ctx->pv_mu);
+    return ctx->pv ? (int64_t)ctx->pv->bytes : 0;
+  });
+}
+
+int mx_pv_set_arena_budget(mx_ctx *ctx, int64_t bytes) {
+  return mx_guard([&]() -> int {
+    if (!ctx || bytes < 0) return fail(MX_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> plk(ctx->pv_mu);
+    ctx->pv_budget_bytes = bytes;
+    // (an arena above the new budget goes back now; one inside it is kept for as long as it serves)
+    if (bytes > 0 && ctx->pv && ctx->pv->bytes > (size_t)bytes) pv_release(ctx);
+    return MX_OK;
+  });
+}
+
+int64_t mx_pv_arena_budget(mx_ctx *ctx) {
+  return mx_guard([&]() -> int64_t {
+    if (!ctx) return fail(MX_ERR_INVALID, "null context");
+    std::lock_guard<std::mutex> plk(ctx->pv_mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t b = 0;
+    const int rc = pv_budget(ctx, &b);
+    return rc ? (int64_t)rc : (int64_t)b;
+  });
+}
+
+int64_t mx_pv_last_chunks(mx_ctx *ctx) {
+  return mx_guard([&]() -> int64_t {
+    if (!ctx) return fail(MX_ERR_INVALID, "null context");
+    std::lock_guard<std::mutex> plk(ctx->pv_mu);
+    return ctx->pv ? ctx->pv->last_chunks : 0;
+  });
 }
 
 }  // extern "C"
 
 namespace {
-// (host containers are used on the way — chunk lists, argument blocks —: nothing they throw may cross the C boundary)
-template <class F>
-int pv_guarded(F &&body) {
-  try {
-    return body();
-  } catch (const std::bad_alloc &) {
-    return fail(MX_ERR_NOMEM, "out of host memory");
-  } catch (const std::exception &e) {
-    return fail(MX_ERR_INVALID, "phase vocoder: %s", e.what());
-  }
-}
-
 int pv_pitch_shift_dev_impl(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32, int16_t *d_pcm_i16) {
   if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
   if (!(semitones >= -48.0 && semitones <= 48.0)) return fail(MX_ERR_INVALID, "semitones out of range [-48, 48]");
   if (a->n == 0 || (!d_pcm_f32 && !d_pcm_i16)) return MX_OK;
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
-  PvPipe *p = nullptr;
-  int rc = pv_pipe(ctx, &p);
-  if (rc) return rc;
-  pv_shard_drop(*p);
   PvRun run;
   run.a = a;
   run.r = std::pow(2.0, semitones / 12.0);
   run.F_lo = 0;
   run.F_hi = pv_frame_count(a->n, run.r);
+  PvPipe *p = nullptr;
+  int rc = pv_pipe(ctx, run.F_hi, &p);
+  if (rc) return rc;
+  pv_shard_drop(*p);
   run.out_lo = 0;
   run.out_hi = a->n;
   run.pcm_f32 = d_pcm_f32;
@@ -542,28 +661,28 @@ int pv_pitch_shift_dev_impl(mx_ctx *ctx, const mx_audio *a, double semitones, fl
 extern "C" {
 
 int mx_pv_pitch_shift_dev(mx_ctx *ctx, const mx_audio *a, double semitones, float *d_pcm_f32, int16_t *d_pcm_i16) {
-  return pv_guarded([&] { return pv_pitch_shift_dev_impl(ctx, a, semitones, d_pcm_f32, d_pcm_i16); });
+  return mx_guard([&]() -> int {
+    return pv_pitch_shift_dev_impl(ctx, a, semitones, d_pcm_f32, d_pcm_i16);
+  });
 }
 
 // Marker-driven variant: the vocoder steered by the editor's markers as App::exportWav is (warped time, pitch bend).
 int64_t mx_pv_render_length(int64_t n, int sampleRate, const mx_marker *markers, int nmarkers) {
-  if (n < 0 || nmarkers < 0 || (nmarkers > 0 && !markers)) return fail(MX_ERR_INVALID, "bad argument");
-  try {
+  return mx_guard([&]() -> int64_t {
+    if (n < 0 || nmarkers < 0 || (nmarkers > 0 && !markers)) return fail(MX_ERR_INVALID, "bad argument");
     PvPlan plan;
     std::string err;
     const int rc = build_pv_plan(markers, nmarkers, sampleRate, n, plan, err);
     if (rc) return fail(rc, "%s", err.c_str());
     return plan.n_out;
-  } catch (const std::exception &e) {  // nothing may propagate across the C boundary
-    return fail(MX_ERR_NOMEM, "phase-vocoder plan: %s", e.what());
-  }
+  });
 }
 
 int mx_pv_plan(int64_t n, int sampleRate, const mx_marker *markers, int nmarkers, int64_t **apos, double **tf,
                double **rf, int64_t **i0, int64_t *frames, int64_t *nsamples) {
-  if (n < 0 || nmarkers < 0 || (nmarkers > 0 && !markers) || !apos || !tf || !rf || !i0 || !frames || !nsamples)
-    return fail(MX_ERR_INVALID, "bad argument");
-  try {
+  return mx_guard([&]() -> int {
+    if (n < 0 || nmarkers < 0 || (nmarkers > 0 && !markers) || !apos || !tf || !rf || !i0 || !frames || !nsamples)
+      return fail(MX_ERR_INVALID, "bad argument");
     PvPlan plan;
     std::string err;
     const int rc = build_pv_plan(markers, nmarkers, sampleRate, n, plan, err);
@@ -583,16 +702,14 @@ int mx_pv_plan(int64_t n, int sampleRate, const mx_marker *markers, int nmarkers
     *frames = (int64_t)F;
     *nsamples = plan.n_out;
     return MX_OK;
-  } catch (const std::bad_alloc &) {
-    return fail(MX_ERR_NOMEM, "out of host memory");
-  }
+  });
 }
 
 int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_marker *markers, int nmarkers,
                      float *d_pcm_f32, int16_t *d_pcm_i16) {
-  if (!ctx || !a || nmarkers < 0 || (nmarkers > 0 && !markers)) return fail(MX_ERR_INVALID, "bad argument");
-  if (a->n == 0 || (!d_pcm_f32 && !d_pcm_i16)) return MX_OK;
-  try {
+  return mx_guard([&]() -> int {
+    if (!ctx || !a || nmarkers < 0 || (nmarkers > 0 && !markers)) return fail(MX_ERR_INVALID, "bad argument");
+    if (a->n == 0 || (!d_pcm_f32 && !d_pcm_i16)) return MX_OK;
     PvPlan plan;
     std::string err;
     int rc = build_pv_plan(markers, nmarkers, sampleRate, a->n, plan, err);
@@ -614,7 +731,7 @@ int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_ma
     }
     std::lock_guard<std::mutex> plk(ctx->pv_mu);
     PvPipe *p = nullptr;
-    rc = pv_pipe(ctx, &p);
+    rc = pv_pipe(ctx, (int64_t)F, &p);
     if (rc) return rc;
     pv_shard_drop(*p);
     PvRun run;
@@ -632,35 +749,35 @@ int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_ma
     if (rc) return rc;
     if (es != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(es));
     return MX_OK;
-  } catch (const std::bad_alloc &) {
-    return fail(MX_ERR_NOMEM, "out of host memory");
-  }
+  });
 }
 
 int mx_pv_render(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_marker *markers, int nmarkers,
                  float *pcm_f32_out, int16_t *pcm_i16_out) {
-  if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
-  const int64_t m = mx_pv_render_length(a->n, sampleRate, markers, nmarkers);
-  if (m < 0) return (int)m;
-  if (m == 0 || (!pcm_f32_out && !pcm_i16_out)) return MX_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  float *d_f = nullptr;
-  int16_t *d_i = nullptr;
-  hipError_t e = hipSuccess;
-  if (pcm_f32_out) e = hipMalloc(&d_f, (size_t)m * sizeof(float));
-  if (e == hipSuccess && pcm_i16_out) e = hipMalloc(&d_i, (size_t)m * sizeof(int16_t));
-  if (e != hipSuccess) {
+  return mx_guard([&]() -> int {
+    if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
+    const int64_t m = mx_pv_render_length(a->n, sampleRate, markers, nmarkers);
+    if (m < 0) return (int)m;
+    if (m == 0 || (!pcm_f32_out && !pcm_i16_out)) return MX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *d_f = nullptr;
+    int16_t *d_i = nullptr;
+    hipError_t e = hipSuccess;
+    if (pcm_f32_out) e = hipMalloc(&d_f, (size_t)m * sizeof(float));
+    if (e == hipSuccess && pcm_i16_out) e = hipMalloc(&d_i, (size_t)m * sizeof(int16_t));
+    if (e != hipSuccess) {
+      hipFree(d_f); hipFree(d_i);
+      return fail(MX_ERR_NOMEM, "device PCM buffers: %s", hipGetErrorString(e));
+    }
+    int rc = mx_pv_render_dev(ctx, a, sampleRate, markers, nmarkers, d_f, d_i);
+    if (rc == MX_OK) {
+      if (d_f) e = hipMemcpy(pcm_f32_out, d_f, (size_t)m * sizeof(float), hipMemcpyDeviceToHost);
+      if (e == hipSuccess && d_i) e = hipMemcpy(pcm_i16_out, d_i, (size_t)m * sizeof(int16_t), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
+    }
     hipFree(d_f); hipFree(d_i);
-    return fail(MX_ERR_NOMEM, "device PCM buffers: %s", hipGetErrorString(e));
-  }
-  int rc = mx_pv_render_dev(ctx, a, sampleRate, markers, nmarkers, d_f, d_i);
-  if (rc == MX_OK) {
-    if (d_f) e = hipMemcpy(pcm_f32_out, d_f, (size_t)m * sizeof(float), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && d_i) e = hipMemcpy(pcm_i16_out, d_i, (size_t)m * sizeof(int16_t), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
-  }
-  hipFree(d_f); hipFree(d_i);
-  return rc;
+    return rc;
+  });
 }
 
 
@@ -674,32 +791,36 @@ int mx_pv_render(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_marker
 // alone, stage 2 again with the carry) — a range of one chunk is analysed once.
 int mx_pv_shard_frames(int64_t n, double semitones, int rank, int world, int64_t *frame_lo, int64_t *frame_hi,
                        int64_t *out_lo, int64_t *out_hi) {
-  if (n <= 0 || world < 1 || rank < 0 || rank >= world || !(semitones >= -48.0 && semitones <= 48.0))
-    return fail(MX_ERR_INVALID, "bad argument");
-  const double r = std::pow(2.0, semitones / 12.0);
-  const int64_t F = pv_frame_count(n, r);
-  int64_t per = (F + world - 1) / world;
-  per = (per + 31) / 32 * 32;
-  // (every rank gets at least one synthesis workgroup of its own: the seams either side of a rank must not overlap)
-  if (world > 1 && F - per * (world - 1) < 32)
-    return fail(MX_ERR_INVALID, "signal too short for %d ranks (%lld frames)", world, (long long)F);
-  const int64_t lo = (int64_t)rank * per, hi = rank == world - 1 ? F : lo + per;
-  if (frame_lo) *frame_lo = lo;
-  if (frame_hi) *frame_hi = hi;
-  if (out_lo) *out_lo = rank == 0 ? 0 : pv_first_output_at(lo * kPvHs, r, n);
-  if (out_hi) *out_hi = rank == world - 1 ? n : pv_first_output_at(hi * kPvHs, r, n);
-  return MX_OK;
+  return mx_guard([&]() -> int {
+    if (n <= 0 || world < 1 || rank < 0 || rank >= world || !(semitones >= -48.0 && semitones <= 48.0))
+      return fail(MX_ERR_INVALID, "bad argument");
+    const double r = std::pow(2.0, semitones / 12.0);
+    const int64_t F = pv_frame_count(n, r);
+    int64_t per = (F + world - 1) / world;
+    per = (per + 31) / 32 * 32;
+    // (every rank gets at least one synthesis workgroup of its own: the seams either side of a rank must not overlap)
+    if (world > 1 && F - per * (world - 1) < 32)
+      return fail(MX_ERR_INVALID, "signal too short for %d ranks (%lld frames)", world, (long long)F);
+    const int64_t lo = (int64_t)rank * per, hi = rank == world - 1 ? F : lo + per;
+    if (frame_lo) *frame_lo = lo;
+    if (frame_hi) *frame_hi = hi;
+    if (out_lo) *out_lo = rank == 0 ? 0 : pv_first_output_at(lo * kPvHs, r, n);
+    if (out_hi) *out_hi = rank == world - 1 ? n : pv_first_output_at(hi * kPvHs, r, n);
+    return MX_OK;
+  });
 }
 
-static int pv_shard_analyze_impl(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world, uint32_t *tot_sums_out,
-                        uint16_t *tot_org_out) {
-  if (!ctx || !a || !tot_sums_out || !tot_org_out) return fail(MX_ERR_INVALID, "bad argument");
+// The three stages, on device memory throughout; the host-pointer entry points wrap them with copies, the _dev entry points
+// hand the caller's buffers straight through.
+//   stage 1 -> d_map_out: 2048 uint32 sums, then 2048 uint16 source bins (12 KiB: one rank's entry of the first all-gather)
+static int pv_shard_analyze_core(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world, void *map_out, bool map_on_device) {
+  if (!ctx || !a || !map_out) return fail(MX_ERR_INVALID, "bad argument");
   int64_t lo, hi, olo, ohi;
   int rc = mx_pv_shard_frames(a->n, semitones, rank, world, &lo, &hi, &olo, &ohi);
   if (rc) return rc;
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
   PvPipe *p = nullptr;
-  rc = pv_pipe(ctx, &p);
+  rc = pv_pipe(ctx, hi - lo + 1, &p);  // (+ the row before the range)
   if (rc) return rc;
   pv_shard_drop(*p);
   const int64_t K = (int64_t)pv_chunks_of(lo, hi, p->C).size();
@@ -729,8 +850,9 @@ static int pv_shard_analyze_impl(mx_ctx *ctx, const mx_audio *a, double semitone
       rs = p->slot[0].tot_sums;
       ro = p->slot[0].tot_org;
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(tot_sums_out, rs, kPvM * 4, hipMemcpyDeviceToHost, p->ss);
-    if (e == hipSuccess) e = hipMemcpyAsync(tot_org_out, ro, kPvM * 2, hipMemcpyDeviceToHost, p->ss);
+    const hipMemcpyKind kind = map_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (e == hipSuccess) e = hipMemcpyAsync(map_out, rs, kPvM * 4, kind, p->ss);
+    if (e == hipSuccess) e = hipMemcpyAsync(static_cast<char *>(map_out) + kPvM * 4, ro, kPvM * 2, kind, p->ss);
   }
   const hipError_t es = hipStreamSynchronize(p->ss);
   hipFree(d_sums);
@@ -740,9 +862,11 @@ static int pv_shard_analyze_impl(mx_ctx *ctx, const mx_audio *a, double semitone
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (analysis): %s", hipGetErrorString(e));
   PvPipe::Shard &j = p->job;
   j.active = true;
+  j.rank = rank;
+  j.world = world;
   j.first = rank == 0;
   j.last = rank == world - 1;
-  j.single = K == 1;
+  j.single = K == 1;  // the rows are resident: stage 2 goes straight to the offsets and the synthesis
   j.a = a;
   j.semitones = semitones;
   j.r = run.r;
@@ -753,27 +877,71 @@ static int pv_shard_analyze_impl(mx_ctx *ctx, const mx_audio *a, double semitone
   return MX_OK;
 }
 
-static int pv_shard_synthesize_impl(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out) {
+//   stage 2: the carry into the rank — a device row (carry_dev), a host row, or folded here from the gathered maps of the
+//   ranks below (maps_all: [world] x 12 KiB as stage 1 wrote them) -> the rank's outputs but its edges, and its two seams
+//   (head then tail, 2 x 3840 floats: one rank's entry of the second all-gather)
+static int pv_shard_synthesize_core(mx_ctx *ctx, const uint32_t *carry_host, const void *d_maps_all, float *d_pcm_f32, int16_t *d_pcm_i16,
+                                    bool own_pcm, float *head_out, float *tail_out, bool seams_on_device) {
   if (!ctx || !head_out || !tail_out) return fail(MX_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
   PvPipe *p = ctx->pv;
   if (!p || !p->job.active || p->job.synthesized) return fail(MX_ERR_INVALID, "mx_pv_shard_analyze has not run on this context");
   PvPipe::Shard &j = p->job;
-  if (!j.first && !carry_in) return fail(MX_ERR_INVALID, "carry_in is required on every rank but the first");
+  if (!j.first && !carry_host && !d_maps_all) return fail(MX_ERR_INVALID, "carry_in is required on every rank but the first");
+  if (!own_pcm && !d_pcm_f32 && !d_pcm_i16) return fail(MX_ERR_INVALID, "no output buffer");
   HIP_TRY(hipSetDevice(ctx->device));
-  // the rank's outputs wait on the device for stage 3 (both formats: the caller chooses there)
+  const hipStream_t sm = ctx->stream;
   const int64_t cnt = j.out_hi - j.out_lo;
   hipError_t e = hipSuccess;
-  if (cnt > 0) {
-    e = hipMalloc(&j.d_f, (size_t)cnt * 4);
-    if (e == hipSuccess) e = hipMalloc(&j.d_i, (size_t)cnt * 2);
+  // the carry first: nothing is allocated yet if it cannot be had
+  uint32_t *fold_s = nullptr;
+  uint16_t *fold_o = nullptr;
+  if (!j.first) {
+    if (d_maps_all) {
+      // the maps of ranks 0 .. rank - 1 composed in order and applied to a zero row: the composed map's sums (a bin whose
+      // source is a bin of the zero row ends at its sum; so does one that restarted)
+      constexpr size_t kEntry = (size_t)kPvM * 6;
+      e = hipMalloc(&fold_s, (size_t)j.rank * kPvM * 4);
+      if (e == hipSuccess) e = hipMalloc(&fold_o, (size_t)j.rank * kPvM * 2);
+      if (e != hipSuccess) {
+        hipFree(fold_s);
+        pv_shard_drop(*p);
+        return fail(MX_ERR_NOMEM, "phase-vocoder rank maps: %s", hipGetErrorString(e));
+      }
+      PV_TRY(hipMemcpy2DAsync(fold_s, (size_t)kPvM * 4, d_maps_all, kEntry, (size_t)kPvM * 4, (size_t)j.rank, hipMemcpyDeviceToDevice, sm));
+      PV_TRY(hipMemcpy2DAsync(fold_o, (size_t)kPvM * 2, static_cast<const char *>(d_maps_all) + (size_t)kPvM * 4, kEntry, (size_t)kPvM * 2,
+                              (size_t)j.rank, hipMemcpyDeviceToDevice, sm));
+      PV_TRY(launch_pv_compose_maps(fold_s, fold_o, j.rank, p->carry_in, p->slot[0].tot_org, sm));
+    } else {
+      PV_TRY(hipMemcpyAsync(p->carry_in, carry_host, kPvM * 4, hipMemcpyHostToDevice, sm));
+    }
     if (e != hipSuccess) {
+      hipStreamSynchronize(sm);
+      hipFree(fold_s);
+      hipFree(fold_o);
       pv_shard_drop(*p);
-      return fail(MX_ERR_NOMEM, "device PCM buffers: %s", hipGetErrorString(e));
+      return fail(MX_ERR_DEVICE, "phase vocoder (carry): %s", hipGetErrorString(e));
     }
   }
-  if (carry_in && !j.first) e = hipMemcpyAsync(p->carry_in, carry_in, kPvM * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (carry): %s", hipGetErrorString(e));
+  // the rank's outputs wait on the device for stage 3: in the caller's buffers, or (host-pointer entry points: the caller
+  // chooses the formats in stage 3) in buffers of the library's own, both formats
+  j.own_pcm = own_pcm;
+  if (own_pcm) {
+    if (cnt > 0) {
+      e = hipMalloc(&j.d_f, (size_t)cnt * 4);
+      if (e == hipSuccess) e = hipMalloc(&j.d_i, (size_t)cnt * 2);
+      if (e != hipSuccess) {
+        hipStreamSynchronize(sm);
+        hipFree(fold_s);
+        hipFree(fold_o);
+        pv_shard_drop(*p);
+        return fail(MX_ERR_NOMEM, "device PCM buffers: %s", hipGetErrorString(e));
+      }
+    }
+  } else {
+    j.d_f = d_pcm_f32;
+    j.d_i = d_pcm_i16;
+  }
   PvRun run;
   run.a = j.a;
   run.r = j.r;
@@ -793,11 +961,15 @@ static int pv_shard_synthesize_impl(mx_ctx *ctx, const uint32_t *carry_in, float
   // the seams, raw: this rank's sums into the N - Hs samples before its first complete hop (all zero on the first rank,
   // whose first hops are complete) and after its last hop
   if (rc == MX_OK) {
-    if (j.first) memset(head_out, 0, kPvSeam * 4);
-    else e = hipMemcpyAsync(head_out, p->head_raw, kPvSeam * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(tail_out, p->tail_raw, kPvSeam * 4, hipMemcpyDeviceToHost, ctx->stream);
+    const hipMemcpyKind kind = seams_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (!j.first) e = hipMemcpyAsync(head_out, p->head_raw, kPvSeam * 4, kind, sm);
+    else if (seams_on_device) e = hipMemsetAsync(head_out, 0, kPvSeam * 4, sm);
+    else memset(head_out, 0, kPvSeam * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(tail_out, p->tail_raw, kPvSeam * 4, kind, sm);
   }
-  const hipError_t es = hipStreamSynchronize(ctx->stream);
+  const hipError_t es = hipStreamSynchronize(sm);
+  hipFree(fold_s);
+  hipFree(fold_o);
   if (rc == MX_OK && e == hipSuccess) e = es;
   if (rc || e != hipSuccess) {
     pv_shard_drop(*p);
@@ -809,17 +981,25 @@ static int pv_shard_synthesize_impl(mx_ctx *ctx, const uint32_t *carry_in, float
   return MX_OK;
 }
 
-static int pv_shard_finish_impl(mx_ctx *ctx, const float *prev_tail, const float *next_head, float *pcm_f32_out,
-                       int16_t *pcm_i16_out) {
+//   stage 3: the neighbours' seams (host rows, or device rows: entries of the gathered seams) -> the rank's edge outputs
+static int pv_shard_finish_core(mx_ctx *ctx, const float *prev_tail, const float *next_head, bool seams_on_device, const void *d_seams_all,
+                                float *pcm_f32_out, int16_t *pcm_i16_out) {
   if (!ctx) return fail(MX_ERR_INVALID, "null context");
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
   PvPipe *p = ctx->pv;
   if (!p || !p->job.active || !p->job.synthesized) return fail(MX_ERR_INVALID, "mx_pv_shard_synthesize has not run on this context");
   PvPipe::Shard &j = p->job;
+  if (d_seams_all) {  // [world] x {head, tail} x 3840 floats, as stage 2 wrote them
+    const float *all = static_cast<const float *>(d_seams_all);
+    prev_tail = j.first ? nullptr : all + ((size_t)(j.rank - 1) * 2 + 1) * kPvSeam;
+    next_head = j.last ? nullptr : all + (size_t)(j.rank + 1) * 2 * kPvSeam;
+    seams_on_device = true;
+  }
   if ((!j.first && !prev_tail) || (!j.last && !next_head)) return fail(MX_ERR_INVALID, "a neighbour's seam is missing");
   HIP_TRY(hipSetDevice(ctx->device));
   const hipStream_t sm = ctx->stream;
   const int64_t cnt = j.out_hi - j.out_lo;
+  const hipMemcpyKind kind = seams_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   hipError_t e = hipSuccess;
   PvArgs g{};
   g.ratio = j.r;
@@ -828,7 +1008,7 @@ static int pv_shard_finish_impl(mx_ctx *ctx, const float *prev_tail, const float
   g.pcm_base = j.out_lo;
   if (!j.first) {
     // the rank's first N - Hs stretched samples: its head + the previous rank's tail, then their outputs
-    PV_TRY(hipMemcpyAsync(p->prev_tail, prev_tail, kPvSeam * 4, hipMemcpyHostToDevice, sm));
+    PV_TRY(hipMemcpyAsync(p->prev_tail, prev_tail, kPvSeam * 4, kind, sm));
     PV_TRY(launch_pv_edge_sum(p->edge_head, p->head_raw, p->prev_tail, kPvSeam, sm));
     g.s = p->edge_head;
     g.s_origin = j.F_lo * kPvHs;
@@ -838,7 +1018,7 @@ static int pv_shard_finish_impl(mx_ctx *ctx, const float *prev_tail, const float
   }
   if (!j.last) {
     // the outputs that interpolate between the rank's last stretched sample and the first one behind it
-    PV_TRY(hipMemcpyAsync(p->next_head, next_head, kPvSeam * 4, hipMemcpyHostToDevice, sm));
+    PV_TRY(hipMemcpyAsync(p->next_head, next_head, kPvSeam * 4, kind, sm));
     PV_TRY(launch_pv_edge_sum(p->edge_tail + 1, p->tail_raw, p->next_head, 4, sm));
     g.s = p->edge_tail;
     g.s_origin = j.F_hi * kPvHs - 1;
@@ -846,8 +1026,10 @@ static int pv_shard_finish_impl(mx_ctx *ctx, const float *prev_tail, const float
     g.out_hi = j.out_hi;
     PV_TRY(launch_pv_resample(g, sm));
   }
-  if (pcm_f32_out && cnt) PV_TRY(hipMemcpyAsync(pcm_f32_out, j.d_f, (size_t)cnt * 4, hipMemcpyDeviceToHost, sm));
-  if (pcm_i16_out && cnt) PV_TRY(hipMemcpyAsync(pcm_i16_out, j.d_i, (size_t)cnt * 2, hipMemcpyDeviceToHost, sm));
+  if (j.own_pcm) {
+    if (pcm_f32_out && cnt) PV_TRY(hipMemcpyAsync(pcm_f32_out, j.d_f, (size_t)cnt * 4, hipMemcpyDeviceToHost, sm));
+    if (pcm_i16_out && cnt) PV_TRY(hipMemcpyAsync(pcm_i16_out, j.d_i, (size_t)cnt * 2, hipMemcpyDeviceToHost, sm));
+  }
   const hipError_t es = hipStreamSynchronize(sm);
   if (e == hipSuccess) e = es;
   pv_shard_drop(*p);
@@ -857,37 +1039,69 @@ static int pv_shard_finish_impl(mx_ctx *ctx, const float *prev_tail, const float
 
 int mx_pv_shard_analyze(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world, uint32_t *tot_sums_out,
                         uint16_t *tot_org_out) {
-  return pv_guarded([&] { return pv_shard_analyze_impl(ctx, a, semitones, rank, world, tot_sums_out, tot_org_out); });
+  return mx_guard([&] {
+    if (!tot_sums_out || !tot_org_out) return fail(MX_ERR_INVALID, "bad argument");
+    // (the two host arrays need not be adjacent: through one 12 KiB landing buffer)
+    std::vector<uint32_t> map((size_t)kPvM * 6 / 4);
+    const int rc = pv_shard_analyze_core(ctx, a, semitones, rank, world, map.data(), false);
+    if (rc) return rc;
+    memcpy(tot_sums_out, map.data(), (size_t)kPvM * 4);
+    memcpy(tot_org_out, map.data() + kPvM, (size_t)kPvM * 2);
+    return MX_OK;
+  });
 }
 int mx_pv_shard_synthesize(mx_ctx *ctx, const uint32_t *carry_in, float *head_out, float *tail_out) {
-  return pv_guarded([&] { return pv_shard_synthesize_impl(ctx, carry_in, head_out, tail_out); });
+  return mx_guard([&] { return pv_shard_synthesize_core(ctx, carry_in, nullptr, nullptr, nullptr, true, head_out, tail_out, false); });
 }
 int mx_pv_shard_finish(mx_ctx *ctx, const float *prev_tail, const float *next_head, float *pcm_f32_out,
                        int16_t *pcm_i16_out) {
-  return pv_guarded([&] { return pv_shard_finish_impl(ctx, prev_tail, next_head, pcm_f32_out, pcm_i16_out); });
+  return mx_guard([&] { return pv_shard_finish_core(ctx, prev_tail, next_head, false, nullptr, pcm_f32_out, pcm_i16_out); });
+}
+
+// The same three stages with everything a rank exchanges left on the device, laid out as the two all-gathers move it: stage 1
+// writes the rank's 12 KiB entry of the maps, stage 2 reads the gathered maps ([world] entries; it folds those of the ranks below
+// into its carry on the device) and writes the rank's 30 KiB entry of the seams, stage 3 reads the gathered seams.  The rank's
+// PCM goes straight into the caller's device buffers (out_hi - out_lo samples, either may be NULL) from stage 2 on.
+int mx_pv_shard_analyze_dev(mx_ctx *ctx, const mx_audio *a, double semitones, int rank, int world, void *d_map_out) {
+  return mx_guard([&] { return pv_shard_analyze_core(ctx, a, semitones, rank, world, d_map_out, true); });
+}
+int mx_pv_shard_synthesize_dev(mx_ctx *ctx, const void *d_maps_all, float *d_pcm_f32, int16_t *d_pcm_i16, void *d_seams_out) {
+  return mx_guard([&] {
+    if (!d_seams_out || !d_maps_all) return fail(MX_ERR_INVALID, "bad argument");
+    float *seams = static_cast<float *>(d_seams_out);
+    return pv_shard_synthesize_core(ctx, nullptr, d_maps_all, d_pcm_f32, d_pcm_i16, false, seams, seams + kPvSeam, true);
+  });
+}
+int mx_pv_shard_finish_dev(mx_ctx *ctx, const void *d_seams_all) {
+  return mx_guard([&] {
+    if (!d_seams_all) return fail(MX_ERR_INVALID, "bad argument");
+    return pv_shard_finish_core(ctx, nullptr, nullptr, true, d_seams_all, nullptr, nullptr);
+  });
 }
 
 int mx_pv_pitch_shift(mx_ctx *ctx, const mx_audio *a, double semitones, float *pcm_f32_out, int16_t *pcm_i16_out) {
-  if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
-  if (a->n == 0 || (!pcm_f32_out && !pcm_i16_out)) return MX_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  float *d_f = nullptr;
-  int16_t *d_i = nullptr;
-  hipError_t e = hipSuccess;
-  if (pcm_f32_out) e = hipMalloc(&d_f, (size_t)a->n * sizeof(float));
-  if (e == hipSuccess && pcm_i16_out) e = hipMalloc(&d_i, (size_t)a->n * sizeof(int16_t));
-  if (e != hipSuccess) {
+  return mx_guard([&]() -> int {
+    if (!ctx || !a) return fail(MX_ERR_INVALID, "null context or audio handle");
+    if (a->n == 0 || (!pcm_f32_out && !pcm_i16_out)) return MX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *d_f = nullptr;
+    int16_t *d_i = nullptr;
+    hipError_t e = hipSuccess;
+    if (pcm_f32_out) e = hipMalloc(&d_f, (size_t)a->n * sizeof(float));
+    if (e == hipSuccess && pcm_i16_out) e = hipMalloc(&d_i, (size_t)a->n * sizeof(int16_t));
+    if (e != hipSuccess) {
+      hipFree(d_f); hipFree(d_i);
+      return fail(MX_ERR_NOMEM, "device PCM buffers: %s", hipGetErrorString(e));
+    }
+    int rc = mx_pv_pitch_shift_dev(ctx, a, semitones, d_f, d_i);
+    if (rc == MX_OK) {
+      if (d_f) e = hipMemcpy(pcm_f32_out, d_f, (size_t)a->n * sizeof(float), hipMemcpyDeviceToHost);
+      if (e == hipSuccess && d_i) e = hipMemcpy(pcm_i16_out, d_i, (size_t)a->n * sizeof(int16_t), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
+    }
     hipFree(d_f); hipFree(d_i);
-    return fail(MX_ERR_NOMEM, "device PCM buffers: %s", hipGetErrorString(e));
-  }
-  int rc = mx_pv_pitch_shift_dev(ctx, a, semitones, d_f, d_i);
-  if (rc == MX_OK) {
-    if (d_f) e = hipMemcpy(pcm_f32_out, d_f, (size_t)a->n * sizeof(float), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && d_i) e = hipMemcpy(pcm_i16_out, d_i, (size_t)a->n * sizeof(int16_t), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(MX_ERR_DEVICE, "PCM download: %s", hipGetErrorString(e));
-  }
-  hipFree(d_f); hipFree(d_i);
-  return rc;
+    return rc;
+  });
 }
 
 }  // extern "C"

@@ -196,32 +196,93 @@ def pv_fold_carry(tot_sums, tot_org, rank: int):
     return carry
 
 
-def pv_pitch_shift_rank(ctx, audio, semitones: float, dist, rank: int, world: int, want_i16: bool = True):
-    """One rank's part of a multi-GPU phase-vocoder pitch shift.  `audio` is the WHOLE signal on this rank's GPU.
-    Two small all-gathers (any torch.distributed backend; payloads are host tensors moved to `device` when the
-    backend needs device memory): 12 KiB of phase maps per rank, then the two 15 KiB seams per rank.
-    -> (out_lo, out_hi, f32, int16 | None): the rank's slice of the output."""
-    import numpy as np
+PV_MAP_BYTES = 2048 * 6        # one rank's entry of the first all-gather: 2048 uint32 sums, then 2048 uint16 source bins
+PV_SEAM_BYTES = 2 * 3840 * 4   # ... and of the second: head then tail, 3840 raw float sums each
+
+
+def pv_pitch_shift_rank_dev(ctx, audio, semitones: float, dist, rank: int, world: int, want_f32: bool = True,
+                            want_i16: bool = True, timings: dict | None = None, agree=None, device=None):
+    """One rank's part of a multi-GPU phase-vocoder pitch shift, everything on the device.  `audio` is the WHOLE signal on
+    this rank's GPU.  The three stages of the C-ABI write / read the send / receive buffers of the two all-gathers as
+    they are (12 KiB of phase maps per rank, then 30 KiB of seams per rank): with RCCL nothing touches the host between
+    the stages; with gloo (CPU tests, one-GPU boxes) the two small buffers are bounced through host tensors for the
+    collective only.  -> (out_lo, out_hi, f32 tensor | None, int16 tensor | None): the rank's slice, on the device.
+    `timings` (a dict) receives per-stage and per-collective seconds of this rank (host clock around blocking calls).
+    `agree` (callable bool -> bool, e.g. an all-reduce MIN of a flag): called by every rank before each all-gather with
+    "my stage succeeded"; if it returns False every rank raises instead of entering a collective a failed rank will never
+    reach (a job that must not hang on one rank's MX_ERR_NOMEM: bench.py)."""
+    import time
+
     import torch
 
-    n = audio.n
-    _, _, out_lo, out_hi = __import__("melonix_amd").pv_shard_frames(n, semitones, rank, world)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    from . import pv_shard_frames
 
-    def all_gather_bytes(arr):
-        mine = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).copy()).to(dev)
-        out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(out, mine)
-        return out.cpu().numpy().reshape(world, -1)
+    _, _, out_lo, out_hi = pv_shard_frames(audio.n, semitones, rank, world)
+    # (`device`: where the buffers live — the current GPU; the CPU suite passes "cpu" with a stand-in context to run this
+    # function's exchange and failure logic over gloo without a GPU)
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    on_dev = dist.get_backend() == "nccl"
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
 
-    sums, org = ctx.pv_shard_analyze(audio, semitones, rank, world)
-    tot = all_gather_bytes(np.concatenate([sums.view(np.uint8), org.view(np.uint8)]))
-    all_sums = np.ascontiguousarray(tot[:, : 4 * 2048]).view(np.uint32).reshape(world, 2048)
-    all_org = np.ascontiguousarray(tot[:, 4 * 2048:]).view(np.uint16).reshape(world, 2048)
-    carry = pv_fold_carry(all_sums, all_org, rank) if rank > 0 else None
-    head, tail = ctx.pv_shard_synthesize(carry)
-    seams = all_gather_bytes(np.concatenate([head, tail])).view(np.float32).reshape(world, 2, 3840)
-    prev_tail = seams[rank - 1, 1] if rank > 0 else None
-    next_head = seams[rank + 1, 0] if rank < world - 1 else None
-    f32, i16 = ctx.pv_shard_finish(out_hi - out_lo, prev_tail, next_head, True, want_i16)
+    def gather(mine, nbytes):
+        out = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
+        if on_dev:
+            dist.all_gather_into_tensor(out, mine)
+            sync()
+        else:
+            h = torch.empty(world * nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(h, mine.cpu())
+            out.copy_(h)
+        return out
+
+    def clock(key, t0):
+        if timings is not None:
+            timings[key] = time.perf_counter() - t0
+
+    def stage(key, fn):
+        err = None
+        t0 = time.perf_counter()
+        try:
+            fn()
+        except Exception as exc:  # (MxError: NOMEM, a device fault)
+            err = exc
+        clock(key, t0)
+        if agree is not None:
+            if not agree(err is None):
+                raise RuntimeError(f"phase-vocoder {key[:-2]} failed on {'this' if err else 'another'} rank" + (f": {err}" if err else ""))
+        elif err is not None:
+            raise err
+
+    cnt = out_hi - out_lo
+    bufs = {}
+
+    def alloc():
+        bufs["f32"] = torch.empty(cnt, dtype=torch.float32, device=dev) if want_f32 else None
+        bufs["i16"] = torch.empty(cnt, dtype=torch.int16, device=dev) if want_i16 else None
+        bufs["map"] = torch.empty(PV_MAP_BYTES, dtype=torch.uint8, device=dev)
+        bufs["seams"] = torch.empty(PV_SEAM_BYTES, dtype=torch.uint8, device=dev)
+        sync()
+        ctx.pv_shard_analyze_dev(audio, semitones, rank, world, bufs["map"].data_ptr())
+
+    stage("stage1_s", alloc)
+    f32, i16 = bufs["f32"], bufs["i16"]
+    t0 = time.perf_counter()
+    maps = gather(bufs["map"], PV_MAP_BYTES)
+    clock("gather_maps_s", t0)
+    stage("stage2_s", lambda: ctx.pv_shard_synthesize_dev(maps.data_ptr(), f32.data_ptr() if want_f32 else None,
+                                                          i16.data_ptr() if want_i16 else None, bufs["seams"].data_ptr()))
+    t0 = time.perf_counter()
+    seams = gather(bufs["seams"], PV_SEAM_BYTES)
+    clock("gather_seams_s", t0)
+    stage("stage3_s", lambda: ctx.pv_shard_finish_dev(seams.data_ptr()))
+    if timings is not None:
+        timings["chunks"] = ctx.pv_last_chunks()
+        timings["arena_bytes"] = ctx.pv_arena_bytes()
     return out_lo, out_hi, f32, i16
+
+
+def pv_pitch_shift_rank(ctx, audio, semitones: float, dist, rank: int, world: int, want_i16: bool = True):
+    """pv_pitch_shift_rank_dev with the rank's slice downloaded: -> (out_lo, out_hi, f32 ndarray, int16 ndarray | None).
+    (Nothing crosses to the host between the stages; rounds 4-5 bounced maps, carry and seams through numpy.)"""
+    lo, hi, f32, i16 = pv_pitch_shift_rank_dev(ctx, audio, semitones, dist, rank, world, True, want_i16)
+    return lo, hi, f32.cpu().numpy(), (i16.cpu().numpy() if i16 is not None else None)

@@ -77,6 +77,41 @@ def loaded_hip():
     return C.CDLL(path)
 
 
+class DevBuf:
+    """`nbytes` of device memory through the process's HIP runtime (no torch in the in-process GPU tests: see loaded_hip),
+    filled with `fill` bytes; .ptr, .read(dtype), .write(ndarray), .free()."""
+
+    def __init__(self, nbytes: int, fill: int = 0):
+        import ctypes as C
+        self.hip, self.nbytes = loaded_hip(), int(nbytes)
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+        p = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(p), max(self.nbytes, 16)) == 0
+        self.ptr = p.value
+        assert self.hip.hipMemset(self.ptr, fill, max(self.nbytes, 16)) == 0
+
+    def read(self, dtype=np.uint8, offset: int = 0, count: int | None = None):
+        dt = np.dtype(dtype)
+        nb = self.nbytes - offset if count is None else count * dt.itemsize
+        out = np.empty(nb // dt.itemsize, dtype=dt)
+        assert self.hip.hipDeviceSynchronize() == 0
+        assert self.hip.hipMemcpy(out.ctypes.data, self.ptr + offset, out.nbytes, 2) == 0
+        return out
+
+    def write(self, arr, offset: int = 0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        assert self.hip.hipMemcpy(self.ptr + offset, arr.ctypes.data, arr.nbytes, 1) == 0
+
+    def free(self):
+        if self.ptr:
+            self.hip.hipFree(self.ptr)
+            self.ptr = None
+
+
 def mag_tol(ref_rows):
     """max_k |g-r| <= 2e-5 * max_k r + 1e-9 per frame (fp32 LDS FFT vs the f64 path)."""
     return 2e-5 * ref_rows.max(axis=-1, keepdims=True) + 1e-9

@@ -165,3 +165,140 @@ def test_two_rank_pcm_gather_equals_export(oracle):
     assert total == len(opcm) == 478903 and len(whole) == total
     assert np.array_equal(whole, oracle.pcm_to_i16(opcm))
     assert parts[0][2] == 0 and parts[0][3] == parts[1][2] and parts[1][3] == total and parts[0][1] == parts[1][0]
+
+
+
+# ---- the sharded phase vocoder's exchange logic without a GPU ---------------------------------------------------
+class _StandInCtx:
+    """What shard.pv_pitch_shift_rank_dev needs of a context, on host memory: the three stages write recognisable entries into the
+    send buffers and check the gathered receive buffers they are handed (rank order, entry sizes, which neighbours' seams).  The
+    transforms themselves need the GPU (tests/test_pv.py); this is the plumbing around them and its failure behaviour."""
+
+    def __init__(self, rank, world, fail_at=None):
+        self.rank, self.world, self.fail_at, self.log = rank, world, fail_at, []
+
+    @staticmethod
+    def _view(ptr, nbytes):
+        import ctypes as C
+        return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr))
+
+    def _maybe_fail(self, stage):
+        if self.fail_at == stage:
+            raise RuntimeError(f"stand-in MX_ERR_NOMEM in stage {stage}")
+
+    def pv_shard_analyze_dev(self, audio, st, rank, world, d_map):
+        from melonix_amd import shard as sh
+        assert (rank, world) == (self.rank, self.world)
+        self._maybe_fail(1)
+        self._view(d_map, sh.PV_MAP_BYTES)[:] = 10 + rank
+        self.log.append("analyze")
+
+    def pv_shard_synthesize_dev(self, d_maps_all, d_f32, d_i16, d_seams):
+        from melonix_amd import shard as sh
+        self._maybe_fail(2)
+        maps = self._view(d_maps_all, self.world * sh.PV_MAP_BYTES).reshape(self.world, sh.PV_MAP_BYTES)
+        assert all((maps[r] == 10 + r).all() for r in range(self.world)), "maps not gathered in rank order"
+        assert d_f32 is None and d_i16
+        seams = self._view(d_seams, sh.PV_SEAM_BYTES)
+        seams[: sh.PV_SEAM_BYTES // 2] = 100 + self.rank  # head
+        seams[sh.PV_SEAM_BYTES // 2:] = 200 + self.rank   # tail
+        self.d_i16 = d_i16
+        self.log.append("synthesize")
+
+    def pv_shard_finish_dev(self, d_seams_all):
+        from melonix_amd import shard as sh
+        self._maybe_fail(3)
+        seams = self._view(d_seams_all, self.world * sh.PV_SEAM_BYTES).reshape(self.world, 2, sh.PV_SEAM_BYTES // 2)
+        for r in range(self.world):
+            assert (seams[r, 0] == 100 + r).all() and (seams[r, 1] == 200 + r).all(), "seams not gathered in rank order"
+        self._view(self.d_i16, 2)[:] = (self.rank + 1, 0)  # the first int16 of the slice := rank + 1
+        self.log.append("finish")
+
+    def pv_last_chunks(self):
+        return 1
+
+    def pv_arena_bytes(self):
+        return 12345
+
+
+class _StandInAudio:
+    def __init__(self, n):
+        self.n = n
+
+
+def _pv_logic_worker(rank, world, port, fail_rank, fail_at, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import melonix_amd as mx
+    from melonix_amd import shard as sh
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def agree(ok_here):
+        fl = torch.tensor([1 if ok_here else 0])
+        dist.all_reduce(fl, op=dist.ReduceOp.MIN)
+        return bool(fl.item())
+
+    n = 10 * SR
+    ctx = _StandInCtx(rank, world, fail_at if rank == fail_rank else None)
+    tm = {}
+    try:
+        lo, hi, f32, i16 = sh.pv_pitch_shift_rank_dev(ctx, _StandInAudio(n), 3.0, dist, rank, world, want_f32=False, want_i16=True,
+                                                      timings=tm, agree=agree, device="cpu")
+        want = mx.pv_shard_frames(n, 3.0, rank, world)[2:]
+        q.put((rank, "ok", (lo, hi) == tuple(want) and f32 is None and i16.numel() == hi - lo and int(i16[0]) == rank + 1, ctx.log, sorted(tm)))
+    except RuntimeError as exc:
+        q.put((rank, "raised", str(exc), ctx.log, sorted(tm)))
+    dist.barrier()  # (every rank is still in step: nobody sits in a collective the failed rank never entered)
+    dist.destroy_process_group()
+
+
+def _run_pv_logic(world, fail_rank, fail_at):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32500 + (os.getpid() % 2000) + 7 * (fail_at or 0)
+    procs = [ctx.Process(target=_pv_logic_worker, args=(r, world, port, fail_rank, fail_at, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    import queue as _q
+    import time as _t
+    t0 = _t.time()
+    while len(got) < world:
+        try:
+            item = q.get(timeout=1.0)
+            got[item[0]] = item[1:]
+        except _q.Empty:
+            assert not [p.exitcode for p in procs if p.exitcode not in (None, 0)], "a rank died"
+            assert _t.time() - t0 < 300, "a rank hangs in a collective"
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_pv_rank_exchange_over_gloo_world2(mxlib):
+    """shard.pv_pitch_shift_rank_dev over gloo with two processes and a stand-in context: stage 1's 12 KiB entries and stage 2's
+    30 KiB entries reach every rank in rank order, the stages run in order, the rank's range is mx_pv_shard_frames', timings are
+    reported for the three stages and the two all-gathers."""
+    got = _run_pv_logic(2, None, None)
+    for r in range(2):
+        kind, ok, log, keys = got[r]
+        assert kind == "ok" and ok is True and log == ["analyze", "synthesize", "finish"]
+        assert keys == ["arena_bytes", "chunks", "gather_maps_s", "gather_seams_s", "stage1_s", "stage2_s", "stage3_s"]
+
+
+@pytest.mark.parametrize("fail_at", [1, 2, 3])
+def test_pv_rank_failure_is_agreed_on_before_every_collective(mxlib, fail_at):
+    """One rank's stage fails (MX_ERR_NOMEM on a crowded device): with `agree` both ranks raise before the next all-gather — the
+    healthy rank does not wait in a collective its neighbour never enters — and the job goes on (the barrier afterwards)."""
+    got = _run_pv_logic(2, 1, fail_at)
+    for r in range(2):
+        kind, msg, log, _ = got[r]
+        assert kind == "raised" and ("this rank" in msg if r == 1 else "another rank" in msg), (r, msg)
+        assert len(log) == fail_at - (1 if r == 1 else 0)  # the healthy rank finished the stage the other one failed in

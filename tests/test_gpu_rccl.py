@@ -51,6 +51,8 @@ def test_bench_under_launcher_two_minutes_rccl_world1():
     # the PCM all-gather secondary ran through RCCL too (one rank: the exchange is a device copy, the code path is the N-rank one)
     g = line["pcm_gather_secondary"]
     assert g["backend"] == "nccl" and g["gathered_ok"] is True and g["bytes_per_rank"] >= 2 * 2 * 60 * 48000 * 0.99
+    # ... and so did the sharded phase vocoder's two all-gathers (phase maps, overlap-add seams) with its three device stages
+    _check_pv_shard(line, 1, "nccl")
     # `value` is the contract's own W + K region; the conditioned figure is a labelled secondary
     assert "value_no_conditioning" not in line and line["value_conditioned"]["conditioning_steps"] == 40
     log = os.environ.get("MX_RCCL_LOG")
@@ -58,6 +60,25 @@ def test_bench_under_launcher_two_minutes_rccl_world1():
         with open(log, "a") as f:
             f.write(json.dumps(line) + "\n")
             f.write(err[-4000:] + "\n")
+
+
+def _check_pv_shard(line, world, backend):
+    """`pv_shard_secondary`: the ranks' int16 slices of a common 2-minute signal concatenate to the single call's
+    output (sha1), every rank's slice of the workload equals the single call over the whole signal, resident ranges (one chunk,
+    analysed once), per-rank stage and all-gather times present."""
+    pv = line["pv_shard_secondary"]
+    assert "error" not in pv, pv
+    assert pv["world_size"] == world and pv["backend"] == backend
+    c = pv["common_signal"]
+    assert c["equal_on_every_rank"] is True and c["sha1_concatenated_int16"] == c["sha1_single_call_int16"]
+    assert c["ranges"][0][0] == 0 and c["ranges"][-1][1] == 120 * 48000
+    assert pv["slices_equal_single_call"] is True
+    assert [r["rank"] for r in pv["ranks"]] == list(range(world))
+    for r in pv["ranks"]:
+        assert r["chunks"] == 1 and r["frames"] >= 32 and r["frames"] % 32 == 0 or r["rank"] == world - 1
+        assert r["stage1_ms"] > 0 and r["stage2_ms"] > 0 and r["stage3_ms"] > 0 and r["gather_maps_ms"] > 0 and r["gather_seams_ms"] > 0
+    assert pv["frames_total"] == sum(r["frames"] for r in pv["ranks"]) and 0 < pv["efficiency_vs_single_call_over_own_share"] < 1.5
+    assert pv["exchanged_bytes_per_rank"] == 12288 + 30720
 
 
 def _check_rank_records(line, world, single_device=False):
@@ -140,7 +161,7 @@ def test_ranks_on_one_device_reproduce_the_single_rank_track(fft, hop, per_rank,
                                                       "gathered_sha1": two["exchange"]["gathered_track_sha1"]}}) + "\n")
 
 
-def test_eight_ranks_on_one_device_carry_rank_records_and_the_pcm_gather():
+def test_eight_ranks_on_one_device_carry_rank_records_the_pcm_gather_and_the_pv_seams():
     """The driver's weak-scaling form at world 8 (5 min per rank to keep eight processes on one GPU short), resynthesis in
     the step: the line carries every rank's own record and the timed int16 PCM all-gather over the ranks'
     shards, each rank having checked its own shard and the others' presence in the gathered stream."""
@@ -153,6 +174,8 @@ def test_eight_ranks_on_one_device_carry_rank_records_and_the_pcm_gather():
     assert g["gathered_ok"] is True and g["world_size"] == 8 and len(g["samples_per_rank"]) == 8
     assert g["bytes_per_rank"] >= 2 * min(g["samples_per_rank"]) and g["seconds"] > 0
     assert abs(g["frac_of_xgmi_peak"] - g["recv_GBps_per_rank"] / (7 * 153.0)) < 1e-12
+    # the phase vocoder sharded over the eight ranks: the collective north_star names (the overlap-add seams) in the N-rank bench
+    _check_pv_shard(line, 8, "gloo")
     log = os.environ.get("MX_RCCL_LOG")
     if log:
         with open(log, "a") as f:

@@ -258,53 +258,151 @@ def test_gpu_chunked_equals_whole_random_lengths(gpu_ctx):
         gpu_ctx.release_scratch()
 
 
-@pytest.mark.gpu
-def test_gpu_arena_is_bounded(gpu_ctx):
-    """The arena is a function of the chunk length alone: 2.36 GB at the default, the same before and after a signal
-    ten times longer; and it is one allocation the context gives back."""
-    import melonix_amd as mx
-    w = accum_sweep(SR)
-    a = gpu_ctx.upload(w)
-    gpu_ctx.release_scratch()
-    assert gpu_ctx.pv_arena_bytes() == 0
-    gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
-    b0 = gpu_ctx.pv_arena_bytes()
-    assert 2.0e9 < b0 <= 2.5e9
-    a.free()
-    a = gpu_ctx.upload(accum_sweep(10 * SR))
-    gpu_ctx.pv_pitch_shift(a, 24.0, want_i16=False)
-    assert gpu_ctx.pv_arena_bytes() == b0
-    gpu_ctx.pv_set_chunk_frames(64)
-    gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
-    assert gpu_ctx.pv_arena_bytes() < 64e6  # (the chunk maps of the recurrence: 2 x 18 MB whatever the chunk)
-    gpu_ctx.pv_set_chunk_frames(0)
-    gpu_ctx.release_scratch()
-    assert gpu_ctx.pv_arena_bytes() == 0
-    a.free()
-    with pytest.raises(mx.MxError):
-        gpu_ctx.pv_set_chunk_frames(-1)
-    # an arena the device cannot give (4 M frames per chunk: 295 GB) is refused before anything is allocated — MX_ERR_NOMEM,
-    # with the sizes in the message — and the context goes on working at the default afterwards
-    # (chunks of 4 M frames want 302 GB; with 64 GB held elsewhere no MI355X has that)
+def _free_device_bytes():
     import ctypes as C
     from conftest import loaded_hip
-    hip = loaded_hip()
-    ballast = C.c_void_p()
-    assert hip.hipMalloc(C.byref(ballast), C.c_size_t(64 << 30)) == 0
+    free, total = C.c_size_t(), C.c_size_t()
+    assert loaded_hip().hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value, total.value
+
+
+@pytest.mark.gpu
+def test_gpu_arena_follows_its_budget(gpu_ctx):
+    """The arena's policy (include/melonix_amd.h, WORK ARENA): a call that fits the budget is one resident chunk, a call
+    that does not is walked in the longest chunks the budget holds — inside the budget either way, bit-identical outputs —,
+    the default budget is a quarter of the free memory, an explicit chunk length overrides it, and the arena is one
+    allocation the context gives back."""
+    import melonix_amd as mx
+    w = (accum_sweep(20 * SR) + _tone(3000.0, 20.0, 0.05)).astype(np.float32)
+    frames = int(np.ceil(len(w) * 2.0 ** (3 / 12.0) / 256)) + 1  # 4461
     a = gpu_ctx.upload(w)
-    gpu_ctx.pv_set_chunk_frames(1 << 22)
     try:
+        gpu_ctx.release_scratch()
+        assert gpu_ctx.pv_arena_bytes() == 0
+        free0, _ = _free_device_bytes()
+        auto = gpu_ctx.pv_arena_budget()
+        assert 0.2 * free0 <= auto <= 0.26 * free0
+        whole_f, whole_i = gpu_ctx.pv_pitch_shift(a, 3.0)
+        b_res = gpu_ctx.pv_arena_bytes()
+        assert gpu_ctx.pv_last_chunks() == 1
+        # resident: one slot, ~34 KiB per frame (+ the constants and one chunk map per 64 frames)
+        assert 33.0 * 1024 * frames < b_res < 37.0 * 1024 * (frames + 64)
+        assert gpu_ctx.pv_arena_budget() == auto  # taken once
+        # a shorter call is served by the arena that is there
+        s = gpu_ctx.upload(w[: 2 * SR])
+        gpu_ctx.pv_pitch_shift(s, 3.0, want_i16=False)
+        assert gpu_ctx.pv_arena_bytes() == b_res and gpu_ctx.pv_last_chunks() == 1
+        s.free()
+        # a budget the call does not fit: chunks, inside the budget, same samples; the arena above the new budget went back at once
+        for budget in (96 << 20, 64 << 20, 41 << 20):
+            gpu_ctx.pv_set_arena_budget(budget)
+            assert gpu_ctx.pv_arena_bytes() == 0 or gpu_ctx.pv_arena_bytes() <= budget
+            f, i = gpu_ctx.pv_pitch_shift(a, 3.0)
+            assert 0 < gpu_ctx.pv_arena_bytes() <= budget and gpu_ctx.pv_arena_budget() == budget
+            assert gpu_ctx.pv_last_chunks() >= 3, (budget, gpu_ctx.pv_last_chunks())
+            assert np.array_equal(f.view(np.uint32), whole_f.view(np.uint32)) and np.array_equal(i, whole_i), budget
+        # a budget below the smallest chunks (two slots of 32 frames: 4.8 MiB): refused with the sizes in the message, nothing allocated
+        gpu_ctx.pv_set_arena_budget(4 << 20)
+        with pytest.raises(mx.MxError) as err:
+            gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
+        assert err.value.code == -3 and "MiB" in str(err.value) and gpu_ctx.pv_arena_bytes() == 0
+        # ... unless the call is short enough to be resident inside it (57 frames: 3.4 MiB)
+        s = gpu_ctx.upload(w[:12000])
+        y, _ = gpu_ctx.pv_pitch_shift(s, 3.0, want_i16=False)
+        assert len(y) == 12000 and gpu_ctx.pv_last_chunks() == 1 and gpu_ctx.pv_arena_bytes() <= 4 << 20
+        s.free()
+        # the explicit chunk length overrides the budget (two slots of exactly that many frames)
+        gpu_ctx.pv_set_arena_budget(0)
+        gpu_ctx.pv_set_chunk_frames(64)
+        f, _ = gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
+        assert gpu_ctx.pv_last_chunks() == -(-frames // 64) or gpu_ctx.pv_last_chunks() == frames // 64
+        assert gpu_ctx.pv_arena_bytes() < 16e6 and np.array_equal(f.view(np.uint32), whole_f.view(np.uint32))
+        gpu_ctx.pv_set_chunk_frames(0)
+        gpu_ctx.release_scratch()
+        assert gpu_ctx.pv_arena_bytes() == 0
+        with pytest.raises(mx.MxError):
+            gpu_ctx.pv_set_chunk_frames(-1)
+        with pytest.raises(mx.MxError):
+            gpu_ctx.pv_set_arena_budget(-1)
+        # an arena the device cannot give is refused before anything is allocated — MX_ERR_NOMEM, sizes in the message — and the
+        # context goes on working afterwards: chunks of 4 M frames want 302 GB, more than any MI355X has
+        gpu_ctx.pv_set_chunk_frames(1 << 22)
         with pytest.raises(mx.MxError) as err:
             gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
         assert err.value.code == -3 and "MiB" in str(err.value)
         assert gpu_ctx.pv_arena_bytes() == 0
+        gpu_ctx.pv_set_chunk_frames(0)
+        y, _ = gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
+        assert np.array_equal(y.view(np.uint32), whole_f.view(np.uint32)) and gpu_ctx.pv_arena_bytes() == b_res
     finally:
-        hip.hipFree(ballast)
-    gpu_ctx.pv_set_chunk_frames(0)
-    y, _ = gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
-    assert len(y) == len(w) and gpu_ctx.pv_arena_bytes() == b0
-    gpu_ctx.release_scratch()
-    a.free()
+        gpu_ctx.pv_set_chunk_frames(0)
+        gpu_ctx.pv_set_arena_budget(0)
+        gpu_ctx.release_scratch()
+        a.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,budget_mb", [(2, 0), (3, 0), (4, 16), (2, 41)])
+def test_gpu_sharded_on_device_equals_whole(gpu_ctx, world, budget_mb):
+    """The _dev form of the three stages, `world` contexts playing the ranks on one device: every stage writes its entry of
+    the next all-gather's buffer and reads the previous one's as gathered (here: the entries concatenated by hand); the carry
+    is folded from the gathered maps on the device; PCM lands in the caller's device buffers.  Default budget: each rank's
+    range is resident — ONE chunk, analysed once (stage 2 launches no analysis); a small budget: ranges walked in chunks.
+    Slices concatenate to the single-call output bit for bit."""
+    import melonix_amd as mx
+    from melonix_amd import shard as sh
+    from conftest import DevBuf
+    w = (accum_sweep(12 * SR) + _tone(3000.0, 12.0, 0.05)).astype(np.float32)
+    n = len(w)
+    a = gpu_ctx.upload(w)
+    ctxs, auds, bufs = [], [], []
+    try:
+        for st in (3.0, -5.0):
+            whole_f, whole_i = gpu_ctx.pv_pitch_shift(a, st)
+            ctxs = [mx.Context(0) for _ in range(world)]
+            for c in ctxs:
+                c.pv_set_arena_budget(budget_mb << 20)
+            auds = [c.upload(w) for c in ctxs]
+            maps = DevBuf(world * sh.PV_MAP_BYTES)
+            seams = DevBuf(world * sh.PV_SEAM_BYTES, fill=0x7f)
+            rng = [mx.pv_shard_frames(n, st, r, world)[2:] for r in range(world)]
+            f32 = [DevBuf(4 * (hi - lo), fill=0xff) for lo, hi in rng]  # (NaNs)
+            i16 = [DevBuf(2 * (hi - lo), fill=0x55) for lo, hi in rng]
+            bufs = [maps, seams] + f32 + i16
+            for r, (c, x) in enumerate(zip(ctxs, auds)):
+                c.pv_shard_analyze_dev(x, st, r, world, maps.ptr + r * sh.PV_MAP_BYTES)
+                if budget_mb == 0:
+                    assert c.pv_last_chunks() == 1, (r, c.pv_last_chunks())
+                else:  # (at +3 st the ranges are beyond these budgets: 4 chunks of 192 frames / 3 of ~570)
+                    assert c.pv_arena_bytes() <= budget_mb << 20 and (c.pv_last_chunks() >= 3 or st < 0), (r, c.pv_last_chunks())
+            # the maps as the host form returns them, and the carry folded on the device = shard.pv_fold_carry (through the outputs)
+            m = maps.read().reshape(world, sh.PV_MAP_BYTES)
+            sums0, org0 = ctxs[0].pv_shard_analyze(auds[0], st, 0, world)
+            assert np.array_equal(m[0, : 4 * 2048].view(np.uint32), sums0) and np.array_equal(m[0, 4 * 2048:].view(np.uint16), org0)
+            assert (org0 == 0xFFFF).all()  # the rank that holds frame 0 restarts every bin
+            for r, c in enumerate(ctxs):
+                # (one format alone may be asked for: rank 1 gets no f32 buffer)
+                c.pv_shard_synthesize_dev(maps.ptr, None if r == 1 else f32[r].ptr, i16[r].ptr, seams.ptr + r * sh.PV_SEAM_BYTES)
+            assert not seams.read(np.float32, 0, 3840).any()  # rank 0's head seam: zeros
+            for c in ctxs:
+                c.pv_shard_finish_dev(seams.ptr)
+            got_i = np.concatenate([b.read(np.int16) for b in i16])
+            assert np.array_equal(got_i, whole_i), (st, world, budget_mb)
+            for r, (lo, hi) in enumerate(rng):
+                if r != 1:
+                    assert np.array_equal(f32[r].read(np.uint32), whole_f[lo:hi].view(np.uint32)), (st, world, budget_mb, r)
+            for c, x in zip(ctxs, auds):
+                x.free()
+                c.close()
+            for b in bufs:
+                b.free()
+            ctxs, auds, bufs = [], [], []
+    finally:
+        for c in ctxs:
+            c.close()
+        for b in bufs:
+            b.free()
+        a.free()
 
 
 @pytest.mark.gpu

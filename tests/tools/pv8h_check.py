@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """tests/tools/pv8h_check.py [hours] [world] — the phase vocoder over BASELINE configs[3]'s signal (8 h of 48 kHz audio, 6.4 M
-analysis frames at +3 st) on ONE GPU: the bounded arena (<= 2.5 GB whatever the length), properties of the output, and the
-multi-GPU path on the same signal — `world` ranks played by contexts on this device, each walking a range many chunks long
-(stage 1 keeps the maps only, stage 2 analyses again with the carry, the rank's edges wait for the seams) — equal to the
-single call bit for bit.  Run by tests/test_gpu_fullsize.py in a process of its own (it holds ~25 GB of device memory)."""
+analysis frames at +3 st) on ONE GPU: the budgeted arena (default: a quarter of the free memory -> a handful of long chunks;
+2.4 GB -> ~200 short ones; same samples), properties of the output, and the multi-GPU path on the same signal — `world` ranks
+played by contexts on this device through the device-pointer stages (mx_pv_shard_*_dev): a range that fits the budget stays
+resident and is analysed ONCE, so a rank's three stages must cost about its share of the single call (<= 1.1 x, VERDICT r05
+item 1) — equal to the single call bit for bit.  Run by tests/test_gpu_fullsize.py in a process of its own."""
 import os
 import sys
 import time
@@ -31,19 +32,37 @@ f32 = torch.empty(n, dtype=torch.float32, device=dev)
 i16 = torch.empty(n, dtype=torch.int16, device=dev)
 torch.cuda.synchronize()
 free1, _ = torch.cuda.mem_get_info()
+budget = ctx.pv_arena_budget()
 ts = []
-for _ in range(2):
+for _ in range(3):
     t0 = time.perf_counter()
     ctx.pv_pitch_shift_dev(audio, st, f32.data_ptr(), i16.data_ptr())
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
 arena = ctx.pv_arena_bytes()
+chunks = ctx.pv_last_chunks()
 free2, _ = torch.cuda.mem_get_info()
 frames = int(np.ceil(n * 2.0 ** (st / 12.0) / 256)) + 1
-print(f"pv {hours:g} h {st:+g} st: {frames} frames, call ms {ts[0]:.1f} (first: arena built) / {ts[1]:.1f}; arena {arena / 1e9:.3f} GB; "
-      f"device memory taken by the call {(free1 - free2) / 1e9:.3f} GB", flush=True)
-assert 0 < arena <= 2.5e9, arena
-assert free1 - free2 <= 2.6e9, (free1, free2)  # nothing else was allocated behind the caller's back
+single_ms = min(ts[1:])
+print(f"pv {hours:g} h {st:+g} st: {frames} frames, call ms {ts[0]:.1f} (first: arena built) / {ts[1]:.1f} / {ts[2]:.1f}; arena {arena / 1e9:.3f} GB "
+      f"of a budget of {budget / 1e9:.1f} GB, {chunks} chunk(s); device memory taken by the call {(free1 - free2) / 1e9:.3f} GB", flush=True)
+assert 0 < arena <= budget and 0.2 * free1 <= budget <= 0.26 * free1, (arena, budget, free1)
+assert free1 - free2 <= arena + 0.2e9, (free1, free2)  # nothing else was allocated behind the caller's back
+assert chunks >= 2 or hours < 2
+# the same call through a 2.4 GB arena (round 5's fixed size): same samples
+small = torch.empty(n, dtype=torch.int16, device=dev)
+ctx.pv_set_arena_budget(2400 << 20)
+t0 = time.perf_counter()
+ctx.pv_pitch_shift_dev(audio, st, None, small.data_ptr())
+torch.cuda.synchronize()
+t_small = (time.perf_counter() - t0) * 1e3
+ctx.pv_pitch_shift_dev(audio, st, None, small.data_ptr())
+print(f"   ... through a 2.4 GB budget: {ctx.pv_last_chunks()} chunks, arena {ctx.pv_arena_bytes() / 1e9:.3f} GB, call ms {t_small:.1f} (arena built in it); "
+      f"int16 {'equal' if torch.equal(small, i16) else 'DIFFERS'}", flush=True)
+assert torch.equal(small, i16) and ctx.pv_arena_bytes() <= 2400 << 20
+del small
+ctx.pv_set_arena_budget(0)
+ctx.release_scratch()
 # properties: int16 = the f32 clamped and scaled; the level of a sweep is kept; deterministic
 ref16 = (f32.clamp(-1.0, 1.0).to(torch.float64) * 32767.0).to(torch.int16)
 assert torch.equal(ref16, i16)
@@ -75,23 +94,56 @@ sel = (expect > band[0] + 3) & (expect < band[1] - 3) & (h > 64) & (h < F - 64)
 assert sel.sum() > 400000 * hours / 8
 assert np.abs(bins[sel] - expect[sel]).max() <= 2.0, float(np.abs(bins[sel] - expect[sel]).max())
 del out_a, pitch
-# the same signal as `world` ranks (contexts on this device; the two exchanges by hand)
+# the same signal as `world` ranks: contexts on this device, the device-pointer stages, the two all-gathers played by two
+# device buffers every "rank" writes its entry of.  The ranks run one after the other (they share the GPU), so a rank's stage
+# times are what it would take on a GPU of its own.
 ctxs = [mx.Context(0) for _ in range(world)]
+for c in ctxs:
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
 auds = [c.wrap_device(audio_t.data_ptr(), n, keepalive=audio_t) for c in ctxs]
-t0 = time.perf_counter()
-tots = [c.pv_shard_analyze(x, st, r, world) for r, (c, x) in enumerate(zip(ctxs, auds))]
-all_sums = np.stack([t[0] for t in tots])
-all_org = np.stack([t[1] for t in tots])
-seams = [c.pv_shard_synthesize(sh.pv_fold_carry(all_sums, all_org, r) if r else None) for r, c in enumerate(ctxs)]
+maps = torch.zeros(world * sh.PV_MAP_BYTES, dtype=torch.uint8, device=dev)
+seams = torch.zeros(world * sh.PV_SEAM_BYTES, dtype=torch.uint8, device=dev)
+rng = [mx.pv_shard_frames(n, st, r, world) for r in range(world)]
+pf = [torch.empty(hi - lo, dtype=torch.float32, device=dev) for _, _, lo, hi in rng]
+pi = [torch.empty(hi - lo, dtype=torch.int16, device=dev) for _, _, lo, hi in rng]
+stage = np.zeros((world, 3))
+info = [None] * world
+
+
+def finish(r):
+    t0 = time.perf_counter()
+    ctxs[r].pv_shard_finish_dev(seams.data_ptr())
+    stage[r, 2] = (time.perf_counter() - t0) * 1e3
+    ctxs[r].release_scratch()  # (its arena goes back: at most three ranks' arenas are alive on this one device)
+
+
+# rank by rank, as far as the data flow allows: stage 2 of rank r needs the maps of the ranks below it, stage 3 of rank r the
+# tail of rank r - 1 and the head of rank r + 1
+for r, (c, x) in enumerate(zip(ctxs, auds)):
+    c.pv_shard_analyze_dev(x, st, r, world, maps.data_ptr() + r * sh.PV_MAP_BYTES)  # (untimed: the arena is built in it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    c.pv_shard_analyze_dev(x, st, r, world, maps.data_ptr() + r * sh.PV_MAP_BYTES)
+    stage[r, 0] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    c.pv_shard_synthesize_dev(maps.data_ptr(), pf[r].data_ptr(), pi[r].data_ptr(), seams.data_ptr() + r * sh.PV_SEAM_BYTES)
+    stage[r, 1] = (time.perf_counter() - t0) * 1e3
+    info[r] = (c.pv_last_chunks(), c.pv_arena_bytes(), c.pv_arena_budget())
+    if r > 0:
+        finish(r - 1)
+finish(world - 1)
+torch.cuda.synchronize()
 ok = True
-for r, c in enumerate(ctxs):
-    _, _, lo, hi = mx.pv_shard_frames(n, st, r, world)
-    pf, pi = c.pv_shard_finish(hi - lo, seams[r - 1][1] if r else None, seams[r + 1][0] if r < world - 1 else None)
-    assert c.pv_arena_bytes() <= 2.5e9
-    ok &= bool(torch.equal(torch.from_numpy(pf.view(np.int32)).to(dev), f32[lo:hi].view(torch.int32)))
-    ok &= bool(torch.equal(torch.from_numpy(pi).to(dev), i16[lo:hi]))
-    del pf, pi
+for r, (flo, fhi, lo, hi) in enumerate(rng):
+    ok &= bool(torch.equal(pf[r].view(torch.int32), f32[lo:hi].view(torch.int32))) and bool(torch.equal(pi[r], i16[lo:hi]))
+    share = single_ms * (fhi - flo) / frames
+    tot = float(stage[r].sum())
+    print(f"   rank {r}/{world}: frames [{flo}, {fhi}), {info[r][0]} chunk(s), arena {info[r][1] / 1e9:.2f} GB of {info[r][2] / 1e9:.1f}; stage ms "
+          f"{stage[r, 0]:.2f} + {stage[r, 1]:.2f} + {stage[r, 2]:.2f} = {tot:.2f} = {tot / share:.3f} x its share of the single call ({share:.2f} ms)", flush=True)
+    # (a resident range is analysed once: <= 1.1 x its share; a range beyond the budget is analysed twice)
+    assert info[r][0] > 1 or tot <= 1.1 * share + 0.3, (r, tot, share)
+for c in ctxs:
     c.close()
-print(f"{world} ranks on one device: {time.perf_counter() - t0:.1f} s incl. host copies; slices {'equal' if ok else 'DIFFER from'} the single call", flush=True)
+print(f"{world} ranks on one device: slices {'equal' if ok else 'DIFFER from'} the single call", flush=True)
 assert ok
 print("pv8h_check ok")

@@ -56,4 +56,5 @@ for _ in range(4):
 h32 = hashlib.sha1(f32.cpu().numpy().tobytes()).hexdigest()
 h16 = hashlib.sha1(i16.cpu().numpy().tobytes()).hexdigest()
 print(f"pv {signal} {minutes:g} min {st:+g} st [{os.environ.get('MX_AB_LIB', 'shipped')}]: call ms {min(ts[1:]):.2f} (runs {', '.join(f'{x:.2f}' for x in ts)}); "
-      f"sha1 f32 {h32[:16]} i16 {h16[:16]}", flush=True)
+      f"sha1 f32 {h32[:16]} i16 {h16[:16]}; arena {ctx.pv_arena_bytes() / 1e9:.2f} GB of a budget of {ctx.pv_arena_budget() / 1e9:.1f} GB, "
+      f"{ctx.pv_last_chunks()} chunk(s)", flush=True)
