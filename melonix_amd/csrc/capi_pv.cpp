@@ -824,14 +824,20 @@ static int pv_shard_analyze_core(mx_ctx *ctx, const mx_audio *a, double semitone
   if (rc) return rc;
   pv_shard_drop(*p);
   const int64_t K = (int64_t)pv_chunks_of(lo, hi, p->C).size();
-  // every chunk's total map (12 KiB each), folded into the rank's behind the last analysis
-  uint32_t *d_sums = nullptr;
-  uint16_t *d_org = nullptr;
-  hipError_t e = hipMalloc(&d_sums, (size_t)K * kPvM * 4);
-  if (e == hipSuccess) e = hipMalloc(&d_org, (size_t)K * kPvM * 2);
-  if (e != hipSuccess) {
-    hipFree(d_sums);
-    return fail(MX_ERR_NOMEM, "phase-vocoder chunk maps: %s", hipGetErrorString(e));
+  // every chunk's total map (12 KiB each), folded into the rank's behind the last analysis; a resident range has one: it is
+  // written where it stays (no allocation on the way of a rank that fits its budget)
+  uint32_t *d_sums = p->slot[0].tot_sums, *own_sums = nullptr;
+  uint16_t *d_org = p->slot[0].tot_org, *own_org = nullptr;
+  hipError_t e = hipSuccess;
+  if (K > 1) {
+    e = hipMalloc(&own_sums, (size_t)K * kPvM * 4);
+    if (e == hipSuccess) e = hipMalloc(&own_org, (size_t)K * kPvM * 2);
+    if (e != hipSuccess) {
+      hipFree(own_sums);
+      return fail(MX_ERR_NOMEM, "phase-vocoder chunk maps: %s", hipGetErrorString(e));
+    }
+    d_sums = own_sums;
+    d_org = own_org;
   }
   PvRun run;
   run.a = a;
@@ -855,8 +861,8 @@ static int pv_shard_analyze_core(mx_ctx *ctx, const mx_audio *a, double semitone
     if (e == hipSuccess) e = hipMemcpyAsync(static_cast<char *>(map_out) + kPvM * 4, ro, kPvM * 2, kind, p->ss);
   }
   const hipError_t es = hipStreamSynchronize(p->ss);
-  hipFree(d_sums);
-  hipFree(d_org);
+  hipFree(own_sums);
+  hipFree(own_org);
   if (rc) return rc;
   if (e == hipSuccess) e = es;
   if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (analysis): %s", hipGetErrorString(e));
@@ -894,31 +900,20 @@ static int pv_shard_synthesize_core(mx_ctx *ctx, const uint32_t *carry_host, con
   const int64_t cnt = j.out_hi - j.out_lo;
   hipError_t e = hipSuccess;
   // the carry first: nothing is allocated yet if it cannot be had
-  uint32_t *fold_s = nullptr;
-  uint16_t *fold_o = nullptr;
   if (!j.first) {
     if (d_maps_all) {
       // the maps of ranks 0 .. rank - 1 composed in order and applied to a zero row: the composed map's sums (a bin whose
-      // source is a bin of the zero row ends at its sum; so does one that restarted)
-      constexpr size_t kEntry = (size_t)kPvM * 6;
-      e = hipMalloc(&fold_s, (size_t)j.rank * kPvM * 4);
-      if (e == hipSuccess) e = hipMalloc(&fold_o, (size_t)j.rank * kPvM * 2);
-      if (e != hipSuccess) {
-        hipFree(fold_s);
-        pv_shard_drop(*p);
-        return fail(MX_ERR_NOMEM, "phase-vocoder rank maps: %s", hipGetErrorString(e));
-      }
-      PV_TRY(hipMemcpy2DAsync(fold_s, (size_t)kPvM * 4, d_maps_all, kEntry, (size_t)kPvM * 4, (size_t)j.rank, hipMemcpyDeviceToDevice, sm));
-      PV_TRY(hipMemcpy2DAsync(fold_o, (size_t)kPvM * 2, static_cast<const char *>(d_maps_all) + (size_t)kPvM * 4, kEntry, (size_t)kPvM * 2,
-                              (size_t)j.rank, hipMemcpyDeviceToDevice, sm));
-      PV_TRY(launch_pv_compose_maps(fold_s, fold_o, j.rank, p->carry_in, p->slot[0].tot_org, sm));
+      // source is a bin of the zero row ends at its sum; so does one that restarted) — read where the all-gather left them,
+      // one 8 KiB sums row and one 4 KiB source-bin row per rank
+      constexpr int kEntry = kPvM * 6;
+      const uint32_t *ms = static_cast<const uint32_t *>(d_maps_all);
+      const uint16_t *mo = reinterpret_cast<const uint16_t *>(static_cast<const char *>(d_maps_all) + (size_t)kPvM * 4);
+      PV_TRY(launch_pv_compose_maps(ms, mo, j.rank, p->carry_in, p->slot[0].tot_org, sm, kEntry / 4, kEntry / 2));
     } else {
       PV_TRY(hipMemcpyAsync(p->carry_in, carry_host, kPvM * 4, hipMemcpyHostToDevice, sm));
     }
     if (e != hipSuccess) {
       hipStreamSynchronize(sm);
-      hipFree(fold_s);
-      hipFree(fold_o);
       pv_shard_drop(*p);
       return fail(MX_ERR_DEVICE, "phase vocoder (carry): %s", hipGetErrorString(e));
     }
@@ -932,8 +927,6 @@ static int pv_shard_synthesize_core(mx_ctx *ctx, const uint32_t *carry_host, con
       if (e == hipSuccess) e = hipMalloc(&j.d_i, (size_t)cnt * 2);
       if (e != hipSuccess) {
         hipStreamSynchronize(sm);
-        hipFree(fold_s);
-        hipFree(fold_o);
         pv_shard_drop(*p);
         return fail(MX_ERR_NOMEM, "device PCM buffers: %s", hipGetErrorString(e));
       }
@@ -968,8 +961,6 @@ static int pv_shard_synthesize_core(mx_ctx *ctx, const uint32_t *carry_host, con
     if (e == hipSuccess) e = hipMemcpyAsync(tail_out, p->tail_raw, kPvSeam * 4, kind, sm);
   }
   const hipError_t es = hipStreamSynchronize(sm);
-  hipFree(fold_s);
-  hipFree(fold_o);
   if (rc == MX_OK && e == hipSuccess) e = es;
   if (rc || e != hipSuccess) {
     pv_shard_drop(*p);

@@ -124,7 +124,9 @@ hipError_t launch_pv_offsets(const PvArgs &a, hipStream_t s);
 hipError_t launch_pv_synthesis(const PvArgs &a, hipStream_t s);
 hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s);
 int64_t pv_halo_floats(int64_t frames);
-hipError_t launch_pv_compose_maps(uint32_t *sums, uint16_t *org, int64_t n, uint32_t *out_sums, uint16_t *out_org, hipStream_t s);
+// the composition, in order, of n maps -> one; sums_stride / org_stride: elements between consecutive maps' rows (0: dense, N/2)
+hipError_t launch_pv_compose_maps(const uint32_t *sums, const uint16_t *org, int64_t n, uint32_t *out_sums, uint16_t *out_org, hipStream_t s,
+                                  int sums_stride = 0, int org_stride = 0);
 hipError_t launch_pv_resample(const PvArgs &a, hipStream_t s);
 hipError_t launch_pv_edge_sum(float *dst, const float *x, const float *y, int n, hipStream_t s);
 // constant-ratio analysis plan written on the device: rows of apos / hop / hratio for global frames fbase, fbase+1, ...

@@ -533,15 +533,18 @@ constexpr int kPvGroup = 32;
 template <bool MAP>
 __global__ __launch_bounds__(kChunkT) void pv_lock_chunks(uint32_t *sums, uint16_t *org, int64_t n, int per_group,
                                                           const uint32_t *init, int init_per_group, uint32_t *out_sums,
-                                                          uint16_t *out_org, uint32_t *final_out) {
+                                                          uint16_t *out_org, uint32_t *final_out, int s_stride = kPvM,
+                                                          int o_stride = kPvM) {
+  // (s_stride / o_stride: elements from one map's row to the next — kPvM where the maps are two dense arrays; the gathered
+  // rank maps of a multi-GPU run interleave a 8 KiB sums row and a 4 KiB source-bin row per rank)
   MX_LATENCY_BOUND_KERNEL();
   __shared__ uint32_t D[2][kPvM];
   __shared__ uint16_t O[MAP ? 2 : 1][MAP ? kPvM : 2];
   const int t = threadIdx.x;
   const int64_t n0 = (int64_t)blockIdx.x * per_group;
   const int64_t cnt = n0 + per_group < n ? per_group : n - n0;
-  sums += n0 * kPvM;
-  org += n0 * kPvM;
+  sums += n0 * s_stride;
+  org += n0 * o_stride;
   if (init && init_per_group) init += (int64_t)blockIdx.x * kPvM;
   uint32_t sd[kChunkV];
   uint16_t so[kChunkV];
@@ -570,14 +573,14 @@ __global__ __launch_bounds__(kChunkT) void pv_lock_chunks(uint32_t *sums, uint16
     if (c + 1 < cnt) {
 #pragma unroll
       for (int j = 0; j < kChunkV; ++j) {
-        nd[j] = sums[(c + 1) * kPvM + t + kChunkT * j];
-        no[j] = org[(c + 1) * kPvM + t + kChunkT * j];
+        nd[j] = sums[(c + 1) * s_stride + t + kChunkT * j];
+        no[j] = org[(c + 1) * o_stride + t + kChunkT * j];
       }
     }
 #pragma unroll
     for (int j = 0; j < kChunkV; ++j) {
       const int k = t + kChunkT * j;
-      if constexpr (!MAP) sums[c * kPvM + k] = sd[j];  // the offsets this map starts from
+      if constexpr (!MAP) sums[c * s_stride + k] = sd[j];  // the offsets this map starts from
       if (co[j] == kPvNoBin) {
         sd[j] = cd[j];
         so[j] = kPvNoBin;
@@ -1131,10 +1134,13 @@ hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s) {
 }
 // The composition, in order, of n maps (sums / org [n][N/2]) -> out_sums / out_org [N/2]: a rank that walks its frames chunk
 // by chunk keeps every chunk's total map (12 KiB) and folds them into the rank's here.
-hipError_t launch_pv_compose_maps(uint32_t *sums, uint16_t *org, int64_t n, uint32_t *out_sums, uint16_t *out_org, hipStream_t s) {
+hipError_t launch_pv_compose_maps(const uint32_t *sums, const uint16_t *org, int64_t n, uint32_t *out_sums, uint16_t *out_org, hipStream_t s,
+                                  int sums_stride, int org_stride) {
   if (n <= 0 || n > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(1), dim3(kChunkT), 0, s, sums, org, n, (int)n, (const uint32_t *)nullptr, 0,
-                     out_sums, out_org, (uint32_t *)nullptr);
+  // (MAP = true reads the maps only)
+  hipLaunchKernelGGL(pv_lock_chunks<true>, dim3(1), dim3(kChunkT), 0, s, const_cast<uint32_t *>(sums), const_cast<uint16_t *>(org), n, (int)n,
+                     (const uint32_t *)nullptr, 0, out_sums, out_org, (uint32_t *)nullptr, sums_stride > 0 ? sums_stride : kPvM,
+                     org_stride > 0 ? org_stride : kPvM);
   return hipGetLastError();
 }
 

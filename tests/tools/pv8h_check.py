@@ -106,32 +106,35 @@ seams = torch.zeros(world * sh.PV_SEAM_BYTES, dtype=torch.uint8, device=dev)
 rng = [mx.pv_shard_frames(n, st, r, world) for r in range(world)]
 pf = [torch.empty(hi - lo, dtype=torch.float32, device=dev) for _, _, lo, hi in rng]
 pi = [torch.empty(hi - lo, dtype=torch.int16, device=dev) for _, _, lo, hi in rng]
-stage = np.zeros((world, 3))
+stage = np.full((world, 3), np.inf)
 info = [None] * world
 
 
 def finish(r):
     t0 = time.perf_counter()
     ctxs[r].pv_shard_finish_dev(seams.data_ptr())
-    stage[r, 2] = (time.perf_counter() - t0) * 1e3
+    stage[r, 2] = min(stage[r, 2], (time.perf_counter() - t0) * 1e3)
     ctxs[r].release_scratch()  # (its arena goes back: at most three ranks' arenas are alive on this one device)
+    torch.cuda.synchronize()
 
 
 # rank by rank, as far as the data flow allows: stage 2 of rank r needs the maps of the ranks below it, stage 3 of rank r the
-# tail of rank r - 1 and the head of rank r + 1
-for r, (c, x) in enumerate(zip(ctxs, auds)):
-    c.pv_shard_analyze_dev(x, st, r, world, maps.data_ptr() + r * sh.PV_MAP_BYTES)  # (untimed: the arena is built in it)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    c.pv_shard_analyze_dev(x, st, r, world, maps.data_ptr() + r * sh.PV_MAP_BYTES)
-    stage[r, 0] = (time.perf_counter() - t0) * 1e3
-    t0 = time.perf_counter()
-    c.pv_shard_synthesize_dev(maps.data_ptr(), pf[r].data_ptr(), pi[r].data_ptr(), seams.data_ptr() + r * sh.PV_SEAM_BYTES)
-    stage[r, 1] = (time.perf_counter() - t0) * 1e3
-    info[r] = (c.pv_last_chunks(), c.pv_arena_bytes(), c.pv_arena_budget())
-    if r > 0:
-        finish(r - 1)
-finish(world - 1)
+# tail of rank r - 1 and the head of rank r + 1.  Two passes, the faster of each stage kept (eight contexts take turns on one
+# device here, tens of GB of arena are mapped and unmapped between the stages: a rank on a GPU of its own has none of that).
+for rep in range(2):
+    for r, (c, x) in enumerate(zip(ctxs, auds)):
+        c.pv_shard_analyze_dev(x, st, r, world, maps.data_ptr() + r * sh.PV_MAP_BYTES)  # (untimed: the arena is built in it)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        c.pv_shard_analyze_dev(x, st, r, world, maps.data_ptr() + r * sh.PV_MAP_BYTES)
+        stage[r, 0] = min(stage[r, 0], (time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        c.pv_shard_synthesize_dev(maps.data_ptr(), pf[r].data_ptr(), pi[r].data_ptr(), seams.data_ptr() + r * sh.PV_SEAM_BYTES)
+        stage[r, 1] = min(stage[r, 1], (time.perf_counter() - t0) * 1e3)
+        info[r] = (c.pv_last_chunks(), c.pv_arena_bytes(), c.pv_arena_budget())
+        if r > 0:
+            finish(r - 1)
+    finish(world - 1)
 torch.cuda.synchronize()
 ok = True
 for r, (flo, fhi, lo, hi) in enumerate(rng):
