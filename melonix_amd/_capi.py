@@ -160,7 +160,21 @@ def check_identity(version: str, path: str) -> None:
 
     if os.environ.get("MELONIX_ALLOW_STALE") == "1" or os.path.abspath(path) != os.path.abspath(_DEFAULT_LIB_PATH):
         return
-    want, have = _build.source_sha(), library_src_sha(version)
+    have = library_src_sha(version)
+    try:
+        want = _build.source_sha()
+    except OSError as exc:
+        # a deployment that carries the library without its sources (a wheel, a box that received only the .so): nothing to compare
+        # with — fall back on the digits build() left beside the library's objects, else say what is missing
+        want = None
+        sha_file = os.path.join(_HERE, "build", "src_sha.txt")
+        if os.path.exists(sha_file):
+            with open(sha_file) as fh:
+                want = fh.read().strip()
+        if not want:
+            raise ImportError(
+                f"{path}: cannot check that the library was built from this tree ({exc}); the sources under melonix_amd/csrc and "
+                "include/ are needed for that — ship them with the library, or set MELONIX_ALLOW_STALE=1 to load it unchecked.") from exc
     if have != want:
         raise ImportError(
             f"{path} was built from other sources than the ones beside it (library src:{have or '?'}, tree src:{want}): "

@@ -173,3 +173,39 @@ def test_loader_refuses_a_library_not_built_from_the_tree(tmp_path, monkeypatch)
     _capi.check_identity(ver, _capi.LIB_PATH)
     monkeypatch.delenv("MELONIX_ALLOW_STALE")
     _capi.check_identity(ver, str(tmp_path / "elsewhere.so"))  # (a library loaded from another path — an A/B build — is not this tree's)
+
+
+def test_loader_without_the_sources_beside_it(tmp_path, monkeypatch):
+    """A deployment that carries the library but not melonix_amd/csrc: the identity check falls back on the digits
+    build() left in melonix_amd/build/src_sha.txt; with neither it raises the explanatory ImportError, not a bare
+    FileNotFoundError."""
+    from melonix_amd import _capi, build
+
+    ver = _capi.lib().mx_version().decode()
+    monkeypatch.delenv("MELONIX_ALLOW_STALE", raising=False)
+    monkeypatch.setattr(build, "CSRC", str(tmp_path / "no_such_csrc"))
+    _capi.check_identity(ver, _capi.LIB_PATH)  # (src_sha.txt carries the digits of the build that made the library)
+    monkeypatch.setattr(_capi, "_HERE", str(tmp_path))
+    with pytest.raises(ImportError, match="cannot check that the library was built from this tree"):
+        _capi.check_identity(ver, _capi.LIB_PATH)
+
+
+@pytest.mark.gpu
+def test_kept_traffic_figures_are_current_on_the_gpu_box():
+    """The hard form of test_kept_traffic_figure_belongs_to_the_shipped_kernel_sources (which only xfails in the CPU suite): on the
+    box that could have re-taken them, every profiles/pmc_latest*.json bench.py quotes roofline.traffic from must belong to the
+    shipped STFT kernel sources — a stale one fails the GPU batch."""
+    import glob
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_latest*.json")))
+    assert len(files) >= 2, files  # the headline size and configs[4]
+    for f in files:
+        with open(f) as fh:
+            kept = json.load(fh)
+        assert kept["kernel_source_sha1"] == bench.kernel_source_hash(), f"{f}: re-take it with tools/profile_gpu.sh"
+        assert kept["hbm_bytes_per_launch"] >= bench.b_alg(kept["fft"], kept["hop"]) * kept["frames"]  # traffic >= algorithmic bytes
