@@ -74,7 +74,7 @@ int mx_ctx_set_stream(mx_ctx *ctx, void *hip_stream);
 int mx_ctx_use_own_stream(mx_ctx *ctx);
 int mx_ctx_synchronize(mx_ctx *ctx);
 /* The context keeps its work buffers between calls (device staging of the host-pointer entry points, the phase
- * vocoder's arena — 2.4 GB whatever the signal's length —, the host landing zone of mx_grains_dev); this releases them.
+ * vocoder's budgeted arena and its automatic budget, the host landing zone of mx_grains_dev); this releases them.
  * mx_ctx_destroy does so too. */
 int mx_ctx_release_scratch(mx_ctx *ctx);
 /* Run length: consecutive frames one workgroup of a bulk (uniform-hop) launch walks.  The sliding-window kernels
@@ -94,7 +94,12 @@ int mx_ctx_set_frames_per_block(mx_ctx *ctx, int frames);
  * facade's Spec worker lands every batch in such a buffer and recycles it.  Free with mx_pinned_free. */
 int mx_pinned_alloc(mx_ctx *ctx, size_t bytes, void **out);
 void mx_pinned_free(mx_ctx *ctx, void *p);
-/* Thread-local description of the last error returned on this thread. */
+/* ERRORS.  Every entry point reports failure through its return value — a negative status (int / int64_t entry points), NaN (the
+ * double / float time maps), MX_ERR_* as the int of mx_time2sample — and a thread-local description of the last error returned on
+ * this thread; nothing is ever thrown across this boundary (every entry point's body runs inside a catch-all: std::bad_alloc ->
+ * MX_ERR_NOMEM, any other exception -> MX_ERR_INVALID), and a failed call leaves its output pointers and handles untouched.
+ * The reference signals no errors at all (spec.cpp / app.cpp:628-666 degrade to empty results); the facade maps a failed call to
+ * an empty vector / a black column the same way. */
 const char *mx_last_error(void);
 /* "melonix_amd <version> gfx950" */
 const char *mx_version(void);
