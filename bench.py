@@ -618,18 +618,21 @@ def main() -> None:
             out16 = torch.empty(n, dtype=torch.int16, device=dev)
             ctx.pv_pitch_shift_dev(audio, 3.0, None, out16.data_ptr())
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ctx.pv_pitch_shift_dev(audio, 3.0, None, out16.data_ptr())
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            runs = []
+            for _ in range(4):  # (one sample of a 10 ms call catches the clock / power manager mid-transition every few boxes)
+                t0 = time.perf_counter()
+                ctx.pv_pitch_shift_dev(audio, 3.0, None, out16.data_ptr())
+                torch.cuda.synchronize()
+                runs.append((time.perf_counter() - t0) * 1e3)
+            dt = min(runs) * 1e-3
             fpv = int(np.ceil(n * 2.0 ** (3 / 12) / 256)) + 1
-            pv = {"pitch_shift_semitones": 3, "frames": fpv, "call_ms": dt * 1e3, "frames_per_s": fpv / dt,
+            pv = {"pitch_shift_semitones": 3, "frames": fpv, "call_ms": dt * 1e3, "call_ms_runs": runs, "frames_per_s": fpv / dt,
                   "arena_bytes": ctx.pv_arena_bytes(), "arena_budget_bytes": ctx.pv_arena_budget(), "chunks": ctx.pv_last_chunks(),
                   "arena_policy": "default: budget = a quarter of the free device memory at the context's first call; a call that "
                                   "fits is one resident chunk, else the longest chunks the budget holds",
                   "output_rms": float(out16.float().pow(2).mean().sqrt().item() / 32767.0),
-                  "note": "build-defined (no reference counterpart); N=4096, synthesis hop 256, identity phase locking; second call timed "
-                          "(the first builds the arena)"}
+                  "note": "build-defined (no reference counterpart); N=4096, synthesis hop 256, identity phase locking; the first call builds "
+                          "the arena (untimed), call_ms = the fastest of the four that follow (call_ms_runs)"}
             ctx.release_scratch()  # (the arena goes back before the other secondaries allocate)
             del out16
         except Exception as exc:  # never let a supplementary figure take the headline line down
