@@ -274,6 +274,7 @@ int mx_ctx_release_scratch(mx_ctx *ctx) {
       std::lock_guard<std::mutex> lk(ctx->pv_mu);
       pv_release(ctx);  // (a staged multi-GPU job lives in that arena: it ends here)
       ctx->pv_budget_auto = 0;  // (the automatic budget is taken again from what is free at the next first use)
+    ctx->pv_rec_full = false;
     }
     {
       std::lock_guard<std::mutex> lk(ctx->zc_mu);

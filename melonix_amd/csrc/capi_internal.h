@@ -119,6 +119,9 @@ struct mx_ctx {
   // the arena's budget: set (mx_pv_set_arena_budget; 0 = not set) and the automatic one (a quarter of the free device memory when
   // the context first needed an arena; forgotten by mx_ctx_release_scratch)
   int64_t pv_budget_bytes = 0, pv_budget_auto = 0;
+  // a signal overflowed the compact record regions once: the context's arenas are laid out with full-size regions from then on
+  // (until mx_ctx_release_scratch)
+  bool pv_rec_full = false;
 };
 
 struct mx_audio {

@@ -34,6 +34,11 @@ constexpr int64_t kPvMaxChunk = 1 << 22;
 constexpr int kPvSlots = 2;  // (three or four buy nothing: profiles/timeline_r05_pv_pipeline.log)
 constexpr int kPvPlanRing = 4;  // chunk k + 3's plan rows are written while chunk k - 1's are long read
 constexpr int kPvOutRing = 4;  // chunk k's synthesis writes while chunk k - 2's fix-up reads k - 2, k - 1 (head) and k - 3 (boundary)
+// Peak records: every analysis workgroup packs its frames' records into a region of its own of kPvRecPerFrame x (its frames)
+// entries — a quarter of the 2048 a frame can have (an impulse, a frame of pure noise floor): sweeps and music have tens to a few
+// hundred peaks per frame.  A run whose signal does not fit raises the overflow flag and is repeated, once, with full regions
+// (kPvM per frame: cannot overflow); the context then stays with those until its scratch is released.
+constexpr int kPvRecPerFrame = 512;
 constexpr int kPvMinScan = 64;              // frames per scan chunk of the phase recurrence, at least
 constexpr int64_t kPvMaxScanChunks = 1536;  // one round of row-walking workgroups, six per CU
 
@@ -54,10 +59,11 @@ int64_t pv_first_output_at(int64_t q, double r, int64_t n) {
 struct PvShape {
   int64_t C = 0;
   int slots = kPvSlots, outs = kPvOutRing, plans = kPvPlanRing;
-  bool operator==(const PvShape &o) const { return C == o.C && slots == o.slots && outs == o.outs && plans == o.plans; }
+  int rpf = kPvRecPerFrame;  // record capacity per frame of an analysis workgroup's region (kPvM: full)
+  bool operator==(const PvShape &o) const { return C == o.C && slots == o.slots && outs == o.outs && plans == o.plans && rpf == o.rpf; }
 };
-constexpr PvShape pv_chunked(int64_t C) { return PvShape{C, kPvSlots, kPvOutRing, kPvPlanRing}; }
-constexpr PvShape pv_resident(int64_t C) { return PvShape{C, 1, 1, 1}; }
+constexpr PvShape pv_chunked(int64_t C, int rpf) { return PvShape{C, kPvSlots, kPvOutRing, kPvPlanRing, rpf}; }
+constexpr PvShape pv_resident(int64_t C, int rpf) { return PvShape{C, 1, 1, 1, rpf}; }
 
 struct PvPipe {
   PvShape shape;
@@ -86,6 +92,9 @@ struct PvPipe {
     double *tf, *rf;
     int64_t *i0;
   } out[kPvOutRing] = {};
+  // [1] raised by an analysis whose record regions are too small for the signal: page-locked host memory the kernels write
+  // through (once, on the rare overflow) and the host reads behind the call's synchronisation without another API call
+  uint32_t *rec_overflow = nullptr;
   uint32_t *carry[2];  // the dense offset row behind chunk k's last frame: carry[k & 1]
   // one rank of a multi-GPU run: what it gets from its neighbours and owes them
   uint32_t *carry_in = nullptr;
@@ -135,8 +144,9 @@ size_t pv_layout(PvPipe &p, const PvShape &sh, char *base) {
   for (int si = 0; si < sh.slots; ++si) {
     PvPipe::Slot &sl = p.slot[si];
     sl.xrows = reinterpret_cast<float2 *>(take((size_t)rows * kPvM * 8));
-    // (room for a peak in every bin — silence, an impulse —: only a frame's first pkcount records are ever touched)
-    sl.recs = reinterpret_cast<uint2 *>(take((size_t)rows * kPvM * 8));
+    // the record pool: one region per analysis workgroup (8 or 16 frames: rows rounded up to 16 covers either cut), rpf entries
+    // per frame; + one row of slack (a walk's lanes past a row's count read entries nobody wrote — behind the last region too)
+    sl.recs = reinterpret_cast<uint2 *>(take(((size_t)(rows + 16) * (size_t)sh.rpf + kPvM) * 8));
     sl.pkmap = reinterpret_cast<uint32_t *>(take((size_t)rows * (kPvM / 32) * 4));
     sl.pkcount = reinterpret_cast<uint32_t *>(take((size_t)rows * 4));
     sl.fthr = reinterpret_cast<float *>(take((size_t)rows * 4));
@@ -212,27 +222,30 @@ int pv_shape_for(mx_ctx *ctx, int64_t frames, PvShape *out) {
   int64_t C = ctx->pv_chunk_frames;
   if (C <= 0)
     if (const char *e = getenv("MELONIX_PV_CHUNK_FRAMES")) C = atoll(e);
+  // (MELONIX_PV_FULL_RECORDS=1: full-size regions from the start — the A/B of the compact layout, tests/test_pv.py)
+  const char *full_env = getenv("MELONIX_PV_FULL_RECORDS");
+  const int rpf = (ctx->pv_rec_full || (full_env && full_env[0] == '1')) ? kPvM : kPvRecPerFrame;
   if (C > 0) {
-    *out = pv_chunked(std::min<int64_t>(kPvMaxChunk, (C + 31) / 32 * 32));
+    *out = pv_chunked(std::min<int64_t>(kPvMaxChunk, (C + 31) / 32 * 32), rpf);
     return MX_OK;
   }
   size_t budget = 0;
   const int rc = pv_budget(ctx, &budget);
   if (rc) return rc;
   const int64_t Fr = std::max<int64_t>(32, (frames + 31) / 32 * 32);
-  if (pv_shape_bytes(pv_resident(Fr)) <= budget) {
-    *out = pv_resident(Fr);
+  if (pv_shape_bytes(pv_resident(Fr, rpf)) <= budget) {
+    *out = pv_resident(Fr, rpf);
     return MX_OK;
   }
   // bytes are affine in C up to the 256-byte roundings: solve, then step down onto the budget
-  const size_t b0 = pv_shape_bytes(pv_chunked(32)), b1 = pv_shape_bytes(pv_chunked(32 + 32 * 1024));
+  const size_t b0 = pv_shape_bytes(pv_chunked(32, rpf)), b1 = pv_shape_bytes(pv_chunked(32 + 32 * 1024, rpf));
   if (b0 > budget)
     return fail(MX_ERR_NOMEM, "phase-vocoder arena budget of %zu MiB is below the %zu MiB the smallest chunks need", budget >> 20, (b0 >> 20) + 1);
   const double per32 = (double)(b1 - b0) / 1024.0;
   C = 32 + 32 * (int64_t)((double)(budget - b0) / per32);
   C = std::min<int64_t>(kPvMaxChunk, std::max<int64_t>(32, C));
-  while (C > 32 && pv_shape_bytes(pv_chunked(C)) > budget) C -= 32;
-  *out = pv_chunked(C);
+  while (C > 32 && pv_shape_bytes(pv_chunked(C, rpf)) > budget) C -= 32;
+  *out = pv_chunked(C, rpf);
   return MX_OK;
 }
 
@@ -247,7 +260,7 @@ int pv_pipe(mx_ctx *ctx, int64_t frames, PvPipe **out) {
   const bool pinned = want.slots == kPvSlots && (ctx->pv_chunk_frames > 0 || getenv("MELONIX_PV_CHUNK_FRAMES"));
   if (ctx->pv) {
     const PvShape &have = ctx->pv->shape;
-    const bool keep = pinned ? have == want : (have.C >= (frames + 31) / 32 * 32 || have == want);
+    const bool keep = pinned ? have == want : ((have.C >= (frames + 31) / 32 * 32 && have.rpf == want.rpf) || have == want);
     if (keep) {
       *out = ctx->pv;
       return MX_OK;
@@ -274,8 +287,9 @@ int pv_pipe(mx_ctx *ctx, int64_t frames, PvPipe **out) {
   pv_layout(*p, want, p->base);
   ctx->pv = p.release();
   PvPipe &q = *ctx->pv;
-  hipError_t e = hipSuccess;
-  {
+  hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&q.rec_overflow), 64, hipHostMallocDefault);
+  if (e == hipSuccess) *q.rec_overflow = 0u;
+  if (e == hipSuccess) {
     // (what gets the side stream's small kernels through beside a transform is their WAVE priority — s_setprio in the
     // kernels: 0.5 ms per hour; the queue's priority measured nothing either way and is left at the default)
     e = hipStreamCreateWithFlags(&q.ss, hipStreamNonBlocking);
@@ -389,6 +403,7 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     g.hratio = p.plan[k % p.NPLAN].hratio;
     g.xrows = sl.xrows;
     g.recs = sl.recs;
+    g.rec_overflow = p.rec_overflow;
     g.pkmap = sl.pkmap;
     g.pkcount = sl.pkcount;
     g.fthr = sl.fthr;
@@ -405,6 +420,8 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     // frames per analysis workgroup: 16 in one launch over the whole signal (flat from 8 to 24 there); a chunk is four
     // rounds of workgroups at most, and what its launch loses is its ragged end — 8 (16: +0.8 ms per hour, 4: +0.2)
     g.frames_per_block = K > 1 ? 8 : 16;
+    g.rec_wg_cap = (uint32_t)(g.frames_per_block * p.shape.rpf);
+    g.rec_fpb_shift = g.frames_per_block == 8 ? 3 : 4;
     if (run.plan) {
       g.tf = o.tf;
       g.rf = o.rf;
@@ -494,6 +511,7 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
     PV_TRY(hipEventRecord(p.ev_syn[k % p.NS], sm));
   };
 
+  if (!run.reuse_analysis) *p.rec_overflow = 0u;  // (host memory; nothing of an earlier call is in flight: every entry point joins its work)
   PV_TRY(hipEventRecord(p.ev_begin, sm));  // the input, and whatever used the arena before, are stream-ordered before this
   PV_TRY(hipStreamWaitEvent(ss, p.ev_begin, 0));
   PV_TRY(hipStreamWaitEvent(sf, p.ev_begin, 0));
@@ -556,6 +574,17 @@ int pv_run(mx_ctx *ctx, PvPipe &p, PvRun &run) {
   return MX_OK;
 }
 
+// Behind a run whose work is complete (the caller has synchronised): did an analysis overflow its compact record regions?
+// Then the run's results are void: the context switches to full-size regions for good (until its scratch is released), the
+// arena goes back, and the caller repeats its run on the one pv_pipe builds next.
+bool pv_take_overflow(mx_ctx *ctx, PvPipe &p) {
+  if (!p.rec_overflow || *p.rec_overflow == 0u) return false;
+  *p.rec_overflow = 0u;
+  ctx->pv_rec_full = true;
+  pv_release(ctx);
+  return true;
+}
+
 }  // namespace
 
 void pv_release(mx_ctx *ctx) {
@@ -574,6 +603,7 @@ void pv_release(mx_ctx *ctx) {
   if (p->ss) hipStreamDestroy(p->ss);
   if (p->sf) hipStreamDestroy(p->sf);
   hipFree(p->base);
+  if (p->rec_overflow) hipHostFree(p->rec_overflow);
   delete p;
   ctx->pv = nullptr;
 }
@@ -642,19 +672,23 @@ int pv_pitch_shift_dev_impl(mx_ctx *ctx, const mx_audio *a, double semitones, fl
   run.r = std::pow(2.0, semitones / 12.0);
   run.F_lo = 0;
   run.F_hi = pv_frame_count(a->n, run.r);
-  PvPipe *p = nullptr;
-  int rc = pv_pipe(ctx, run.F_hi, &p);
-  if (rc) return rc;
-  pv_shard_drop(*p);
   run.out_lo = 0;
   run.out_hi = a->n;
   run.pcm_f32 = d_pcm_f32;
   run.pcm_i16 = d_pcm_i16;
-  rc = pv_run(ctx, *p, run);
-  const hipError_t es = hipStreamSynchronize(ctx->stream);
-  if (rc) return rc;
-  if (es != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(es));
-  return MX_OK;
+  for (int attempt = 0;; ++attempt) {
+    PvPipe *p = nullptr;
+    int rc = pv_pipe(ctx, run.F_hi, &p);
+    if (rc) return rc;
+    pv_shard_drop(*p);
+    rc = pv_run(ctx, *p, run);
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (rc) return rc;
+    if (es != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(es));
+    if (!pv_take_overflow(ctx, *p)) return MX_OK;
+    // (more peaks than the compact record regions hold — an impulse train, noise —: once more, with full-size regions)
+    if (attempt) return fail(MX_ERR_DEVICE, "phase vocoder: record regions overflowed at full size");
+  }
 }
 }  // namespace
 
@@ -730,10 +764,6 @@ int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_ma
       }
     }
     std::lock_guard<std::mutex> plk(ctx->pv_mu);
-    PvPipe *p = nullptr;
-    rc = pv_pipe(ctx, (int64_t)F, &p);
-    if (rc) return rc;
-    pv_shard_drop(*p);
     PvRun run;
     run.a = a;
     run.plan = &plan;
@@ -744,11 +774,18 @@ int mx_pv_render_dev(mx_ctx *ctx, const mx_audio *a, int sampleRate, const mx_ma
     run.F_hi = (int64_t)F;
     run.pcm_f32 = d_pcm_f32;
     run.pcm_i16 = d_pcm_i16;
-    rc = pv_run(ctx, *p, run);
-    const hipError_t es = hipStreamSynchronize(ctx->stream);  // (the plan's host arrays die with this frame)
-    if (rc) return rc;
-    if (es != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(es));
-    return MX_OK;
+    for (int attempt = 0;; ++attempt) {
+      PvPipe *p = nullptr;
+      rc = pv_pipe(ctx, (int64_t)F, &p);
+      if (rc) return rc;
+      pv_shard_drop(*p);
+      rc = pv_run(ctx, *p, run);
+      const hipError_t es = hipStreamSynchronize(ctx->stream);  // (the plan's host arrays die with this frame)
+      if (rc) return rc;
+      if (es != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder: %s", hipGetErrorString(es));
+      if (!pv_take_overflow(ctx, *p)) return MX_OK;
+      if (attempt) return fail(MX_ERR_DEVICE, "phase vocoder: record regions overflowed at full size");
+    }
   });
 }
 
@@ -820,52 +857,59 @@ static int pv_shard_analyze_core(mx_ctx *ctx, const mx_audio *a, double semitone
   if (rc) return rc;
   std::lock_guard<std::mutex> plk(ctx->pv_mu);
   PvPipe *p = nullptr;
-  rc = pv_pipe(ctx, hi - lo + 1, &p);  // (+ the row before the range)
-  if (rc) return rc;
-  pv_shard_drop(*p);
-  const int64_t K = (int64_t)pv_chunks_of(lo, hi, p->C).size();
-  // every chunk's total map (12 KiB each), folded into the rank's behind the last analysis; a resident range has one: it is
-  // written where it stays (no allocation on the way of a rank that fits its budget)
-  uint32_t *d_sums = p->slot[0].tot_sums, *own_sums = nullptr;
-  uint16_t *d_org = p->slot[0].tot_org, *own_org = nullptr;
-  hipError_t e = hipSuccess;
-  if (K > 1) {
-    e = hipMalloc(&own_sums, (size_t)K * kPvM * 4);
-    if (e == hipSuccess) e = hipMalloc(&own_org, (size_t)K * kPvM * 2);
-    if (e != hipSuccess) {
-      hipFree(own_sums);
-      return fail(MX_ERR_NOMEM, "phase-vocoder chunk maps: %s", hipGetErrorString(e));
-    }
-    d_sums = own_sums;
-    d_org = own_org;
-  }
   PvRun run;
-  run.a = a;
-  run.r = std::pow(2.0, semitones / 12.0);
-  run.F_lo = lo;
-  run.F_hi = hi;
-  run.totals_only = true;
-  run.totmaps_sums = d_sums;
-  run.totmaps_org = d_org;
-  rc = pv_run(ctx, *p, run);
-  if (rc == MX_OK) {
-    const uint32_t *rs = d_sums;
-    const uint16_t *ro = d_org;
+  int64_t K = 1;
+  for (int attempt = 0;; ++attempt) {
+    rc = pv_pipe(ctx, hi - lo + 1, &p);  // (+ the row before the range)
+    if (rc) return rc;
+    pv_shard_drop(*p);
+    K = (int64_t)pv_chunks_of(lo, hi, p->C).size();
+    // every chunk's total map (12 KiB each), folded into the rank's behind the last analysis; a resident range has one: it is
+    // written where it stays (no allocation on the way of a rank that fits its budget)
+    uint32_t *d_sums = p->slot[0].tot_sums, *own_sums = nullptr;
+    uint16_t *d_org = p->slot[0].tot_org, *own_org = nullptr;
+    hipError_t e = hipSuccess;
     if (K > 1) {
-      e = launch_pv_compose_maps(d_sums, d_org, K, p->slot[0].tot_sums, p->slot[0].tot_org, p->ss);
-      rs = p->slot[0].tot_sums;
-      ro = p->slot[0].tot_org;
+      e = hipMalloc(&own_sums, (size_t)K * kPvM * 4);
+      if (e == hipSuccess) e = hipMalloc(&own_org, (size_t)K * kPvM * 2);
+      if (e != hipSuccess) {
+        hipFree(own_sums);
+        return fail(MX_ERR_NOMEM, "phase-vocoder chunk maps: %s", hipGetErrorString(e));
+      }
+      d_sums = own_sums;
+      d_org = own_org;
     }
-    const hipMemcpyKind kind = map_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (e == hipSuccess) e = hipMemcpyAsync(map_out, rs, kPvM * 4, kind, p->ss);
-    if (e == hipSuccess) e = hipMemcpyAsync(static_cast<char *>(map_out) + kPvM * 4, ro, kPvM * 2, kind, p->ss);
+    run = PvRun{};
+    run.a = a;
+    run.r = std::pow(2.0, semitones / 12.0);
+    run.F_lo = lo;
+    run.F_hi = hi;
+    run.totals_only = true;
+    run.totmaps_sums = d_sums;
+    run.totmaps_org = d_org;
+    rc = pv_run(ctx, *p, run);
+    if (rc == MX_OK) {
+      const uint32_t *rs = d_sums;
+      const uint16_t *ro = d_org;
+      if (K > 1) {
+        e = launch_pv_compose_maps(d_sums, d_org, K, p->slot[0].tot_sums, p->slot[0].tot_org, p->ss);
+        rs = p->slot[0].tot_sums;
+        ro = p->slot[0].tot_org;
+      }
+      const hipMemcpyKind kind = map_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+      if (e == hipSuccess) e = hipMemcpyAsync(map_out, rs, kPvM * 4, kind, p->ss);
+      if (e == hipSuccess) e = hipMemcpyAsync(static_cast<char *>(map_out) + kPvM * 4, ro, kPvM * 2, kind, p->ss);
+    }
+    const hipError_t es = hipStreamSynchronize(p->ss);
+    hipFree(own_sums);
+    hipFree(own_org);
+    if (rc) return rc;
+    if (e == hipSuccess) e = es;
+    if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (analysis): %s", hipGetErrorString(e));
+    if (!pv_take_overflow(ctx, *p)) break;
+    // (more peaks than the compact record regions hold: once more, with full-size regions)
+    if (attempt) return fail(MX_ERR_DEVICE, "phase vocoder: record regions overflowed at full size");
   }
-  const hipError_t es = hipStreamSynchronize(p->ss);
-  hipFree(own_sums);
-  hipFree(own_org);
-  if (rc) return rc;
-  if (e == hipSuccess) e = es;
-  if (e != hipSuccess) return fail(MX_ERR_DEVICE, "phase vocoder (analysis): %s", hipGetErrorString(e));
   PvPipe::Shard &j = p->job;
   j.active = true;
   j.rank = rank;
@@ -965,6 +1009,10 @@ static int pv_shard_synthesize_core(mx_ctx *ctx, const uint32_t *carry_host, con
   if (rc || e != hipSuccess) {
     pv_shard_drop(*p);
     return rc ? rc : fail(MX_ERR_DEVICE, "phase vocoder (synthesis): %s", hipGetErrorString(e));
+  }
+  if (*p->rec_overflow != 0u) {  // (a chunked range analyses again here, cut as in stage 1, which passed: cannot happen)
+    pv_shard_drop(*p);
+    return fail(MX_ERR_DEVICE, "phase vocoder (synthesis): record regions overflowed behind a stage 1 that fitted");
   }
   j.synthesized = true;
   j.head_hi = run.head_hi;

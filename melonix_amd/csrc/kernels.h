@@ -76,10 +76,18 @@ struct PvArgs {
   // continued itself, else 0; a peak that does not continue restarts (offset 0: its bins keep their analysis phases).
   float2 *xrows;       // [frames][N/2]
   uint32_t *pkmap;     // [frames][N/64] bit k: bin k is a spectral peak of the frame
-  uint32_t *pkcount;   // [frames] number of peaks (= records) of the frame
+  uint32_t *pkcount;   // [frames] bits 0..11: number of peaks (= records) of the frame; bits 12..: where they start inside the
+                       // frame's analysis workgroup's region of the record pool (below)
   float *fthr;         // [frames] the frame's activity threshold (squared magnitude): what the next frame's records compare with
-  uint2 *recs;         // [frames][N/2] the frame's records (only the first pkcount are written or read); the second sweep
-                       // REPLACES rec.y by C_f of the peak (0 = restarted): delta has no reader after it
+  uint2 *recs;         // the frames' records, in the pool; the second sweep REPLACES rec.y by C_f of
+                       // the peak (0 = restarted): delta has no reader after it.  Every analysis workgroup (frames_per_block
+                       // consecutive frames) packs its frames' records one behind the other into a region of rec_wg_cap entries
+                       // of its own (no atomics: the layout is a function of the signal).  A region that does not hold its
+                       // frames (rec_wg_cap < frames_per_block * N/2 is a bet on the signal: an impulse makes every bin a peak)
+                       // raises *rec_overflow: the caller discards the run and repeats it with full-sized regions
+  uint32_t rec_wg_cap; // records per analysis workgroup's region
+  int rec_fpb_shift;   // log2(frames_per_block of the analysis launch): local frame f lies in region f >> rec_fpb_shift
+  uint32_t *rec_overflow;  // [1] set to 1 by an analysis workgroup whose region is too small (the run's results are void)
   uint32_t *chunk_sums;  // [ceil(frames/scan_chunk)][N/2] a chunk's composed map: delta (or restart value) ...
   uint16_t *chunk_org;   // ... and source bin at the chunk's start (0xFFFF: restart); then the chunk-start offsets
   uint32_t *group_sums;  // [ceil(chunks/32)][N/2] the same for groups of 32 chunks (the composition is two-level)

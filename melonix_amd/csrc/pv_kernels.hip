@@ -19,7 +19,8 @@
 // Stages:
 //   pv_analysis   one workgroup walks consecutive frames: Hann-windowed frame at a_f -> the LDS-resident real FFT of
 //                 stft_core.h -> X/N, rows [F][N/2] complex; the frame's peaks (active, not below rho times any of its
-//                 four neighbours) as a 2048-bit map and, compacted in bin order, one record per peak:
+//                 four neighbours) as a 2048-bit map and, compacted in bin order (a workgroup's frames one behind the other in its
+//                 region of the record pool; pkcount[f] = count | place), one record per peak:
 //                 (bin p, owner q of bin p in the PREVIOUS frame's peak map, continues?, delta) with
 //                 delta = P_{f-1}[p] + inc_f[p] - P_f[p] — made one frame later from the two rows in HBM/L2 (the gathers
 //                 travel under the next frame's transform)
@@ -63,6 +64,15 @@ constexpr int kPvReach = 32;             // a peak owns bins at most this far aw
 constexpr float kPvPeakMargin2 = 0.9990234375f * 0.9990234375f;
 constexpr uint16_t kPvNoBin = 0xFFFF;    // owner / origin: none
 constexpr uint32_t kRecQValid = 1u << 22, kRecCont = 1u << 23;
+// pkcount[f] packs the frame's peak count (bits 0..11: 0..2048) and where its records start INSIDE its analysis workgroup's
+// region of the record pool (bits 12..: below 16 x 2048): one word per frame tells a reader how many records and where.
+constexpr int kPkOffShift = 12;
+constexpr uint32_t kPkCountMask = (1u << kPkOffShift) - 1u;
+// first record of local frame f: its analysis workgroup's region ((f >> rec_fpb_shift) regions of rec_wg_cap entries in front)
+// + the frame's offset inside it
+__device__ __forceinline__ uint32_t pv_rec_start(const PvArgs &a, int64_t f, uint32_t info) {
+  return (uint32_t)(f >> a.rec_fpb_shift) * a.rec_wg_cap + (info >> kPkOffShift);
+}
 static_assert(kPlan4096E == 16, "pv kernels use the 16-points-per-thread tables of N = 4096");
 static_assert(t1_size<PV>() == kPvM, "the FFT image of this plan is exactly one spectrum (XOR layout, no padding)");
 
@@ -198,6 +208,10 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   const int64_t f0 = (int64_t)lb * a.frames_per_block;
   const int64_t f1 = f0 + a.frames_per_block < a.frames ? f0 + a.frames_per_block : a.frames;
   if (f0 >= f1) return;
+  // this workgroup's region of the record pool: its frames' records one behind the other, the first frame's (pv_heads writes
+  // them) in front.  rec_run: records of the frames before the one whose offset is being fixed.
+  uint2 *const rec_base = a.recs + (size_t)lb * a.rec_wg_cap;
+  uint32_t rec_run = 0u;
   // The records of the workgroup's FIRST frame need the previous workgroup's last row, peak map and threshold: pv_heads
   // makes them, behind this kernel (a warm-up transform of frame f0 - 1 in front of every sixteen frames was 6 % of the
   // kernel's time and 0.8 GB of duplicate rows).
@@ -231,6 +245,16 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     pass1<P>(Y, v);
     __syncthreads();  // every wave is past the previous frame's peak numbering: plist and npk are complete
     if (pend) pend_cnt = (int)npk;
+    // where frame f - 1's records start (f > f0; npk is its count — also for the workgroup's first frame, whose records
+    // pv_heads writes): behind those of the frames before it.  A region that does not hold them voids the run.
+    uint32_t rec_off = 0u;
+    bool rec_fits = true;
+    if (f > f0) {
+      const uint32_t c1 = npk;
+      rec_off = rec_run;
+      rec_fits = rec_off + c1 <= a.rec_wg_cap;
+      rec_run += c1;
+    }
     // the pending frame's (f - 1) first record per thread: its spectrum and the one before at the peak, from their rows
     float2 ga = make_float2(0.f, 0.f), gb = make_float2(0.f, 0.f);
     int gp = 0;
@@ -331,8 +355,8 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
     __syncthreads();  // this frame's peak map is complete
     // the pending frame's records (one per thread from the registers; a frame with more peaks than threads gathers the
     // rest here): the second wavefront's lanes first — the first one has this frame's peaks to number
-    if (pend) {
-      uint2 *rrow = a.recs + (size_t)(f - 1) * P::M;
+    if (pend && rec_fits) {
+      uint2 *rrow = rec_base + rec_off;
       const float2 *xa = a.xrows + (size_t)(f - 1) * P::M, *xb = a.xrows + (size_t)(f >= 2 ? f - 2 : 0) * P::M;
       for (int i = ti; i < pend_cnt; i += P::T) {
         if (i != ti) {
@@ -350,7 +374,13 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
       const int inc = pv_number_peaks(w, t, plist[f & 1]);
       if (t == 63) npk = (uint32_t)inc;
       a.pkmap[(size_t)f * W + t] = w;
-      if (t == 63) a.pkcount[f] = (uint32_t)inc;
+      if (t == 63) {
+        // count and place of this frame's records (rec_run: the records of the workgroup's frames before it); a frame that
+        // does not fit its region is placed at the region's front — in bounds — and voids the run
+        const bool fits = rec_run + (uint32_t)inc <= a.rec_wg_cap;
+        a.pkcount[f] = (uint32_t)inc | ((fits ? rec_run : 0u) << kPkOffShift);
+        if (!fits) *a.rec_overflow = 1u;
+      }
     }
     pend = f > f0;  // (the first frame's records are pv_heads')
     thr2_2 = thr2_1;
@@ -361,10 +391,11 @@ __global__ __launch_bounds__(PV::T) void pv_analysis(const PvArgs a) {
   __syncthreads();
   pend_cnt = (int)npk;
   // the last frame's records: no next transform to hide the gathers under (a one-frame workgroup's are pv_heads')
-  if (f1 - 1 > f0) {
+  const bool last_fits = rec_run + (uint32_t)pend_cnt <= a.rec_wg_cap;
+  if (f1 - 1 > f0 && last_fits) {
     const int64_t fl = f1 - 1;
     const int m1 = m0 == 0 ? 2 : m0 - 1, m2 = m1 == 0 ? 2 : m1 - 1;  // m1: frame fl's map, m2: frame fl - 1's
-    uint2 *rrow = a.recs + (size_t)fl * P::M;
+    uint2 *rrow = rec_base + rec_run;
     const float2 *xa = a.xrows + (size_t)fl * P::M, *xb = a.xrows + (size_t)(fl >= 1 ? fl - 1 : 0) * P::M;
     const uint32_t lh = a.hop[fl];
     const double lhr = a.hratio[fl];
@@ -402,7 +433,7 @@ __global__ __launch_bounds__(PV::T) void pv_heads(const PvArgs a) {
   const uint32_t h = a.hop[f];
   const double hr = a.hratio[f];
   const float thrq = f >= 1 ? a.fthr[f - 1] : 0.f;
-  uint2 *rrow = a.recs + (size_t)f * P::M;
+  uint2 *rrow = a.recs + pv_rec_start(a, f, a.pkcount[f]);  // (the front of its analysis workgroup's region)
   const float2 *xa = a.xrows + (size_t)f * P::M, *xb = a.xrows + (size_t)(f >= 1 ? f - 1 : 0) * P::M;
   for (int i = t; i < cnt; i += P::T) {
     const int p = plist[i];
@@ -444,34 +475,50 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
   constexpr int kAhead = 4;
   uint32_t cn[kAhead];
   uint2 rn[kAhead];
+  // (a row's count and the place of its records are one word, pkcount[row]: the words run one block further ahead than the
+  // records they address — iq: those of the block in rn, in_: those of the block behind it — so a record load never waits
+  // for its address)
+  uint32_t iq[kAhead], in_[kAhead];
   // (unconditional loads — a row past the chunk reads the chunk's last row again, a thread past the row's count reads an
   // entry nobody wrote: neither is used — so that the compiler can count them: behind a branch every wait becomes vmcnt(0)
   // and the ring hides nothing)
-  auto request = [&](int64_t rr, uint32_t &cnt_, uint2 &rec_) {
+  auto info_of = [&](int64_t rr) { return a.pkcount[rr < r1 ? rr : r1 - 1]; };
+  auto request = [&](int64_t rr, uint32_t info, uint32_t &cnt_, uint2 &rec_) {
     const int64_t rq = rr < r1 ? rr : r1 - 1;
-    cnt_ = rr < r1 ? a.pkcount[rq] : 0u;
-    rec_ = a.recs[(size_t)rq * kPvM + t];
+    cnt_ = rr < r1 ? (info & kPkCountMask) : 0u;
+    rec_ = a.recs[(size_t)pv_rec_start(a, rq, info) + t];
   };
 #pragma unroll
-  for (int j = 0; j < kAhead; ++j) request(r0 + j, cn[j], rn[j]);
+  for (int j = 0; j < kAhead; ++j) {
+    iq[j] = info_of(r0 + j);
+    in_[j] = info_of(r0 + kAhead + j);
+  }
+#pragma unroll
+  for (int j = 0; j < kAhead; ++j) request(r0 + j, iq[j], cn[j], rn[j]);
   __syncthreads();
   for (int64_t rb = r0; rb < r1; rb += kAhead) {
-    uint32_t cc[kAhead];
+    uint32_t cc[kAhead], ic[kAhead];
     uint2 rc[kAhead];
 #pragma unroll
     for (int j = 0; j < kAhead; ++j) {
       cc[j] = cn[j];
       rc[j] = rn[j];
+      ic[j] = iq[j];
     }
 #pragma unroll
-    for (int j = 0; j < kAhead; ++j) request(rb + kAhead + j, cn[j], rn[j]);
+    for (int j = 0; j < kAhead; ++j) {
+      iq[j] = in_[j];
+      request(rb + kAhead + j, iq[j], cn[j], rn[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) in_[j] = info_of(rb + 2 * kAhead + j);
 #pragma unroll
     for (int j = 0; j < kAhead; ++j) {
       const int64_t r = rb + j;
       if (r >= r1) break;  // (block-uniform)
       const int cnt = (int)cc[j];
       uint2 rec = rc[j];
-      uint2 *rrow = a.recs + (size_t)r * kPvM;
+      uint2 *rrow = a.recs + pv_rec_start(a, r, ic[j]);
       const int cp = cw == 0 ? 2 : cw - 1, cx = cw == 2 ? 0 : cw + 1;
       if (t < W) CM[cx][t] = 0u;  // (last read during the previous row, before the barrier that ended it)
       for (int i = t; i < cnt; i += kLockT) {
@@ -654,9 +701,11 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   // G = 2^lg lanes (as many as the frame's peak count leaves: a sweep's handful of peaks are 65-bin intervals, music's
   // hundreds are short).  The first round's records arrive as arguments (requested a frame earlier).
   auto lanes_per_peak = [](int cnt) { return cnt <= 8 ? 4 : cnt <= 16 ? 3 : cnt <= 32 ? 2 : cnt <= 64 ? 1 : 0; };
-  auto fill_cd = [&](int64_t fr, int cnt, int tt, uint32_t r_i, uint32_t cv, uint32_t r_m, uint32_t r_n) {
+  // (`info`: the frame's pkcount word — its peak count and where its records start)
+  auto fill_cd = [&](int64_t fr, uint32_t info, int tt, uint32_t r_i, uint32_t cv, uint32_t r_m, uint32_t r_n) {
+    const int cnt = (int)(info & kPkCountMask);
     const int lg = lanes_per_peak(cnt), G = 1 << lg, sub = tt & (G - 1);
-    const uint2 *rrow = a.recs + (size_t)fr * P::M;
+    const uint2 *rrow = a.recs + pv_rec_start(a, fr, info);
     bool first = true;
     for (int i = tt >> lg; i < cnt; i += P::T >> lg) {
       if (!first) {
@@ -680,11 +729,12 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   };
   // (a peak's record, its offset and its neighbours' records — their bins bound its interval —: all requested a frame ahead;
   // read when the interval is written they were L2 round trips in front of a barrier the other wavefront was waiting at)
-  auto fetch_fill = [&](int64_t fr, int cnt, int tt, uint32_t &r_i, uint32_t &cv, uint32_t &r_m, uint32_t &r_n) {
+  auto fetch_fill = [&](int64_t fr, uint32_t info, int tt, uint32_t &r_i, uint32_t &cv, uint32_t &r_m, uint32_t &r_n) {
+    const int cnt = (int)(info & kPkCountMask);
     const int i = tt >> lanes_per_peak(cnt);
     r_i = cv = r_m = r_n = 0u;
     if (i < cnt) {
-      const uint2 *rrow = a.recs + (size_t)fr * P::M;
+      const uint2 *rrow = a.recs + pv_rec_start(a, fr, info);
       const uint2 rc = rrow[i];
       r_i = rc.x;
       cv = rc.y;
@@ -729,14 +779,14 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   // an s_waitcnt vmcnt(0) at the top of every frame)
   int lane0;
   asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
-  int cnt1 = 0, cnt2 = 0;
+  uint32_t cnt1 = 0u, cnt2 = 0u;  // (the pkcount words of frames f + 1, f + 2)
   if (f0 < f1) {
     request_row(f0, t_);
     zero_cd(t_);
     uint32_t r_i, cv, r_m, r_n;
-    const int cnt0 = (int)a.pkcount[f0];
+    const uint32_t cnt0 = a.pkcount[f0];
     fetch_fill(f0, cnt0, t_, r_i, cv, r_m, r_n);
-    cnt1 = f0 + 1 < f1 ? (int)a.pkcount[f0 + 1 + lane0] : 0;
+    cnt1 = f0 + 1 < f1 ? a.pkcount[f0 + 1 + lane0] : 0u;
     __syncthreads();
     fill_cd(f0, cnt0, t_, r_i, cv, r_m, r_n);
     row_landed();
@@ -768,7 +818,7 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // the next frame's first round of records (its count came a frame ago) and the count of the frame after it
     uint32_t nr_i, ncv, nr_m, nr_n;
     fetch_fill(f + 1 < f1 ? f + 1 : f, cnt1, t, nr_i, ncv, nr_m, nr_n);
-    cnt2 = f + 2 < f1 ? (int)a.pkcount[f + 2 + lane0] : 0;
+    cnt2 = f + 2 < f1 ? a.pkcount[f + 2 + lane0] : 0u;
     cpx Y[P::E], v[P::E];
     // This thread's 2 x 16 bins of the frame: c = t + T e and its mirror M - c (bin M, thread 0's mirror of c = 0, is the
     // dropped Nyquist bin: the read is clamped and the coefficient zeroed), and their offsets

@@ -357,7 +357,7 @@ def test_shards_of_circular_window_kernels_equal_unsharded(N, hop, world, hours)
 
 def test_pv_hour_is_bit_for_bit_what_the_single_launch_gave():
     """The hour of the bench workload at +3 st under every arena policy — the default budget (a quarter of the free memory: the
-    hour is RESIDENT, one chunk, 27.8 GB), budgets of 8 and 2.4 GB (chunks of ~59 k and ~17 k frames) and an explicit chunk
+    hour is RESIDENT, one chunk, 17.9 GB), budgets of 8 and 2.4 GB (chunks of ~179 k and ~52 k frames) and an explicit chunk
     length of 8192 frames: the output's sha1s are the ones round 4's single launch over a 33 GB arena produced
     (`profiles/variants_r04_pv_steps.log`), f32 and int16.  (A sha1 pinned to this build's own earlier output: the vocoder is
     build-defined — its oracle comparison is on seconds-long signals, tests/test_pv.py.)"""
@@ -367,7 +367,7 @@ def test_pv_hour_is_bit_for_bit_what_the_single_launch_gave():
     import sys
 
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pv_ab.py")
-    for var, val, chunks in (("", "", 1), ("MELONIX_PV_ARENA_MB", "8192", 7), ("MELONIX_PV_ARENA_MB", "2400", 24), ("MELONIX_PV_CHUNK_FRAMES", "8192", 98)):
+    for var, val, chunks in (("", "", 1), ("MELONIX_PV_ARENA_MB", "8192", 5), ("MELONIX_PV_ARENA_MB", "2400", 16), ("MELONIX_PV_CHUNK_FRAMES", "8192", 98)):
         env = dict(os.environ)
         for k in ("MX_AB_LIB", "MELONIX_PV_CHUNK_FRAMES", "MELONIX_PV_ARENA_MB"):
             env.pop(k, None)

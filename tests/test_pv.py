@@ -285,8 +285,8 @@ def test_gpu_arena_follows_its_budget(gpu_ctx):
         whole_f, whole_i = gpu_ctx.pv_pitch_shift(a, 3.0)
         b_res = gpu_ctx.pv_arena_bytes()
         assert gpu_ctx.pv_last_chunks() == 1
-        # resident: one slot, ~34 KiB per frame (+ the constants and one chunk map per 64 frames)
-        assert 33.0 * 1024 * frames < b_res < 37.0 * 1024 * (frames + 64)
+        # resident: one slot, ~22 KiB per frame (rows 16, compact records 4, stretched signal, maps; + the constants)
+        assert 21.0 * 1024 * frames < b_res < 24.0 * 1024 * (frames + 64)
         assert gpu_ctx.pv_arena_budget() == auto  # taken once
         # a shorter call is served by the arena that is there
         s = gpu_ctx.upload(w[: 2 * SR])
@@ -294,22 +294,22 @@ def test_gpu_arena_follows_its_budget(gpu_ctx):
         assert gpu_ctx.pv_arena_bytes() == b_res and gpu_ctx.pv_last_chunks() == 1
         s.free()
         # a budget the call does not fit: chunks, inside the budget, same samples; the arena above the new budget went back at once
-        for budget in (96 << 20, 64 << 20, 41 << 20):
+        for budget in (80 << 20, 56 << 20, 36 << 20):
             gpu_ctx.pv_set_arena_budget(budget)
             assert gpu_ctx.pv_arena_bytes() == 0 or gpu_ctx.pv_arena_bytes() <= budget
             f, i = gpu_ctx.pv_pitch_shift(a, 3.0)
             assert 0 < gpu_ctx.pv_arena_bytes() <= budget and gpu_ctx.pv_arena_budget() == budget
             assert gpu_ctx.pv_last_chunks() >= 3, (budget, gpu_ctx.pv_last_chunks())
             assert np.array_equal(f.view(np.uint32), whole_f.view(np.uint32)) and np.array_equal(i, whole_i), budget
-        # a budget below the smallest chunks (two slots of 32 frames: 4.8 MiB): refused with the sizes in the message, nothing allocated
-        gpu_ctx.pv_set_arena_budget(4 << 20)
+        # a budget below the smallest chunks (two slots of 32 frames: 3.5 MiB): refused with the sizes in the message, nothing allocated
+        gpu_ctx.pv_set_arena_budget(3 << 20)
         with pytest.raises(mx.MxError) as err:
             gpu_ctx.pv_pitch_shift(a, 3.0, want_i16=False)
         assert err.value.code == -3 and "MiB" in str(err.value) and gpu_ctx.pv_arena_bytes() == 0
-        # ... unless the call is short enough to be resident inside it (57 frames: 3.4 MiB)
+        # ... unless the call is short enough to be resident inside it (57 frames: 2.4 MiB)
         s = gpu_ctx.upload(w[:12000])
         y, _ = gpu_ctx.pv_pitch_shift(s, 3.0, want_i16=False)
-        assert len(y) == 12000 and gpu_ctx.pv_last_chunks() == 1 and gpu_ctx.pv_arena_bytes() <= 4 << 20
+        assert len(y) == 12000 and gpu_ctx.pv_last_chunks() == 1 and gpu_ctx.pv_arena_bytes() <= 3 << 20
         s.free()
         # the explicit chunk length overrides the budget (two slots of exactly that many frames)
         gpu_ctx.pv_set_arena_budget(0)
@@ -356,7 +356,60 @@ def test_gpu_arena_follows_its_budget(gpu_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,budget_mb", [(2, 0), (3, 0), (4, 16), (2, 41)])
+def test_gpu_compact_records_and_their_overflow(gpu_ctx, monkeypatch):
+    """The peak records are packed: an analysis workgroup's frames one behind the other in a region of 512 entries per frame (a
+    quarter of a frame's worst case), recoff[f] says where — 22 instead of 34 KiB per frame of arena.  A signal with more peaks
+    than that (an impulse train makes every bin a peak; white noise a third of them) raises the overflow flag: the call
+    repeats itself once on full-size regions and the context stays with those until its scratch is released.  Outputs are
+    those of a context laid out with full regions from the start (MELONIX_PV_FULL_RECORDS=1), bit for bit, either way."""
+    import melonix_amd as mx
+    rng = np.random.default_rng(11)
+    n = 6 * SR
+    sig = _chunk_signals()
+    signals = {"sweep": sig["sweep"], "impulses": sig["impulses"], "white": (0.3 * rng.uniform(-1, 1, n)).astype(np.float32),
+               "sweep+burst": np.concatenate([sig["sweep"][:SR], sig["impulses"][:SR // 2], sig["sweep"][:SR]])}
+    full = mx.Context(0)
+    compact = mx.Context(0)
+    try:
+        for name, w in signals.items():
+            frames = int(np.ceil(len(w) * 2.0 ** (3 / 12.0) / 256)) + 1
+            monkeypatch.setenv("MELONIX_PV_FULL_RECORDS", "1")
+            a = full.upload(w)
+            ref_f, ref_i = full.pv_pitch_shift(a, 3.0)
+            full_bytes = full.pv_arena_bytes()
+            a.free()
+            monkeypatch.delenv("MELONIX_PV_FULL_RECORDS")
+            compact.release_scratch()  # (back to compact regions, whatever the previous signal did)
+            a = compact.upload(w)
+            f, i = compact.pv_pitch_shift(a, 3.0)
+            assert np.array_equal(f.view(np.uint32), ref_f.view(np.uint32)) and np.array_equal(i, ref_i), name
+            b = compact.pv_arena_bytes()
+            if name == "sweep":
+                assert b < 0.7 * full_bytes and b < 24.0 * 1024 * (frames + 64)   # compact regions held
+            else:
+                assert b == full_bytes, (name, b, full_bytes)                      # overflowed: the arena is the full one now
+            # the context stays on full regions: a second call does not overflow again (same arena, same samples) ...
+            f2, _ = compact.pv_pitch_shift(a, 3.0, want_i16=False)
+            assert np.array_equal(f2.view(np.uint32), ref_f.view(np.uint32)) and compact.pv_arena_bytes() == b
+            # ... chunked too (the retry happens inside a pipelined run as well), and as ranks
+            compact.release_scratch()
+            compact.pv_set_chunk_frames(96)
+            f3, _ = compact.pv_pitch_shift(a, 3.0, want_i16=False)
+            assert np.array_equal(f3.view(np.uint32), ref_f.view(np.uint32)), name
+            compact.pv_set_chunk_frames(0)
+            compact.release_scratch()
+            sums, org = compact.pv_shard_analyze(a, 3.0, 0, 2)
+            head, tail = compact.pv_shard_synthesize(None)
+            _, _, lo, hi = mx.pv_shard_frames(len(w), 3.0, 0, 2)
+            a.free()
+            assert (org == 0xFFFF).all() and not head.any() and hi - lo > 0
+    finally:
+        full.close()
+        compact.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,budget_mb", [(2, 0), (3, 0), (4, 12), (2, 24)])
 def test_gpu_sharded_on_device_equals_whole(gpu_ctx, world, budget_mb):
     """The _dev form of the three stages, `world` contexts playing the ranks on one device: every stage writes its entry of
     the next all-gather's buffer and reads the previous one's as gathered (here: the entries concatenated by hand); the carry
@@ -387,7 +440,7 @@ def test_gpu_sharded_on_device_equals_whole(gpu_ctx, world, budget_mb):
                 c.pv_shard_analyze_dev(x, st, r, world, maps.ptr + r * sh.PV_MAP_BYTES)
                 if budget_mb == 0:
                     assert c.pv_last_chunks() == 1, (r, c.pv_last_chunks())
-                else:  # (at +3 st the ranges are beyond these budgets: 4 chunks of 192 frames / 3 of ~570)
+                else:  # (at +3 st the ranges are beyond these budgets: chunks of ~220 / ~480 frames)
                     assert c.pv_arena_bytes() <= budget_mb << 20 and (c.pv_last_chunks() >= 3 or st < 0), (r, c.pv_last_chunks())
             # the maps as the host form returns them, and the carry folded on the device = shard.pv_fold_carry (through the outputs)
             m = maps.read().reshape(world, sh.PV_MAP_BYTES)
