@@ -282,18 +282,21 @@ int mx_pv_pitch_shift(mx_ctx *ctx, const mx_audio *a, double semitones, float *p
  *            else a quarter of what hipMemGetInfo reports free when the context first needs an arena (taken once, kept
  *            until mx_ctx_release_scratch).  mx_pv_arena_budget: the budget in force.  An arena above a newly set budget
  *            is given back at once.
- *   resident a call whose frames fit the budget (34 KiB per frame: spectra 16 KiB, peak records 16 KiB, the stretched
- *            signal, maps and plan rows; 27.5 GB for an hour at +3 semitones) is ONE chunk: analysis, phase recurrence
- *            and synthesis each run once over the whole call, and a rank of a multi-GPU run (below) analyses its frames
- *            once.
+ *   resident a call whose frames fit the budget (22 KiB per frame: spectra 16 KiB, peak records 4 KiB, the stretched signal,
+ *            maps and plan rows; 17.9 GB for an hour at +3 semitones) is ONE chunk: analysis, phase recurrence and synthesis
+ *            each run once over the whole call, and a rank of a multi-GPU run (below) analyses its frames once.
  *   chunked  what does not fit (8 h on one GPU) is walked in chunks — the longest multiple of 32 frames of which two
- *            slots of spectra + records and a ring of four stretched-signal buffers (70.6 KiB per frame of a chunk) fit
+ *            slots of spectra + records and a ring of four stretched-signal buffers (47 KiB per frame of a chunk) fit
  *            the budget.  Chunks meet on multiples of 32 frames — the synthesis workgroups — and hand each other the
  *            phase row and the overlap-add seam the way the ranks of a multi-GPU run do: the output is bit-identical
  *            whatever the chunk length, resident included.  While a chunked call runs, two internal streams carry the
  *            phase recurrence and the fix-up / resampling beside the transforms; both are joined before the call returns.
+ *   records  the peak records are packed (room for 512 peaks per frame on average over an analysis workgroup's 8 or 16
+ *            frames; a frame can have 2048).  A signal with more (an impulse train) makes the call repeat itself once,
+ *            transparently, on an arena with full-size record regions (34 / 71 KiB per frame), which the context then keeps
+ *            until mx_ctx_release_scratch; the samples are the same either way.  MELONIX_PV_FULL_RECORDS=1 starts there.
  *   MX_ERR_NOMEM (checked against hipMemGetInfo before allocating) if the device cannot give the arena, or if the
- *            budget is below what the smallest chunks need (two slots of 32 frames: 4.8 MiB).
+ *            budget is below what the smallest chunks need (two slots of 32 frames: 3.5 MiB).
  * mx_pv_set_chunk_frames(frames > 0) overrides the policy with two-slot chunks of exactly that length (rounded up to a
  * multiple of 32; 0 = back to the budget; the environment variable MELONIX_PV_CHUNK_FRAMES likewise): a test that wants
  * many chunk boundaries in a short signal.  mx_pv_arena_bytes: what the context holds right now (0 before the first

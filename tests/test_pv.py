@@ -325,17 +325,17 @@ def test_gpu_arena_follows_its_budget(gpu_ctx):
         with pytest.raises(mx.MxError):
             gpu_ctx.pv_set_arena_budget(-1)
         # an arena the device cannot give is refused before anything is allocated — MX_ERR_NOMEM, sizes in the message — and the
-        # context goes on working afterwards: chunks of 4 M frames want 305 GB; an empty MI355X has 288 GiB = 309 GB, so a
-        # ballast sized from what is free leaves less than that (skipped if the device is too crowded for the ballast itself)
+        # context goes on working afterwards: chunks of 4 M frames want 202 GB (305 with full-size record regions); an empty MI355X
+        # has 288 GiB = 309 GB, so a ballast sized from what is free leaves 150 GB (skipped if the ballast itself cannot be had)
         from conftest import DevBuf
         free_now, _ = _free_device_bytes()
         ballast = None
-        if free_now > 300e9:
+        if free_now > 170e9:
             try:
-                ballast = DevBuf(int(free_now - 280e9))
+                ballast = DevBuf(int(free_now - 150e9))
             except AssertionError:
                 ballast = None
-        if ballast is not None or free_now <= 300e9:
+        if ballast is not None or free_now <= 170e9:
             gpu_ctx.pv_set_chunk_frames(1 << 22)
             try:
                 with pytest.raises(mx.MxError) as err:
@@ -359,7 +359,7 @@ def test_gpu_arena_follows_its_budget(gpu_ctx):
 def test_gpu_compact_records_and_their_overflow(gpu_ctx, monkeypatch):
     """The peak records are packed: an analysis workgroup's frames one behind the other in a region of 512 entries per frame (a
     quarter of a frame's worst case), recoff[f] says where — 22 instead of 34 KiB per frame of arena.  A signal with more peaks
-    than that (an impulse train makes every bin a peak; white noise a third of them) raises the overflow flag: the call
+    than that (an impulse train makes every bin a peak) raises the overflow flag: the call
     repeats itself once on full-size regions and the context stays with those until its scratch is released.  Outputs are
     those of a context laid out with full regions from the start (MELONIX_PV_FULL_RECORDS=1), bit for bit, either way."""
     import melonix_amd as mx
@@ -386,6 +386,9 @@ def test_gpu_compact_records_and_their_overflow(gpu_ctx, monkeypatch):
             b = compact.pv_arena_bytes()
             if name == "sweep":
                 assert b < 0.7 * full_bytes and b < 24.0 * 1024 * (frames + 64)   # compact regions held
+            elif name == "white":
+                # (a local maximum over five bins: ~410 peaks per frame of white noise — inside the 512 a frame has on average)
+                assert b == full_bytes or b < 0.7 * full_bytes, (name, b, full_bytes)
             else:
                 assert b == full_bytes, (name, b, full_bytes)                      # overflowed: the arena is the full one now
             # the context stays on full regions: a second call does not overflow again (same arena, same samples) ...
