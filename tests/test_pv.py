@@ -374,6 +374,7 @@ def test_gpu_compact_records_and_their_overflow(gpu_ctx, monkeypatch):
         for name, w in signals.items():
             frames = int(np.ceil(len(w) * 2.0 ** (3 / 12.0) / 256)) + 1
             monkeypatch.setenv("MELONIX_PV_FULL_RECORDS", "1")
+            full.release_scratch()  # (an arena sized for THIS signal: a context keeps a bigger one it already has)
             a = full.upload(w)
             ref_f, ref_i = full.pv_pitch_shift(a, 3.0)
             full_bytes = full.pv_arena_bytes()
