@@ -3,13 +3,16 @@
 #   /usr/local/graft/bin/gpurun --timeout 2700 -- 'bash tools/run_gpu_batch.sh'
 set -u
 mkdir -p gpurun_out
-MX_FAULT_LOG=gpurun_out/fault_sweep_r06_device.log MX_RCCL_LOG=gpurun_out/rccl_r06.log timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -5
-bash tools/profile_pv.sh r06 sweep 2>&1 | tail -24
+for pass in 1 2; do
+  MX_FAULT_LOG=gpurun_out/fault_sweep_r06_device.log MX_RCCL_LOG=gpurun_out/rccl_r06.log timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/gpu_suite_pass$pass.log
+  tail -3 gpurun_out/gpu_suite_pass$pass.log
+done
+bash tools/profile_gpu.sh r06 > gpurun_out/profile_r06.log 2>&1; tail -14 gpurun_out/prof_r06_summary.txt
 python bench.py > gpurun_out/bench_check.json 2> gpurun_out/bench_check.err
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/bench_check.json"))
 pv = d["phase_vocoder_supplementary"]
-print({k: d[k] for k in ("value", "ms_per_step", "outputs_ok", "library_src_sha")}, d["roofline"]["frac"], pv["call_ms"], pv["arena_bytes"], pv["chunks"], d.get("gpu_over_cpu_step"))
+print({k: d[k] for k in ("value", "ms_per_step", "outputs_ok", "library_src_sha")}, d["roofline"]["frac"], d["roofline"]["traffic"], pv["call_ms"], pv["arena_bytes"], pv["chunks"], d.get("gpu_over_cpu_step"))
 PY
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
