@@ -70,8 +70,9 @@ constexpr int kPkOffShift = 12;
 constexpr uint32_t kPkCountMask = (1u << kPkOffShift) - 1u;
 // first record of local frame f: its analysis workgroup's region ((f >> rec_fpb_shift) regions of rec_wg_cap entries in front)
 // + the frame's offset inside it
-__device__ __forceinline__ uint32_t pv_rec_start(const PvArgs &a, int64_t f, uint32_t info) {
-  return (uint32_t)(f >> a.rec_fpb_shift) * a.rec_wg_cap + (info >> kPkOffShift);
+// (64-bit: 4 M frames of full-size regions are 8.6e9 entries)
+__device__ __forceinline__ size_t pv_rec_start(const PvArgs &a, int64_t f, uint32_t info) {
+  return (size_t)(f >> a.rec_fpb_shift) * a.rec_wg_cap + (info >> kPkOffShift);
 }
 static_assert(kPlan4096E == 16, "pv kernels use the 16-points-per-thread tables of N = 4096");
 static_assert(t1_size<PV>() == kPvM, "the FFT image of this plan is exactly one spectrum (XOR layout, no padding)");
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(kLockT) void pv_lock_walk(const PvArgs a) {
   auto request = [&](int64_t rr, uint32_t info, uint32_t &cnt_, uint2 &rec_) {
     const int64_t rq = rr < r1 ? rr : r1 - 1;
     cnt_ = rr < r1 ? (info & kPkCountMask) : 0u;
-    rec_ = a.recs[(size_t)pv_rec_start(a, rq, info) + t];
+    rec_ = a.recs[pv_rec_start(a, rq, info) + t];
   };
 #pragma unroll
   for (int j = 0; j < kAhead; ++j) {

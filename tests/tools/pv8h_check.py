@@ -60,6 +60,18 @@ ctx.pv_pitch_shift_dev(audio, st, None, small.data_ptr())
 print(f"   ... through a 2.4 GB budget: {ctx.pv_last_chunks()} chunks, arena {ctx.pv_arena_bytes() / 1e9:.3f} GB, call ms {t_small:.1f} (arena built in it); "
       f"int16 {'equal' if torch.equal(small, i16) else 'DIFFERS'}", flush=True)
 assert torch.equal(small, i16) and ctx.pv_arena_bytes() <= 2400 << 20
+# ... and RESIDENT (a budget that holds all 6.4 M frames in one chunk: 141 GB, more than the default quarter allows): same samples
+if hours >= 2 and free2 > 190e9:
+    ctx.pv_set_arena_budget(170 << 30)
+    ctx.pv_pitch_shift_dev(audio, st, None, small.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.pv_pitch_shift_dev(audio, st, None, small.data_ptr())
+    torch.cuda.synchronize()
+    t_res = (time.perf_counter() - t0) * 1e3
+    print(f"   ... resident under a 170 GiB budget: {ctx.pv_last_chunks()} chunk, arena {ctx.pv_arena_bytes() / 1e9:.1f} GB, call ms {t_res:.1f}; "
+          f"int16 {'equal' if torch.equal(small, i16) else 'DIFFERS'}", flush=True)
+    assert ctx.pv_last_chunks() == 1 and torch.equal(small, i16)
 del small
 ctx.pv_set_arena_budget(0)
 ctx.release_scratch()
