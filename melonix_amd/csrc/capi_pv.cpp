@@ -295,28 +295,31 @@ int pv_pipe(mx_ctx *ctx, int64_t frames, PvPipe **out) {
     e = hipStreamCreateWithFlags(&q.ss, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&q.sf, hipStreamNonBlocking);
   }
-  std::vector<hipEvent_t *> evs = {&q.ev_begin, &q.ev_fin};
-  for (int i = 0; i < kPvSlots; ++i) {
-    evs.push_back(&q.ev_an[i]);
-    evs.push_back(&q.ev_lock[i]);
-    evs.push_back(&q.ev_syn[i]);
-  }
+  hipEvent_t *const evs[] = {&q.ev_begin,  &q.ev_fin,     &q.ev_an[0],  &q.ev_an[1],
+                             &q.ev_lock[0], &q.ev_lock[1], &q.ev_syn[0], &q.ev_syn[1]};
+  static_assert(kPvSlots == 2, "the event list above names both slots");
   for (hipEvent_t *ev : evs)
     if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
-  // the constants
-  std::vector<float> hann((size_t)kPvN), hann_sc((size_t)kPvN);
-  for (int j = 0; j < kPvN; ++j) {
-    hann[(size_t)j] = (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * j / kPvN));
-    hann_sc[(size_t)j] = hann[(size_t)j] * fold_scale(kPvN);  // exact: a power of two
+  // the constants (host tables on the way: a failed allocation must not leave a half-built pipe behind — the next call would
+  // find an arena of the wanted shape and use it)
+  try {
+    std::vector<float> hann((size_t)kPvN), hann_sc((size_t)kPvN);
+    for (int j = 0; j < kPvN; ++j) {
+      hann[(size_t)j] = (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * j / kPvN));
+      hann_sc[(size_t)j] = hann[(size_t)j] * fold_scale(kPvN);  // exact: a power of two
+    }
+    std::vector<float2> wsplit((size_t)kPvM);
+    for (int c = 0; c < kPvM; ++c) {
+      const double ang = 2.0 * 3.14159265358979323846 * c / kPvN;
+      wsplit[(size_t)c] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    if (e == hipSuccess) e = hipMemcpy(q.hann, hann.data(), kPvN * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(q.hann_scaled, hann_sc.data(), kPvN * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(q.wsplit, wsplit.data(), (size_t)kPvM * 8, hipMemcpyHostToDevice);
+  } catch (...) {
+    pv_release(ctx);
+    throw;
   }
-  std::vector<float2> wsplit((size_t)kPvM);
-  for (int c = 0; c < kPvM; ++c) {
-    const double ang = 2.0 * 3.14159265358979323846 * c / kPvN;
-    wsplit[(size_t)c] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-  }
-  if (e == hipSuccess) e = hipMemcpy(q.hann, hann.data(), kPvN * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(q.hann_scaled, hann_sc.data(), kPvN * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(q.wsplit, wsplit.data(), (size_t)kPvM * 8, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     pv_release(ctx);
     return fail(MX_ERR_DEVICE, "phase vocoder setup: %s", hipGetErrorString(e));

@@ -457,6 +457,13 @@ void device_entries() {
     const int rc = mx_pv_pitch_shift(ctx, a, 3.0, pf.data(), pi.data());
     return {rc, rc < 0 ? 0 : fnv(pi.data(), (size_t)n * 2, fnv(pf.data(), (size_t)n * 4))};
   });
+  sweep("mx_pv_pitch_shift (arena rebuilt)", [&]() -> Result {
+    // every call builds the arena anew: the pipe's construction (streams, events, host tables) is swept too, and a failure
+    // in the middle of it must not leave a half-built pipe for the next call to find
+    int rc = mx_ctx_release_scratch(ctx);
+    if (rc == MX_OK) rc = mx_pv_pitch_shift(ctx, a, 3.0, pf.data(), nullptr);
+    return {rc, rc < 0 ? 0 : fnv(pf.data(), (size_t)n * 4)};
+  });
   sweep("mx_pv_pitch_shift (chunks of 64)", [&]() -> Result {
     int rc = mx_pv_set_chunk_frames(ctx, 64);
     if (rc == MX_OK) rc = mx_pv_pitch_shift(ctx, a, 3.0, pf.data(), nullptr);
