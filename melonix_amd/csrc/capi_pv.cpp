@@ -890,7 +890,15 @@ static int pv_shard_analyze_core(mx_ctx *ctx, const mx_audio *a, double semitone
     run.totals_only = true;
     run.totmaps_sums = d_sums;
     run.totmaps_org = d_org;
-    rc = pv_run(ctx, *p, run);
+    try {
+      rc = pv_run(ctx, *p, run);
+    } catch (...) {
+      hipStreamSynchronize(p->ss);
+      hipStreamSynchronize(ctx->stream);
+      hipFree(own_sums);
+      hipFree(own_org);
+      throw;
+    }
     if (rc == MX_OK) {
       const uint32_t *rs = d_sums;
       const uint16_t *ro = d_org;
@@ -997,7 +1005,14 @@ static int pv_shard_synthesize_core(mx_ctx *ctx, const uint32_t *carry_host, con
   run.pcm_base = j.out_lo;
   run.out_lo = run.head_hi = j.out_lo;
   run.out_hi = run.tail_lo = j.out_hi;
-  int rc = pv_run(ctx, *p, run);
+  int rc;
+  try {
+    rc = pv_run(ctx, *p, run);
+  } catch (...) {  // (host containers inside: a failed allocation must not leave the job holding the PCM buffers it has just taken)
+    hipStreamSynchronize(sm);
+    pv_shard_drop(*p);
+    throw;
+  }
   // the seams, raw: this rank's sums into the N - Hs samples before its first complete hop (all zero on the first rank,
   // whose first hops are complete) and after its last hop
   if (rc == MX_OK) {
