@@ -77,6 +77,37 @@ def test_gpu_matches_oracle(gpu_ctx, pv, st):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("st,mix", [(3.0, False), (-5.0, True)])
+def test_gpu_two_minutes_match_the_oracle(gpu_ctx, pv, st, mix):
+    """The oracle comparison at a size where the recurrence is really two-level: two minutes = 26 759 frames at +3 st — 419 scan
+    chunks of 64 frames in 14 groups of 32 maps, 836 synthesis workgroups —, against the seconds-long signals of the tests
+    above (11 scan chunks, one group).  Same tolerance: 2e-5 of full scale.  (The definition is a numpy program over whole
+    arrays: ~20 s and ~1.5 GB for two minutes, which is why the hour is checked by properties and shape independence instead.)"""
+    n = 120 * SR
+    w = accum_sweep(n)
+    if mix:
+        t = np.arange(n) / SR
+        w = (0.6 * w + 0.2 * np.sin(2 * np.pi * 554.37 * t) + 0.05 * np.sin(2 * np.pi * 3000.0 * t)).astype(np.float32)
+    a = gpu_ctx.upload(w)
+    try:
+        f32, i16 = gpu_ctx.pv_pitch_shift(a, st)
+        assert gpu_ctx.pv_last_chunks() == 1
+        ref = pv.pitch_shift(w.astype(np.float64), st)
+        err = np.abs(f32 - ref)
+        assert f32.shape == ref.shape and err.max() <= 2e-5, float(err.max())
+        want16 = (np.clip(f32, -1.0, 1.0).astype(np.float64) * 32767.0).astype(np.int16)
+        assert np.array_equal(i16, want16)
+        # ... and the same samples through chunks that cut the recurrence's groups (7 chunks of 4096 frames)
+        gpu_ctx.pv_set_chunk_frames(4096)
+        g32, _ = gpu_ctx.pv_pitch_shift(a, st, want_i16=False)
+        assert np.array_equal(g32.view(np.uint32), f32.view(np.uint32))
+    finally:
+        gpu_ctx.pv_set_chunk_frames(0)
+        gpu_ctx.release_scratch()
+        a.free()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 5, 300, 4096, 8191, 8192 + 17, 33 * 256 + 3])
 def test_gpu_short_inputs(gpu_ctx, pv, n):
     """Fewer frames than one synthesis workgroup walks, one frame, sizes around the block and hop sizes."""
