@@ -77,13 +77,14 @@ def test_gpu_matches_oracle(gpu_ctx, pv, st):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("st,mix", [(3.0, False), (-5.0, True)])
-def test_gpu_two_minutes_match_the_oracle(gpu_ctx, pv, st, mix):
-    """The oracle comparison at a size where the recurrence is really two-level: two minutes = 26 759 frames at +3 st — 419 scan
-    chunks of 64 frames in 14 groups of 32 maps, 836 synthesis workgroups —, against the seconds-long signals of the tests
-    above (11 scan chunks, one group).  Same tolerance: 2e-5 of full scale.  (The definition is a numpy program over whole
-    arrays: ~20 s and ~1.5 GB for two minutes, which is why the hour is checked by properties and shape independence instead.)"""
-    n = 120 * SR
+@pytest.mark.parametrize("st,mix,seconds", [(3.0, False, 120), (-5.0, True, 120), (3.0, False, 600)])
+def test_gpu_minutes_match_the_oracle(gpu_ctx, pv, st, mix, seconds):
+    """The oracle comparison at sizes where the recurrence is really two-level: two minutes = 26 759 frames at +3 st — 419 scan
+    chunks of 64 frames in 14 groups of 32 maps, 836 synthesis workgroups —, and ten minutes = 133 787 frames — the full 1536
+    scan chunks (88 frames each) in 48 groups —, against the seconds-long signals of the tests above (11 scan chunks, one
+    group).  Same tolerance: 2e-5 of full scale.  (The definition is a numpy program over whole arrays — 7 GB for ten minutes —
+    with a Python loop over the frames; the hour against it: tests/tools/pv_hour_vs_oracle.py, profiles/pv_hour_vs_oracle_r06.log.)"""
+    n = seconds * SR
     w = accum_sweep(n)
     if mix:
         t = np.arange(n) / SR
