@@ -681,6 +681,32 @@ def test_gpu_marker_render_matches_oracle(gpu_ctx, pv, mk):
     a.free()
 
 
+@pytest.mark.gpu
+def test_gpu_marker_render_two_minutes_matches_oracle(gpu_ctx, pv):
+    """The marker-driven render at a size where its plan rows travel through several chunks and the recurrence is two-level:
+    two minutes, five markers (stretch, squeeze, bends that ramp up and down), resident and in chunks of 2048 frames — both
+    within 5e-5 of the oracle's render and equal to each other bit for bit."""
+    n = 120 * SR
+    t = np.arange(n) / SR
+    w = (0.7 * accum_sweep(n) + 0.1 * np.sin(2 * np.pi * 2500.0 * t)).astype(np.float32)
+    mk = [(SR, 0, 0.0, 2.0), (30 * SR, 0, -1.5, -3.0), (60 * SR, 0, 2.0, 5.0), (90 * SR, 0, 0.5, -1.0), (n - 1, 0, 0, 0)]
+    a = gpu_ctx.upload(w)
+    try:
+        f32, i16 = gpu_ctx.pv_render(a, SR, mk)
+        assert gpu_ctx.pv_last_chunks() == 1
+        ref = pv.render(w.astype(np.float64), SR, mk)
+        assert f32.shape == ref.shape and len(ref) > n  # (the markers stretch by one second net)
+        assert np.abs(f32 - ref).max() <= 5e-5, float(np.abs(f32 - ref).max())
+        assert np.array_equal(i16, (np.clip(f32, -1.0, 1.0).astype(np.float64) * 32767.0).astype(np.int16))
+        gpu_ctx.pv_set_chunk_frames(2048)
+        g32, _ = gpu_ctx.pv_render(a, SR, mk, want_i16=False)
+        assert gpu_ctx.pv_last_chunks() >= 8 and np.array_equal(g32.view(np.uint32), f32.view(np.uint32))
+    finally:
+        gpu_ctx.pv_set_chunk_frames(0)
+        gpu_ctx.release_scratch()
+        a.free()
+
+
 _UNALIGNED_OUTPUTS = r"""
 import ctypes as C, os, sys
 import numpy as np
