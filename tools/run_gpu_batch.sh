@@ -3,11 +3,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 2700 -- 'bash tools/run_gpu_batch.sh'
 set -u
 mkdir -p gpurun_out
-for pass in 1 2; do
-  MX_FAULT_LOG=gpurun_out/fault_sweep_r06_device.log MX_RCCL_LOG=gpurun_out/rccl_r06.log timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/gpu_suite_pass$pass.log
-  tail -3 gpurun_out/gpu_suite_pass$pass.log
-done
-bash tools/profile_gpu.sh r06 > gpurun_out/profile_r06.log 2>&1; tail -14 gpurun_out/prof_r06_summary.txt
+MX_FAULT_LOG=gpurun_out/fault_sweep_r06_device.log MX_RCCL_LOG=gpurun_out/rccl_r06.log timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -5
 python bench.py > gpurun_out/bench_check.json 2> gpurun_out/bench_check.err
 python - <<'PY'
 import json
