@@ -41,8 +41,7 @@
 //                 hop); after each frame the oldest hop is complete and leaves as one 1 KiB store, normalised by
 //                 sum w^2 = 3N/(8 Hs).  Only the N - Hs samples either side of a workgroup boundary see two workgroups:
 //                 the left one leaves its partial sums in s, the right one in a halo buffer
-//   pv_fixup      finishes the two outer boundaries of a range in place; the interior ones are finished where the resamplers read
-//                 them (pv_s: left workgroup's raw sums + right workgroup's halo, in frame order: deterministic, no atomics)
+//   pv_fixup      adds the halo to s across each boundary (in frame order: deterministic, no atomics)
 //   pv_resample   linear interpolation at i*r -> f32 / int16 PCM (pv_resample_frames: the marker-driven variant,
 //                 where each frame carries its own warped time and ratio and owns a range of output samples)
 // One rank of a multi-GPU run executes the same kernels on its range of frames in three stages
@@ -958,19 +957,18 @@ __global__ __launch_bounds__(PV::T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     reinterpret_cast<float2 *>(a.s + (f1 - a.first) * kPvHs)[t_ + P::T * j] = make_float2(acc[j].x, acc[j].y);
 }
 
-// Boundary b (0..nb): s over [f0_b*Hs, f0_b*Hs + N - Hs) holds the left workgroup's raw sums (none at b = 0); the right
-// workgroup's halo is added (none at b = nb) and the sum normalised.  The INTERIOR boundaries (0 < b < nb) are finished where
-// they are read — pv_s below, inside the resamplers: round 6; a kernel of its own used to rewrite 47 % of s for them —; this
-// kernel finishes the two OUTER ones in place, where the missing side comes from somewhere else: the previous chunk's finished
-// samples or the previous rank's tail at b = 0, the next chunk's / rank's head at b = nb (the overlap-add seams of SURVEY 8e(3)).
+// Boundary b (0..nb): s over [f0_b*Hs, f0_b*Hs + N - Hs) holds the left workgroup's raw sums (none at b = 0); add the
+// right workgroup's halo (none at b = nb) and normalise.  Across ranks (multi-GPU) the missing side comes from the
+// neighbour: prev_tail at b = 0, next_head at b = nb — the overlap-add seams of SURVEY 8e(3).
 __global__ __launch_bounds__(256) void pv_fixup(const PvArgs a) {
   using f32x4 = float __attribute__((ext_vector_type(4)));
   const int64_t fs = a.frames - a.first;
   const int64_t nb = pv_blocks(fs);
+  // boundary and offset both come from blockIdx.x (gridDim.y stops at 65535: 2.1 M frames, an hour at +20 semitones);
   // four samples per thread (s, the halos and the seams are 16-byte aligned: arena offsets, multiples of the hop)
   static_assert(kPvHalo % 4 == 0, "whole 16-byte pieces");
   constexpr int kPerB = (kPvHalo / 4 + 255) / 256;
-  const int64_t b = (blockIdx.x / kPerB) == 0 ? 0 : nb;
+  const int64_t b = (int64_t)(blockIdx.x / kPerB);
   const int i = ((int)(blockIdx.x % kPerB) * 256 + threadIdx.x) * 4;
   if (i >= kPvHalo) return;
   if ((b == 0 && a.skip_head) || (b == nb && a.skip_tail)) return;
@@ -985,22 +983,11 @@ __global__ __launch_bounds__(256) void pv_fixup(const PvArgs a) {
     *reinterpret_cast<f32x4 *>(a.s + i) = v * kPvNorm;
     return;
   }
-  f32x4 v = *reinterpret_cast<const f32x4 *>(a.s + fs * kPvHs + i);
-  if (a.next_head) v += *reinterpret_cast<const f32x4 *>(a.next_head + i);
-  *reinterpret_cast<f32x4 *>(a.s + fs * kPvHs + i) = v * kPvNorm;
-}
-
-// Stretched sample q of the range (index into a.s), finished: inside the N - Hs samples behind an interior synthesis-workgroup
-// boundary s holds the left workgroup's raw sums — the right workgroup's halo is added and the sum normalised here, exactly
-// as pv_fixup did in place ((s + halo) * 1/sum w^2: the same two roundings); everywhere else s is final as it is.  `nb1`:
-// the last interior boundary (pv_blocks - 1; 0 where the caller's s is a plain buffer: a rank's edge rows).
-__device__ __forceinline__ float pv_s(const PvArgs &a, int64_t q, int64_t nb1) {
-  const float v = a.s[q];
-  const int64_t blk = q >> 13;
-  const int within = (int)(q & 8191);
-  static_assert(kPvBlockFrames * kPvHs == 8192, "a synthesis workgroup's hops are 8192 stretched samples");
-  if (blk >= 1 && blk <= nb1 && within < kPvHalo) return (v + a.halo[(size_t)blk * kPvHalo + within]) * kPvNorm;
-  return v;
+  const int64_t fb = b == nb ? fs : b * kPvBlockFrames;
+  f32x4 v = *reinterpret_cast<const f32x4 *>(a.s + fb * kPvHs + i);
+  if (b < nb) v += *reinterpret_cast<const f32x4 *>(a.halo + (size_t)b * kPvHalo + i);
+  else if (a.next_head) v += *reinterpret_cast<const f32x4 *>(a.next_head + i);
+  *reinterpret_cast<f32x4 *>(a.s + fb * kPvHs + i) = v * kPvNorm;
 }
 
 // Four consecutive output samples per thread: the two outputs leave as 16- and 8-byte stores (a wavefront's 4- and 2-byte
@@ -1017,7 +1004,6 @@ __global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
   const int64_t e0 = pv_resample_start(a) + ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   const int64_t e_lo = a.out_lo - a.pcm_base, e_hi = a.out_hi - a.pcm_base;
   if (e0 >= e_hi) return;
-  const int64_t nb1 = a.halo ? pv_blocks(a.frames - a.first) - 1 : 0;
   float v[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -1028,7 +1014,7 @@ __global__ __launch_bounds__(256) void pv_resample(const PvArgs a) {
     const double fl = floor(pos);
     const int64_t m = (int64_t)fl - a.s_origin;  // s[0] is stretched sample s_origin of the whole signal
     const float tt = (float)(pos - fl);
-    v[q] = (1.0f - tt) * pv_s(a, m, nb1) + tt * pv_s(a, m + 1, nb1);
+    v[q] = (1.0f - tt) * a.s[m] + tt * a.s[m + 1];
   }
   int16_t w[4];
 #pragma unroll
@@ -1068,13 +1054,12 @@ __global__ __launch_bounds__(256) void pv_resample_frames(const PvArgs a) {
   const int64_t j = blockIdx.x, f = a.frame_base + j;
   const int64_t lo = a.i0[j], hi = a.i0[j + 1];
   const double tf = a.tf[j], rs = a.rf[j] * (double)a.sample_rate, sr = (double)a.sample_rate;
-  const int64_t nb1 = a.halo ? pv_blocks(a.frames - a.first) - 1 : 0;
   for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
     const double pos = (double)(f * kPvHs) + ((double)i / sr - tf) * rs + (double)(kPvN / 2);
     const double fl = floor(pos);
     const int64_t m = (int64_t)fl - a.s_origin;
     const float tt = (float)(pos - fl);
-    const float v = (1.0f - tt) * pv_s(a, m, nb1) + tt * pv_s(a, m + 1, nb1);
+    const float v = (1.0f - tt) * a.s[m] + tt * a.s[m + 1];
     if (a.pcm_f32) a.pcm_f32[i - a.pcm_base] = v;
     if (a.pcm_i16) {
       const float c = v < -1.f ? -1.f : (1.f < v ? 1.f : v);
@@ -1188,8 +1173,10 @@ hipError_t launch_pv_synthesize(const PvArgs &a, hipStream_t s) {
 }
 hipError_t launch_pv_finish(const PvArgs &a, hipStream_t s) {
   if (a.frames - a.first <= 0) return hipSuccess;
+  const int64_t nb = pv_blocks(a.frames - a.first);
   constexpr int kPerB = (kPvHalo / 4 + 255) / 256;
-  hipLaunchKernelGGL(pv_fixup, dim3(2u * kPerB), dim3(256), 0, s, a);  // (the two outer boundaries; the interior ones: pv_s)
+  if ((nb + 1) * (int64_t)kPerB > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pv_fixup, dim3((unsigned)((nb + 1) * kPerB)), dim3(256), 0, s, a);
   if (a.i0)  // marker-driven: one workgroup per frame
     hipLaunchKernelGGL(pv_resample_frames, dim3((unsigned)(a.frames - a.first)), dim3(256), 0, s, a);
   else if (a.out_hi > a.out_lo)
