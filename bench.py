@@ -17,8 +17,11 @@ left pad, no data-path collective; the one exchange is an all-gather of the pitc
 `value` is the contract's own region and nothing else: W untimed warm-up steps, then K timed steps between
 barrier + synchronize pairs, the first thing the process does with the device after its setup.  Everything
 else in the line is a labelled secondary measured afterwards (`value_conditioned`, `noise_input_secondary`,
-`pcm_gather_secondary`, the supplementary figures, `cpu_baseline`).  Under WORLD_SIZE > 1 the line carries
-`ranks`: every rank's own kernel times, package power, shader clock and PCI address.
+`pcm_gather_secondary`, `pv_shard_secondary`, the supplementary figures, `cpu_baseline`).  Under WORLD_SIZE > 1 the line
+carries `ranks` — every rank's own kernel times, package power, shader clock and PCI address — and `pv_shard_secondary`:
+the build-defined phase vocoder sharded over the ranks, whose two small all-gathers (phase maps, overlap-add seams) are the
+seam exchange BASELINE.json's north_star names; per-rank stage and all-gather times, output checked against
+the single call.
 """
 from __future__ import annotations
 
