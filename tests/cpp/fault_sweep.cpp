@@ -10,6 +10,8 @@
 // fault is lost.
 //
 //   fault_sweep host      the entry points that need no device (time maps, grains, schedules, the PV plan, the WAV writer)
+//   fault_sweep host-malloc / device-malloc   (built with -DSWEEP_MALLOC, no sanitizer) the same sweeps with the faults in the
+//                         library's own malloc() calls — the arrays it hands out for mx_free — instead of operator new
 //   fault_sweep device    ... and those that do (context, audio, STFT in all modes, kept rows, grain table, resynthesis,
 //                         export, phase vocoder incl. the three rank stages, pyramid): only allocations made FROM the
 //                         library's own code are faulted there (the HIP runtime beneath it is not the subject)
@@ -35,13 +37,21 @@ thread_local long g_fail_at = 0;       // fail the g_fail_at-th eligible allocat
 thread_local long g_seen = 0;          // eligible allocations of the call so far
 thread_local bool g_fired = false;
 bool g_only_library_callers = false;   // device mode: only allocations whose caller is code of libmelonix_amd.so
+bool g_fault_malloc = false;           // "malloc" modes: the faults go into the library's own malloc() calls instead of operator new
 
 bool from_library(void *ret) {
   Dl_info info;
   return dladdr(ret, &info) && info.dli_fname && strstr(info.dli_fname, "libmelonix_amd");
 }
-bool should_fail(void *ret) {
-  if (!g_in_call || g_fail_at <= 0 || g_fired) return false;
+bool should_fail(void *ret, bool is_malloc = false) {
+  if (!g_in_call || g_fail_at <= 0 || g_fired || is_malloc != g_fault_malloc) return false;
+  if (is_malloc) {  // the library's own output arrays (mx_free'd by the caller): only calls made from its code
+    const bool was = g_in_call;
+    g_in_call = false;
+    const bool lib = from_library(ret);
+    g_in_call = was;
+    if (!lib) return false;
+  }
   if (g_only_library_callers) {
     const bool was = g_in_call;
     g_in_call = false;  // (dladdr may allocate)
@@ -99,6 +109,17 @@ void operator delete(void *p, std::size_t, std::align_val_t) noexcept { std::fre
 void operator delete[](void *p, std::size_t, std::align_val_t) noexcept { std::free(p); }
 void operator delete(void *p, const std::nothrow_t &) noexcept { std::free(p); }
 void operator delete[](void *p, const std::nothrow_t &) noexcept { std::free(p); }
+
+#ifdef SWEEP_MALLOC
+// (a build without sanitizers: malloc itself is replaced — glibc keeps the real one reachable as __libc_malloc)
+extern "C" {
+void *__libc_malloc(size_t);
+void *malloc(size_t n) {
+  if (should_fail(__builtin_return_address(0), true)) return nullptr;
+  return __libc_malloc(n);
+}
+}
+#endif
 
 // ---- the sweep -----------------------------------------------------------------------------------------------------------------
 namespace {
@@ -555,8 +576,15 @@ int main(int argc, char **argv) {
     return 0;
   }
   printf("fault_sweep %s against %s\n", mode.c_str(), mx_version());
+  if (mode == "host-malloc" || mode == "device-malloc") {
+#ifndef SWEEP_MALLOC
+    fprintf(stderr, "built without -DSWEEP_MALLOC\n");
+    return 2;
+#endif
+    g_fault_malloc = true;
+  }
   host_entries();
-  if (mode == "device") {
+  if (mode == "device" || mode == "device-malloc") {
     g_only_library_callers = true;
     device_entries();
   }

@@ -78,6 +78,21 @@ def test_allocation_fault_sweep_host_entry_points_under_asan(mxlib, tmp_path):
         assert mm and int(mm.group(1)) >= at_least, (name, tail)
 
 
+def test_malloc_fault_sweep_host_entry_points(mxlib, tmp_path):
+    """The same sweep with the faults in the library's own malloc() calls — the arrays it hands out for mx_free (grains,
+    schedules, the phase-vocoder plan) —: built with -DSWEEP_MALLOC (malloc itself replaced; no sanitizer under it), every
+    failed malloc made from the library's code gives MX_ERR_NOMEM with a message and untouched outputs."""
+    exe = _build_sweep(tmp_path, ["-DSWEEP_MALLOC"])
+    r = subprocess.run([exe, "host-malloc"], capture_output=True, text=True, timeout=600)
+    tail = r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0, tail
+    m = re.search(r"fault_sweep host-malloc: (\d+) faults injected, 0 failed checks", r.stdout)
+    assert m and int(m.group(1)) >= 9 and "FAIL " not in r.stderr, tail
+    for name, n in (("mx_grains", 2), ("mx_schedule_build", 1), ("mx_schedule_build_table", 1), ("mx_pv_plan", 4)):
+        mm = re.search(r"^\s+" + name + r"\s+(\d+) allocation", r.stdout, flags=re.M)
+        assert mm and int(mm.group(1)) == n, (name, tail)
+
+
 @pytest.mark.gpu
 def test_allocation_fault_sweep_device_entry_points(mxlib, tmp_path):
     """All entry points on the GPU box: allocations made from the library's own code fail one by one (the HIP runtime's own are
@@ -93,7 +108,14 @@ def test_allocation_fault_sweep_device_entry_points(mxlib, tmp_path):
     for name in ("mx_ctx_create / destroy", "mx_stft_hop", "mx_stft_ranges_keep / rows", "mx_grain_table_dev", "mx_resynth_to_wav",
                  "mx_pv_pitch_shift", "mx_pv_render", "mx_pv_shard_* (rank 1 of 2)", "mx_minmax_pyramid"):
         assert re.search(r"^\s+" + re.escape(name) + r"\s+\d+ allocation", r.stdout, flags=re.M), (name, tail)
+    # ... and the library's own malloc() calls on the device paths (the grain table's arrays)
+    exe_m = _build_sweep(tmp_path, ["-DSWEEP_MALLOC"])
+    rm = subprocess.run([exe_m, "device-malloc"], capture_output=True, text=True, timeout=1500)
+    tail_m = rm.stdout[-4000:] + rm.stderr[-3000:]
+    assert rm.returncode == 0, tail_m
+    mm = re.search(r"fault_sweep device-malloc: (\d+) faults injected, 0 failed checks", rm.stdout)
+    assert mm and int(mm.group(1)) >= 12, tail_m
     log = os.environ.get("MX_FAULT_LOG")
     if log:
         with open(log, "w") as f:
-            f.write(r.stdout)
+            f.write(r.stdout + rm.stdout)

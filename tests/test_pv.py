@@ -388,6 +388,41 @@ def test_gpu_arena_follows_its_budget(gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_random_budgets_lengths_and_shifts(gpu_ctx):
+    """Property: whatever the budget (3.5 MiB .. resident), the signal's length and the shift, the arena stays inside the
+    budget, the call is cut as the policy says (one chunk iff the resident shape fits) and the samples are those of the
+    resident run, bit for bit — also for the marker-driven render."""
+    rng = np.random.default_rng(20260930)
+    try:
+        for case in range(12):
+            n = int(rng.integers(20000, 700000))
+            st = float(np.round(rng.uniform(-12.0, 12.0), 2))
+            t = np.arange(n) / SR
+            w = (0.4 * np.sin(2 * np.pi * (200.0 + 700.0 * t) * t) + 0.1 * np.sin(2 * np.pi * 1234.5 * t) + 0.01 * rng.uniform(-1, 1, n)).astype(np.float32)
+            a = gpu_ctx.upload(w)
+            gpu_ctx.pv_set_arena_budget(0)
+            gpu_ctx.release_scratch()
+            whole_f, whole_i = gpu_ctx.pv_pitch_shift(a, st)
+            assert gpu_ctx.pv_last_chunks() == 1
+            resident = gpu_ctx.pv_arena_bytes()
+            mk = [(n // 5, 0, 0.1, 2.0), (n // 2, 0, -0.15, -4.0), (n - 1, 0, 0, 0)]
+            whole_r, _ = gpu_ctx.pv_render(a, SR, mk, want_i16=False)
+            for _ in range(3):
+                budget = int(rng.integers(4 << 20, max(resident + (8 << 20), 6 << 20)))
+                gpu_ctx.pv_set_arena_budget(budget)
+                f, i = gpu_ctx.pv_pitch_shift(a, st)
+                assert gpu_ctx.pv_arena_bytes() <= budget, (case, budget)
+                assert (gpu_ctx.pv_last_chunks() == 1) == (budget >= resident), (case, budget, resident, gpu_ctx.pv_last_chunks())
+                assert np.array_equal(f.view(np.uint32), whole_f.view(np.uint32)) and np.array_equal(i, whole_i), (case, n, st, budget)
+                r_, _ = gpu_ctx.pv_render(a, SR, mk, want_i16=False)
+                assert gpu_ctx.pv_arena_bytes() <= budget and np.array_equal(r_.view(np.uint32), whole_r.view(np.uint32)), (case, budget)
+            a.free()
+    finally:
+        gpu_ctx.pv_set_arena_budget(0)
+        gpu_ctx.release_scratch()
+
+
+@pytest.mark.gpu
 def test_gpu_compact_records_and_their_overflow(gpu_ctx, monkeypatch):
     """The peak records are packed: an analysis workgroup's frames one behind the other in a region of 512 entries per frame (a
     quarter of a frame's worst case), recoff[f] says where — 22 instead of 34 KiB per frame of arena.  A signal with more peaks
