@@ -544,6 +544,60 @@ def test_gpu_sharded_on_device_equals_whole(gpu_ctx, world, budget_mb):
 
 
 @pytest.mark.gpu
+def test_gpu_sharded_on_device_random_worlds_budgets_and_shifts(gpu_ctx):
+    """Property over the part no box here can run on real hardware: for random world sizes (2..7), signal lengths, shifts and
+    per-rank budgets (resident ranges and chunked ones in one job), the device-pointer stages — gathered maps folded into the
+    carry on the device, gathered seams — give slices that concatenate to the single call, bit for bit, f32 and int16."""
+    import melonix_amd as mx
+    from melonix_amd import shard as sh
+    from conftest import DevBuf
+    rng = np.random.default_rng(77)
+    for case in range(8):
+        world = int(rng.integers(2, 8))
+        n = int(rng.integers(world * 40 * 256, 900000))
+        st = float(np.round(rng.uniform(-9.0, 9.0), 2))
+        t = np.arange(n) / SR
+        w = (0.4 * np.sin(2 * np.pi * (150.0 + 500.0 * t) * t) + 0.15 * np.sin(2 * np.pi * 987.6 * t) + 0.01 * rng.uniform(-1, 1, n)).astype(np.float32)
+        a = gpu_ctx.upload(w)
+        whole_f, whole_i = gpu_ctx.pv_pitch_shift(a, st)
+        a.free()
+        try:
+            rngs = [mx.pv_shard_frames(n, st, r, world) for r in range(world)]
+        except mx.MxError:
+            continue  # (a rank would get fewer than 32 frames at this ratio: not a job the library accepts)
+        ctxs = [mx.Context(0) for _ in range(world)]
+        bufs = []
+        try:
+            for c in ctxs:  # (half the ranks on the default budget — resident —, half on one a few chunks long)
+                c.pv_set_arena_budget(0 if rng.random() < 0.5 else int(rng.integers(4 << 20, 12 << 20)))
+            auds = [c.upload(w) for c in ctxs]
+            maps = DevBuf(world * sh.PV_MAP_BYTES)
+            seams = DevBuf(world * sh.PV_SEAM_BYTES, fill=0x7f)
+            f32 = [DevBuf(4 * (hi - lo), fill=0xff) for _, _, lo, hi in rngs]
+            i16 = [DevBuf(2 * (hi - lo), fill=0x55) for _, _, lo, hi in rngs]
+            bufs = [maps, seams] + f32 + i16
+            order = list(rng.permutation(world))  # (the stages of different ranks in any order: only the gathers order them)
+            for r in order:
+                ctxs[r].pv_shard_analyze_dev(auds[r], st, r, world, maps.ptr + r * sh.PV_MAP_BYTES)
+            for r in list(rng.permutation(world)):
+                ctxs[r].pv_shard_synthesize_dev(maps.ptr, f32[r].ptr, i16[r].ptr, seams.ptr + r * sh.PV_SEAM_BYTES)
+            for r in list(rng.permutation(world)):
+                ctxs[r].pv_shard_finish_dev(seams.ptr)
+            got_f = np.concatenate([b.read(np.uint32) for b in f32])
+            got_i = np.concatenate([b.read(np.int16) for b in i16])
+            assert rngs[0][2] == 0 and rngs[-1][3] == n
+            assert np.array_equal(got_f, whole_f.view(np.uint32)), (case, world, n, st)
+            assert np.array_equal(got_i, whole_i), (case, world, n, st)
+            for x in auds:
+                x.free()
+        finally:
+            for c in ctxs:
+                c.close()
+            for b in bufs:
+                b.free()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world,C", [(2, 64), (3, 32), (2, 1 << 13)])
 def test_gpu_sharded_chunked_equals_whole(gpu_ctx, world, C):
     """Ranks whose ranges are longer than a chunk (stage 1 keeps the maps only, stage 2 analyses again; the rank's edges
