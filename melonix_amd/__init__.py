@@ -333,15 +333,15 @@ class Context:
 
     # (the same stages with everything on the device: pointers are integers, e.g. torch tensors' data_ptr())
     def pv_shard_analyze_dev(self, audio: Audio, semitones: float, rank: int, world: int, d_map_out: int):
-        _capi.check(_capi.lib().mx_pv_shard_analyze_dev(self.handle, audio.handle, float(semitones), rank, world,
-                                                        C.c_void_p(d_map_out)))
+        _capi.check(_capi.lib().mx_pv_shard_analyze_dev(self.handle, audio.handle, float(semitones), int(rank), int(world),
+                                                        C.c_void_p(int(d_map_out))))
 
     def pv_shard_synthesize_dev(self, d_maps_all: int, d_f32: int | None, d_i16: int | None, d_seams_out: int):
-        _capi.check(_capi.lib().mx_pv_shard_synthesize_dev(self.handle, C.c_void_p(d_maps_all), C.c_void_p(d_f32 or 0),
-                                                           C.c_void_p(d_i16 or 0), C.c_void_p(d_seams_out)))
+        _capi.check(_capi.lib().mx_pv_shard_synthesize_dev(self.handle, C.c_void_p(int(d_maps_all)), C.c_void_p(int(d_f32 or 0)),
+                                                           C.c_void_p(int(d_i16 or 0)), C.c_void_p(int(d_seams_out))))
 
     def pv_shard_finish_dev(self, d_seams_all: int):
-        _capi.check(_capi.lib().mx_pv_shard_finish_dev(self.handle, C.c_void_p(d_seams_all)))
+        _capi.check(_capi.lib().mx_pv_shard_finish_dev(self.handle, C.c_void_p(int(d_seams_all))))
 
     def minmax_pyramid(self, audio: Audio):
         """App::calcPicks on the GPU -> list of (count_l, 2) float32 arrays {min,max}, one per level."""
