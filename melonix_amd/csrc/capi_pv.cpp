@@ -4,8 +4,8 @@
 //
 // The vocoder works inside a work arena with a memory BUDGET (round 6: mx_pv_set_arena_budget / MELONIX_PV_ARENA_MB; the
 // default is a quarter of what the device has free at the context's first phase-vocoder call).  A call whose frames fit the
-// budget is ONE chunk: its spectra stay resident between analysis and synthesis (one slot, 34 KiB per frame: 27.5 GB for an
-// hour at +3 st) and a rank of a multi-GPU run analyses its frames once.  What does not fit is walked CHUNK BY CHUNK, two
+// budget is ONE chunk: its spectra stay resident between analysis and synthesis (one slot, 22 KiB per frame with the compact
+// record regions below: 17.9 GB for an hour at +3 st) and a rank of a multi-GPU run analyses its frames once.  What does not fit is walked CHUNK BY CHUNK, two
 // slots alternating, with the longest chunk the budget holds (round 5: a fixed 32768 frames whatever was free; rounds 1-4 laid
 // the whole signal out at 41 KiB per frame and an 8-hour signal did not fit the GPU).  What one chunk hands the next is what one rank of a
 // multi-GPU run hands its neighbour (pv_kernels.hip, mx_pv_shard_*): the frame before the chunk is analysed again as its
@@ -35,8 +35,8 @@ constexpr int kPvSlots = 2;  // (three or four buy nothing: profiles/timeline_r0
 constexpr int kPvPlanRing = 4;  // chunk k + 3's plan rows are written while chunk k - 1's are long read
 constexpr int kPvOutRing = 4;  // chunk k's synthesis writes while chunk k - 2's fix-up reads k - 2, k - 1 (head) and k - 3 (boundary)
 // Peak records: every analysis workgroup packs its frames' records into a region of its own of kPvRecPerFrame x (its frames)
-// entries — a quarter of the 2048 a frame can have (an impulse, a frame of pure noise floor): sweeps and music have tens to a few
-// hundred peaks per frame.  A run whose signal does not fit raises the overflow flag and is repeated, once, with full regions
+// entries — a quarter of the 2048 a frame can have (an impulse): sweeps and music have tens to a few hundred peaks per frame,
+// white noise ~410.  A run whose signal does not fit raises the overflow flag and is repeated, once, with full regions
 // (kPvM per frame: cannot overflow); the context then stays with those until its scratch is released.
 constexpr int kPvRecPerFrame = 512;
 constexpr int kPvMinScan = 64;              // frames per scan chunk of the phase recurrence, at least

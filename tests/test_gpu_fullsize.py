@@ -386,7 +386,7 @@ def test_pv_hour_is_bit_for_bit_what_the_single_launch_gave():
 def test_pv_eight_hours_on_one_gpu_bounded_arena():
     """BASELINE configs[3]'s signal through the phase vocoder on ONE GPU (tests/tools/pv8h_check.py): rounds 1-4 needed
     ~260 GB of work buffers for it (41 KiB per frame, one allocation) and failed with MX_ERR_NOMEM; under the default budget
-    (a quarter of the free memory) it is walked in a handful of long chunks, under a 2.4 GB budget in ~200 short ones.
+    (a quarter of the free memory) it is walked in a handful of long chunks, under a 2.4 GB budget in ~120 short ones.
     Properties of the output (int16 = clamped f32, level kept, deterministic, the output's pitch track = the sweep's times
     2^(3/12) by this build's own STFT) and the multi-GPU path on the same signal: eight ranks (an hour each: configs[3]) played on this device through the
     device-pointer stages — resident ranges analysed ONCE, stage times against the single call's — equal it bit for bit."""

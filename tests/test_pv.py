@@ -425,7 +425,7 @@ def test_gpu_random_budgets_lengths_and_shifts(gpu_ctx):
 @pytest.mark.gpu
 def test_gpu_compact_records_and_their_overflow(gpu_ctx, monkeypatch):
     """The peak records are packed: an analysis workgroup's frames one behind the other in a region of 512 entries per frame (a
-    quarter of a frame's worst case), recoff[f] says where — 22 instead of 34 KiB per frame of arena.  A signal with more peaks
+    quarter of a frame's worst case), pkcount[f] carries count and place in one word — 22 instead of 34 KiB per frame of arena.  A signal with more peaks
     than that (an impulse train makes every bin a peak) raises the overflow flag: the call
     repeats itself once on full-size regions and the context stays with those until its scratch is released.  Outputs are
     those of a context laid out with full regions from the start (MELONIX_PV_FULL_RECORDS=1), bit for bit, either way."""

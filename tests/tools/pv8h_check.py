@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tests/tools/pv8h_check.py [hours] [world] — the phase vocoder over BASELINE configs[3]'s signal (8 h of 48 kHz audio, 6.4 M
 analysis frames at +3 st) on ONE GPU: the budgeted arena (default: a quarter of the free memory -> a handful of long chunks;
-2.4 GB -> ~200 short ones; same samples), properties of the output, and the multi-GPU path on the same signal — `world` ranks
+2.4 GB -> ~120 short ones; 170 GiB -> one resident chunk; same samples), properties of the output, and the multi-GPU path on the same signal — `world` ranks
 played by contexts on this device through the device-pointer stages (mx_pv_shard_*_dev): a range that fits the budget stays
 resident and is analysed ONCE, so a rank's three stages must cost about its share of the single call (<= 1.1 x, VERDICT r05
 item 1) — equal to the single call bit for bit.  Run by tests/test_gpu_fullsize.py in a process of its own."""
